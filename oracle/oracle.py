@@ -1,0 +1,168 @@
+"""ctypes binding of the CPU oracle (oracle/heston_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: may be imported by tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg -- never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libheston_oracle.so")
+
+EU, AM, DIV, AM_DIV = 0, 1, 2, 3
+_dp = C.POINTER(C.c_double)
+
+
+class _Params(C.Structure):
+    _fields_ = [
+        ("m1", C.c_int), ("m2", C.c_int), ("N", C.c_int), ("variant", C.c_int),
+        ("delta_t", C.c_double), ("theta", C.c_double),
+        ("r_d", C.c_double), ("r_f", C.c_double),
+        ("rho", C.c_double), ("sigma", C.c_double), ("kappa", C.c_double), ("eta", C.c_double),
+        ("num_dividends", C.c_int),
+        ("div_dates", _dp), ("div_amounts", _dp), ("div_percentages", _dp),
+    ]
+
+
+class _Dump(C.Structure):
+    _fields_ = [("step", C.c_int)] + [(k, _dp) for k in (
+        "b", "b1", "b2", "A0U", "A1U", "A2U", "Y0rhs", "Y1", "Y1rhs", "Unext")]
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "heston_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.ho_max_threads.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _f64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def make_params(m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, variant=EU,
+                dividends=None):
+    p = _Params()
+    p.m1, p.m2, p.N, p.variant = m1, m2, N, variant
+    p.delta_t, p.theta, p.r_d, p.r_f = delta_t, theta, r_d, r_f
+    p.rho, p.sigma, p.kappa, p.eta = rho, sigma, kappa, eta
+    keep = []
+    if dividends is not None:
+        dates, amounts, pcts = (_f64(x) for x in dividends)
+        keep = [dates, amounts, pcts]
+        p.num_dividends = len(dates)
+        p.div_dates, p.div_amounts, p.div_percentages = _p(dates), _p(amounts), _p(pcts)
+    else:
+        p.num_dividends = 0
+    p._keep = keep
+    return p
+
+
+def grid(m1, S, S_0, K, c, m2, V, V_0, d):
+    vs, vv = np.empty(m1 + 1), np.empty(m2 + 1)
+    ds, dv = np.empty(m1), np.empty(m2)
+    lib().ho_grid(C.c_int(m1), C.c_double(S), C.c_double(S_0), C.c_double(K), C.c_double(c),
+                  C.c_int(m2), C.c_double(V), C.c_double(V_0), C.c_double(d),
+                  _p(vs), _p(vv), _p(ds), _p(dv))
+    return vs, vv, ds, dv
+
+
+def rebuild_variance(m2, V_0_new, V=5.0, d=5.0 / 500):
+    vv, dv = np.empty(m2 + 1), np.empty(m2)
+    lib().ho_rebuild_variance(C.c_int(m2), C.c_double(V_0_new), C.c_double(V), C.c_double(d), _p(vv), _p(dv))
+    return vv, dv
+
+
+def find_s_index(vec_s, S_0):
+    return lib().ho_find_s_index(C.c_int(len(vec_s) - 1), _p(_f64(vec_s)), C.c_double(S_0))
+
+
+def find_v_index(vec_v, V_0):
+    return lib().ho_find_v_index(C.c_int(len(vec_v) - 1), _p(_f64(vec_v)), C.c_double(V_0))
+
+
+def solve(params, vec_s, vec_v, delta_s, delta_v, U, U_0=None, dump_step=0):
+    """One instance.  Returns (U_T, lambda_bar or None, dump dict or None)."""
+    m = (params.m1 + 1) * (params.m2 + 1)
+    U = _f64(U).copy()
+    U_0 = _f64(U_0)
+    lam = np.zeros(m) if params.variant in (AM, AM_DIV) else None
+    dump, arrs = None, None
+    if dump_step:
+        dump = _Dump()
+        dump.step = dump_step
+        arrs = {}
+        for k, _ in _Dump._fields_[1:]:
+            arrs[k] = np.zeros(m)
+            setattr(dump, k, _p(arrs[k]))
+    rc = lib().ho_solve(C.byref(params), _p(_f64(vec_s)), _p(_f64(vec_v)), _p(_f64(delta_s)), _p(_f64(delta_v)),
+                        _p(U), _p(U_0), _p(lam), C.byref(dump) if dump is not None else None)
+    if rc != 0:
+        raise RuntimeError("ho_solve failed rc=%d" % rc)
+    return U, lam, arrs
+
+
+def solve_batch(params, vec_s, vec_v, delta_s, delta_v, U, U_0=None, threads=0, want_lambda=False):
+    n = vec_s.shape[0]
+    U = _f64(U).copy()
+    U_0 = _f64(U_0)
+    lam = np.zeros_like(U) if (want_lambda and params.variant in (AM, AM_DIV)) else None
+    t = lib().ho_solve_batch(C.byref(params), C.c_int(n), _p(_f64(vec_s)), _p(_f64(vec_v)),
+                             _p(_f64(delta_s)), _p(_f64(delta_v)), _p(U), _p(U_0), _p(lam), C.c_int(threads))
+    return U, lam, t
+
+
+def base_prices(params, S_0, V_0, vec_s, vec_v, delta_s, delta_v, U, U_0=None, V=5.0, d=5.0 / 500, threads=0):
+    n = vec_s.shape[0]
+    U = _f64(U).copy()
+    vec_v, delta_v = _f64(vec_v).copy(), _f64(delta_v).copy()
+    out = np.empty(n)
+    rc = lib().ho_base_prices(C.byref(params), C.c_int(n), C.c_double(S_0), C.c_double(V_0), C.c_double(V),
+                              C.c_double(d), _p(_f64(vec_s)), _p(vec_v), _p(_f64(delta_s)), _p(delta_v),
+                              _p(U), _p(_f64(U_0)), _p(out), C.c_int(threads))
+    if rc != 0:
+        raise RuntimeError("ho_base_prices failed rc=%d" % rc)
+    return out, U
+
+
+def jacobian(params, S_0, V_0, vec_s, vec_v, delta_s, delta_v, U_0, eps=1e-6, V=5.0, d=5.0 / 500, threads=0):
+    n = vec_s.shape[0]
+    vec_v, delta_v = _f64(vec_v).copy(), _f64(delta_v).copy()
+    J, base = np.empty((n, 5)), np.empty(n)
+    rc = lib().ho_jacobian(C.byref(params), C.c_int(n), C.c_double(S_0), C.c_double(V_0), C.c_double(V),
+                           C.c_double(d), _p(_f64(vec_s)), _p(vec_v), _p(_f64(delta_s)), _p(delta_v),
+                           _p(_f64(U_0)), _p(J), _p(base), C.c_double(eps), C.c_int(threads))
+    if rc != 0:
+        raise RuntimeError("ho_jacobian failed rc=%d" % rc)
+    return J, base
+
+
+def lm_update(J, residuals, lam):
+    J, r = _f64(J), _f64(residuals)
+    delta = np.empty(5)
+    lib().ho_lm_update(C.c_int(J.shape[0]), _p(J), _p(r), C.c_double(lam), _p(delta))
+    return delta
+
+
+def max_threads():
+    return lib().ho_max_threads()
