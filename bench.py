@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline metric of BASELINE.json on MI355X:
+grid-points x timesteps / sec of the batched Douglas ADI sweep on a 512x256 grid, 1000 time steps.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--instances I]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch: hadi_DO_timestepping on `I` independent
+European calls per GPU (workload C2 of SURVEY.md 8(d): strikes 85..115, canonical Heston parameters),
+inputs already resident in HBM, including operator setup, layout pack/unpack and all 1000 time steps.
+Instances are sharded across ranks with no data-path collective (scaling: weak).
+
+Extra objects on the JSON line:
+  roofline      dominant kernel = hadi_pass_a (row pass).  achieved = 16 B x points per launch / mean launch
+                duration (HIP events on the library's stream, hadi_set_profiling) against the 8 TB/s HBM peak.
+                `sweep` repeats it for the whole Douglas step (32 B per point-step, both passes).
+  cpu_baseline  the CPU oracle (plain-C port of the reference's algorithm, OpenMP over instances) timed
+                on this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured float4 copy)
+B_ALG_PASS = 16.0            # algorithmic bytes per grid point per pass (read once + write once, fp64)
+B_ALG_STEP = 32.0            # per Douglas step: two directional passes
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--instances", type=int, default=256, help="option instances per GPU")
+    ap.add_argument("--m1", type=int, default=512)
+    ap.add_argument("--m2", type=int, default=256)
+    ap.add_argument("--timesteps", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import __graft_entry__ as G
+    G.build()
+    import pde_based_heston_solver_gpu_accelerated_amd as H
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world if world > 1 else 1
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    # ---- workload C2: this rank's shard of the strike ladder ---------------------------------------
+    S_0, V_0, T, r_d, r_f = 100.0, 0.04, 1.0, 0.025, 0.0
+    rho, sigma, kappa, eta, theta = -0.9, 0.3, 1.5, 0.04, 0.8
+    m1, m2, N, n_loc = args.m1, args.m2, args.timesteps, args.instances
+    n_glob = n_loc * n_gpus
+    all_strikes = [100.0] if n_glob == 1 else [85.0 + 30.0 * k / (n_glob - 1) for k in range(n_glob)]
+    strikes = all_strikes[rank * n_loc:(rank + 1) * n_loc]
+    grids_h = H.GridViewsBatch.for_strikes(m1, m2, S_0, V_0, strikes)
+    U0_h = grids_h.call_payoff(strikes)
+    grids = grids_h.to(dev)
+    U0 = torch.from_numpy(U0_h).to(dev)
+    U = torch.empty_like(U0)
+    m = (m1 + 1) * (m2 + 1)
+    solver = H.HestonADI(local_rank)
+
+    def step():
+        U.copy_(U0)  # workspace.U <- U_0 before every call (heston_calibration.cpp:216); D2D, part of the pass
+        torch.cuda.synchronize()
+        solver.DO_timestepping(m1, m2, N, T / N, theta, r_d, r_f, rho, sigma, kappa, eta, grids, U)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    sweep_ms = 0.0
+    for _ in range(args.steps):
+        step()
+        sweep_ms += solver.timing()["sweep_ms"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    units = float(n_glob) * m * N * args.steps
+    value = units / elapsed
+
+    # price sanity inside the bench: every rank checks its instance nearest K = 100 is a sane call price
+    k_mid = min(range(n_loc), key=lambda k: abs(strikes[k] - 100.0))
+    g = H.Grid(m1, 8 * strikes[k_mid], S_0, strikes[k_mid], strikes[k_mid] / 5, m2, 5.0, V_0, 5.0 / 500)
+    price_mid = float(U[k_mid, g.find_s_index(S_0) + g.find_v0_index(V_0) * (m1 + 1)].item())
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel, one extra profiled pass outside the timed region -----
+        solver.set_profiling(True)
+        step()
+        tm = solver.timing()
+        solver.set_profiling(False)
+        pts = float(n_loc) * m
+        a_ms = tm["pass_a_ms"] / max(1, tm["pass_a_launches"])
+        b_ms = tm["pass_b_ms"] / max(1, tm["pass_b_launches"])
+        ach_a = B_ALG_PASS * pts / (a_ms * 1e-3) / 1e9
+        ach_b = B_ALG_PASS * pts / (b_ms * 1e-3) / 1e9
+        ach_step = B_ALG_STEP * pts * N / (tm["sweep_ms"] * 1e-3) / 1e9
+        roofline = {
+            "bound": "hbm", "kernel": "hadi_pass_a<%d>" % (8 if m1 > 256 else 4 if m1 > 128 else 2 if m1 > 64 else 1),
+            "achieved": round(ach_a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_a / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "avg_launch_ms": round(a_ms, 5), "bytes_per_launch_algorithmic": B_ALG_PASS * pts,
+            "pass_b": {"achieved": round(ach_b, 1), "frac": round(ach_b / HBM_PEAK_GBS, 4), "avg_launch_ms": round(b_ms, 5)},
+            "sweep": {"achieved": round(ach_step, 1), "frac": round(ach_step / HBM_PEAK_GBS, 4),
+                      "bytes_per_point_step": B_ALG_STEP, "sweep_ms": round(tm["sweep_ms"], 3),
+                      "setup_ms": round(tm["setup_ms"], 3), "finish_ms": round(tm["finish_ms"], 3)},
+        }
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                key = "%dx%dx%d" % (m1, m2, n_loc)
+                if key in rec:
+                    roofline["traffic"] = rec[key]["pass_a_bytes_per_launch"]
+                    roofline["traffic_source"] = rec[key].get("source", "profiles/pmc_traffic.json")
+            except Exception:
+                pass
+
+        # ---- single-instance latency (the literal config[1]: ONE European call) ----------------------
+        g1 = H.GridViewsBatch.for_strikes(m1, m2, S_0, V_0, [100.0])
+        u1 = g1.call_payoff([100.0])
+        g1d = g1.to(dev)
+        u1d = torch.from_numpy(u1).to(dev)
+        w1 = torch.empty_like(u1d)
+        best = 1e30
+        for _ in range(3):
+            w1.copy_(u1d)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            solver.DO_timestepping(m1, m2, N, T / N, theta, r_d, r_f, rho, sigma, kappa, eta, g1d, w1)
+            best = min(best, time.perf_counter() - t1)
+        gi = H.Grid(m1, 800.0, S_0, 100.0, 20.0, m2, 5.0, V_0, 5.0 / 500)
+        price1 = float(w1[0, gi.find_s_index(S_0) + gi.find_v0_index(V_0) * (m1 + 1)].item())
+
+        # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores ------------
+        cpu = None
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as O
+            cores = O.max_threads()
+            n_cpu = max(1, min(cores, 64))
+            N_cpu = max(10, min(N, 60))
+            gs = H.GridViewsBatch.for_strikes(m1, m2, S_0, V_0, all_strikes[:n_cpu] if n_glob >= n_cpu else [100.0] * n_cpu)
+            u0c = gs.call_payoff(all_strikes[:n_cpu] if n_glob >= n_cpu else [100.0] * n_cpu)
+            p = O.make_params(m1, m2, N_cpu, T / N, theta, r_d, r_f, rho, sigma, kappa, eta, O.EU)
+            t1 = time.perf_counter()
+            _, _, used = O.solve_batch(p, gs.Vec_s, gs.Vec_v, gs.Delta_s, gs.Delta_v, u0c, threads=cores)
+            dt_cpu = time.perf_counter() - t1
+            cpu = {"value": n_cpu * m * N_cpu / dt_cpu, "unit": "point-steps/s", "cores": int(used), "kind": "port",
+                   "sample": "%d instances x %d of the %d time steps of the same %dx%d workload, OpenMP over instances, %.1f s wall"
+                             % (n_cpu, N_cpu, N, m1, m2, dt_cpu)}
+
+        info = solver.device_info()
+        out = {
+            "metric": "grid-points x timesteps/sec (ADI sweep), %dx%d grid" % (m1, m2),
+            "value": value, "unit": "point-steps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2: European calls, Heston Douglas ADI, %dx%d grid, %d time steps, %d strikes per GPU "
+                                   "(85..115), HBM-resident inputs" % (m1, m2, N, n_loc),
+                       "m1": m1, "m2": m2, "timesteps": N, "instances_per_gpu": n_loc, "instances_total": n_glob,
+                       "parallelism": "instances sharded over %d GPU(s), no collective" % n_gpus},
+            "effective_GBps": value * B_ALG_STEP / 1e9,
+            "sweep_only_point_steps_per_s": float(n_loc) * m * N * args.steps / (sweep_ms * 1e-3),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "single_instance": {"wall_ms": best * 1e3, "price": price1, "reference_price": 8.8942192888223310,
+                                "price_abs_err": abs(price1 - 8.8942192888223310)},
+            "price_check": {"strike": strikes[k_mid], "price": price_mid},
+            "device": info,
+        }
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    solver.close()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

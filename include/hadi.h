@@ -1,0 +1,182 @@
+/*
+ * hadi.h -- C ABI of libhadi: the MI355X-native batched Heston Douglas-ADI time stepper.
+ *
+ * Drop-in boundary for the hot path of BCW-dot/PDE-based-Heston-Solver-GPU-accelerated.
+ * The reference has no FFI: its hot path is reached through the host-callable batched
+ * launchers listed below (Kokkos templates).  Each entry point here takes, as flat arrays,
+ * exactly the data those launchers take as Kokkos Views / struct arrays
+ * (GridViews: grid_pod.hpp:8-15; DO_Workspace.U: DO_solver_workspace.hpp:7; U_0; dividend
+ * views; model / market / numerics scalars), so a maintainer can bind it from the reference
+ * host code with `view.data()` pointers -- see INTEGRATION.md.
+ *
+ *   hadi_DO_timestepping            <- device_DO_timestepping{,_american,_dividend,_american_dividend}
+ *                                      (src/device_solver.hpp:194-266, 274-374, 382-641, 650-942)
+ *                                      + Device_BoundaryConditions::initialize (hes_boundary_kernels.hpp:41-75)
+ *                                      + Device_A{0,1,2}::build_matrix (hes_a0_kernels.hpp:30,
+ *                                        hes_a1_kernels.hpp:51, hes_a2_shuffled_kernels.hpp:103)
+ *   hadi_parallel_DO_solve          <- parallel_DO_solve (src/device_solver.hpp:52-185)
+ *   hadi_compute_base_prices[_*]    <- compute_base_prices{,_american,_dividends,_american_dividends}
+ *                                      (src/jacobian_computation.cpp:368, 629, 922, 1232)
+ *   hadi_compute_jacobian[_*]       <- compute_jacobian{,_american,_dividends,_american_dividends}
+ *                                      (src/jacobian_computation.cpp:204, 457, 726, 1031)
+ *   hadi_compute_parameter_update   <- compute_parameter_update_on_device + solve_5x5_device
+ *                                      (src/jacobian_computation.cpp:20-195)
+ *   hadi_make_grid / hadi_rebuild_variance <- Grid::Grid (src/grid.cpp:16-61),
+ *                                      GridViews::rebuild_variance_views (src/grid_pod.hpp:25-73)
+ *
+ * Conventions
+ *   - All arithmetic is IEEE fp64.  Logical layout of every [n][m] field is the reference's:
+ *     idx = i + j*(m1+1), i = s-index (fastest), j = v-index, m = (m1+1)(m2+1)
+ *     (src/device_solver.cpp:713).  The library keeps its own internal HBM layout.
+ *   - Array arguments live in the memory space named by hadi_problem.memspace
+ *     (HADI_MEM_DEVICE: device pointers, data already resident in HBM; HADI_MEM_HOST: host
+ *     pointers, the library stages them).  Scalars, per-instance parameter overrides and the
+ *     dividend schedule are always host memory.  Outputs (base_prices, J) follow memspace.
+ *   - Every call is synchronous on the handle's stream (the reference fences before returning:
+ *     device_solver.hpp:184, jacobian_computation.cpp:363,447).  A handle is not thread-safe.
+ *   - Return value: HADI_OK or an error code; hadi_last_error() gives the message.  The
+ *     reference has `void` returns and silently reads index -1 when S_0 is not a grid node
+ *     (jacobian_computation.cpp:275-288); here that is HADI_ERR_NOT_ON_GRID.
+ *   - There is no CPU fallback: without a usable gfx950 device hadi_create fails.
+ */
+#ifndef HADI_H
+#define HADI_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HADI_VERSION_MAJOR 0
+#define HADI_VERSION_MINOR 1
+
+typedef struct hadi_ctx hadi_ctx;
+
+enum hadi_status {
+    HADI_OK = 0,
+    HADI_ERR_INVALID = 1,      /* bad argument (NULL, sizes, variant) */
+    HADI_ERR_UNSUPPORTED = 2,  /* grid shape outside what the kernels cover */
+    HADI_ERR_HIP = 3,          /* a HIP runtime call failed */
+    HADI_ERR_NOT_ON_GRID = 4,  /* S_0 is not a node of some instance's s-grid */
+    HADI_ERR_NO_DEVICE = 5,    /* no usable GPU: the product has no CPU path */
+    HADI_ERR_ALLOC = 6
+};
+
+enum hadi_variant { HADI_EU = 0, HADI_AM = 1, HADI_DIV = 2, HADI_AM_DIV = 3 };
+enum hadi_memspace { HADI_MEM_HOST = 0, HADI_MEM_DEVICE = 1 };
+
+/* One batch of independent option instances = one league of teams in the reference
+ * (TeamPolicy(nInstances, AUTO), device_solver.hpp:83-88). */
+typedef struct hadi_problem {
+    int n_instances;
+    int m1, m2;            /* grid intervals: (m1+1) s-nodes, (m2+1) v-nodes */
+    int variant;           /* enum hadi_variant */
+    int memspace;          /* enum hadi_memspace, applies to the array fields below */
+
+    /* time discretisation (shared); N_i / delta_t_i override per instance (multi-maturity,
+     * heston_calibration.cpp:2165-2171), host arrays of length n_instances or NULL */
+    int N;
+    double delta_t;
+    double theta;
+    const int *N_i;
+    const double *delta_t_i;
+
+    /* market + Heston parameters (shared across the batch in the reference,
+     * jacobian_computation.cpp:206-208); *_i override per instance (host arrays) or NULL */
+    double r_d, r_f;
+    double rho, sigma, kappa, eta;
+    const double *rho_i, *sigma_i, *kappa_i, *eta_i;
+
+    /* GridViews, one row per instance (grid_pod.hpp:9-15) */
+    const double *vec_s;   /* [n][m1+1] */
+    const double *vec_v;   /* [n][m2+1] */
+    const double *delta_s; /* [n][m1]   */
+    const double *delta_v; /* [n][m2]   */
+
+    /* discrete dividends, shared (device_solver.hpp:409-413); host arrays */
+    int num_dividends;
+    const double *dividend_dates, *dividend_amounts, *dividend_percentages;
+
+    /* DO_Workspace.U: in = initial condition, out = solution at T.  [n][m] */
+    double *U;
+    /* payoff for the American projection (U_0_i, device_solver.hpp:304); [n][m].
+     * NULL = use the initial U. */
+    const double *U_0;
+    /* optional output: lambda_bar at T (DO_solver_workspace.hpp:22); [n][m] or NULL */
+    double *lambda_bar;
+} hadi_problem;
+
+/* Timing of the last sweep on this handle, measured with HIP events on the handle's
+ * stream.  Kernel sums are only filled when profiling was enabled with hadi_set_profiling. */
+typedef struct hadi_timing {
+    double setup_ms;        /* staging + operator/boundary setup + layout pack */
+    double sweep_ms;        /* the N-step time loop only */
+    double finish_ms;       /* unpack + price pick */
+    double pass_a_ms;       /* sum over launches of the row-pass kernel   (profiling only) */
+    double pass_b_ms;       /* sum over launches of the column-pass kernel (profiling only) */
+    long long pass_a_launches, pass_b_launches;
+    long long point_steps;  /* sum over instances of (m1+1)(m2+1)*N_i */
+} hadi_timing;
+
+/* ---- handle ----------------------------------------------------------------------------- */
+int hadi_create(hadi_ctx **out, int device_id);
+int hadi_destroy(hadi_ctx *ctx);
+const char *hadi_last_error(const hadi_ctx *ctx);
+const char *hadi_status_string(int status);
+int hadi_version(void);
+int hadi_set_profiling(hadi_ctx *ctx, int enabled);
+int hadi_get_timing(const hadi_ctx *ctx, hadi_timing *out);
+/* Device the handle runs on: name, CU count, gcn arch string (for bench reports). */
+int hadi_device_info(const hadi_ctx *ctx, char *name, int name_len, int *compute_units, char *arch, int arch_len);
+/* Opaque hipStream_t of the handle (void*), so callers can order their own work after it. */
+void *hadi_stream(hadi_ctx *ctx);
+
+/* ---- grids (host code, no GPU needed) ------------------------------------------------------ */
+int hadi_make_grid(int m1, double S, double S_0, double K, double c,
+                   int m2, double V, double V_0, double d,
+                   double *vec_s, double *vec_v, double *delta_s, double *delta_v);
+int hadi_rebuild_variance(int m2, double V_0_new, double V, double d, double *vec_v, double *delta_v);
+int hadi_find_s_index(int m1, const double *vec_s, double S_0);  /* -1 if not a node */
+int hadi_find_v_index(int m2, const double *vec_v, double V_0);  /* 0 if not a node (grid_pod.hpp:76-87) */
+
+/* ---- the hot path -------------------------------------------------------------------------- */
+int hadi_DO_timestepping(hadi_ctx *ctx, const hadi_problem *p);
+
+int hadi_parallel_DO_solve(hadi_ctx *ctx, const hadi_problem *p, double S_0, double V_0,
+                           double *base_prices /* [n] */);
+
+/* v-grid rebuilt from (V_0, V = 5.0, d = 5.0/500) exactly as every call site of the reference
+ * does (jacobian_computation.cpp:253); p->vec_v / p->delta_v are ignored. */
+int hadi_compute_base_prices(hadi_ctx *ctx, const hadi_problem *p, double S_0, double V_0,
+                             double *base_prices);
+int hadi_compute_base_prices_american(hadi_ctx *ctx, const hadi_problem *p, double S_0, double V_0,
+                                      double *base_prices);
+int hadi_compute_base_prices_dividends(hadi_ctx *ctx, const hadi_problem *p, double S_0, double V_0,
+                                       double *base_prices);
+int hadi_compute_base_prices_american_dividends(hadi_ctx *ctx, const hadi_problem *p, double S_0,
+                                                double V_0, double *base_prices);
+
+/* J: [n][5], columns kappa, eta, sigma, rho, v0; forward differences with step eps.
+ * p->U is not used as input (the reference restarts every solve from U_0); p->U_0 is required. */
+int hadi_compute_jacobian(hadi_ctx *ctx, const hadi_problem *p, double S_0, double V_0, double eps,
+                          double *J, double *base_prices);
+int hadi_compute_jacobian_american(hadi_ctx *ctx, const hadi_problem *p, double S_0, double V_0,
+                                   double eps, double *J, double *base_prices);
+int hadi_compute_jacobian_dividends(hadi_ctx *ctx, const hadi_problem *p, double S_0, double V_0,
+                                    double eps, double *J, double *base_prices);
+int hadi_compute_jacobian_american_dividends(hadi_ctx *ctx, const hadi_problem *p, double S_0,
+                                             double V_0, double eps, double *J, double *base_prices);
+
+/* Levenberg-Marquardt normal equations on this rank's rows (host arrays):
+ * partial[0..24] = J^T J (row-major), partial[25..29] = J^T r, partial[30] = sum r^2.
+ * The 31 doubles are what gets all-reduced across GPUs. */
+int hadi_lm_partials(int n, const double *J, const double *residuals, double *partial31);
+/* delta = (J^T J with diagonal *(1+lambda))^-1 J^T r by 5x5 partial-pivot elimination. */
+int hadi_lm_solve(const double *partial31, double lambda, double *delta5);
+/* Both steps on one rank: compute_parameter_update_on_device. */
+int hadi_compute_parameter_update(int n, const double *J, const double *residuals, double lambda,
+                                  double *delta5);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HADI_H */

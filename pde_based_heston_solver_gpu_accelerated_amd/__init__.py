@@ -1,0 +1,14 @@
+"""MI355X-native batched Heston Douglas-ADI time stepper (libhadi) -- Python host mirror.
+
+Drop-in for the hot path of BCW-dot/PDE-based-Heston-Solver-GPU-accelerated:
+`parallel_DO_solve`, `compute_base_prices*`, `compute_jacobian*`, `device_DO_timestepping*`.
+The compute runs in hand-written HIP kernels for gfx950 behind the C ABI in include/hadi.h;
+this package only marshals arguments.  There is no CPU fallback.
+"""
+from ._native import EU, AM, DIV, AM_DIV, HadiError, LIB_PATH  # noqa: F401
+from .grid import Grid, GridViewsBatch  # noqa: F401
+from .solver import (HestonADI, DOWorkspace, Dividends, compute_parameter_update,  # noqa: F401
+                     lm_partials, lm_solve)
+
+__all__ = ["EU", "AM", "DIV", "AM_DIV", "HadiError", "Grid", "GridViewsBatch", "HestonADI", "DOWorkspace",
+           "Dividends", "compute_parameter_update", "lm_partials", "lm_solve", "LIB_PATH"]

@@ -1,0 +1,732 @@
+// hadi_api.hip -- host side of libhadi: handle, HBM buffers, launches.  C ABI in include/hadi.h.
+// There is deliberately no CPU compute path in this file: without a GPU hadi_create fails.
+#include "../../include/hadi.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "hadi_kernels.h"
+#include "hadi_plan.h"
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> kev;  // per-launch events (profiling)
+    int profiling = 0;
+    int cu_count = 256;
+    std::string name, arch;
+    std::string err;
+    hadi_timing timing{};
+    // grow-only device buffers
+    DevBuf U, Y, LAM, U0, UT;
+    DevBuf scoef, b2row, rowc, a2i, pb, rinv, rwork, ipar, par8;
+    DevBuf g_s, g_v, g_ds, g_dv;      // grids owned by the library (staged / broadcast)
+    DevBuf src_v, src_dv, sel_a, sel_b, v0_i;
+    DevBuf natU, natU0, natOut, prices, status;
+};
+
+int fail(Ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIP_TRY(c, call)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail((c), HADI_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                      \
+    } while (0)
+
+int ensure(Ctx *c, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return HADI_OK;
+    if (b.p) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    const size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(c, HADI_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+    }
+    b.cap = want;
+    return HADI_OK;
+}
+
+template <class T>
+T *ptr(DevBuf &b) {
+    return static_cast<T *>(b.p);
+}
+
+int grid1d(size_t n, int block = 256, int cap = 4096) {
+    size_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > (size_t)cap) g = cap;
+    return (int)g;
+}
+
+// ---- host grid code (grid.cpp:16-61, grid_pod.hpp:25-87) ---------------------------------------
+void sorted_insert_drop_largest(double *v, int n, double x0) {
+    // push_back(x0); sort; pop_back on an ascending array of n values
+    if (!(x0 < v[n - 1])) return;
+    int pos = 0;
+    while (pos < n && v[pos] <= x0) pos++;
+    for (int k = n - 1; k > pos; k--) v[k] = v[k - 1];
+    v[pos] = x0;
+}
+void build_v(int m2, double V_0, double V, double d, double *vec_v, double *delta_v) {
+    const double Delta_eta = (1.0 / m2) * std::asinh(V / d);
+    for (int i = 0; i <= m2; i++) vec_v[i] = d * std::sinh(i * Delta_eta);
+    sorted_insert_drop_largest(vec_v, m2 + 1, V_0);
+    for (int i = 0; i < m2; i++) delta_v[i] = vec_v[i + 1] - vec_v[i];
+}
+
+// ---- one batched sweep ----------------------------------------------------------------------------
+struct SweepDesc {
+    int n = 0;               // instances actually solved (6x the caller's for a Jacobian)
+    int m1 = 0, m2 = 0, variant = 0;
+    double theta = 0, r_d = 0, r_f = 0;
+    std::vector<double> par8;  // [n][8] rho sigma kappa eta dt N . .
+    int Nmax = 0;
+    bool uniform_steps = true;
+    double dt0 = 0;
+    const double *d_vec_s = nullptr, *d_vec_v = nullptr, *d_delta_s = nullptr, *d_delta_v = nullptr;  // device [n][..]
+    const double *d_natU = nullptr;   // device natural [n_src][m]
+    const double *d_natU0 = nullptr;  // device natural [n_src][m] or null
+    int n_src = 0;                    // natural arrays hold n_src instances, instance k reads k % n_src
+    int num_div = 0;
+    const double *div_dates = nullptr, *div_amounts = nullptr, *div_pcts = nullptr;
+};
+
+template <int B>
+void launch_pass_a(const HadiPlan &pl, const HadiSweepArgs &a, int n, hipStream_t s) {
+    hipLaunchKernelGGL(hadi_pass_a<B>, dim3(pl.grid_a), dim3(64), 0, s, a, n);
+}
+
+int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
+    if (hadi_make_plan(d.m1, d.m2, d.n, 8 * c->cu_count, &pl))
+        return fail(c, HADI_ERR_UNSUPPORTED,
+                    "grid %dx%d not supported (need 2 <= m1 <= 1024, 3 <= m2 <= min(m1, %d))", d.m1, d.m2,
+                    HADI_MAX_P * HADI_LC - 1);
+    const HadiLayout &L = pl.L;
+    const bool american = d.variant == HADI_AM || d.variant == HADI_AM_DIV;
+    const bool dividend = d.variant == HADI_DIV || d.variant == HADI_AM_DIV;
+    if (dividend && !d.uniform_steps)
+        return fail(c, HADI_ERR_UNSUPPORTED, "dividends need one shared (N, delta_t) for the batch");
+    const size_t st = (size_t)L.inst_stride * d.n * sizeof(double);
+    int rc;
+    if ((rc = ensure(c, c->U, st))) return rc;
+    if ((rc = ensure(c, c->Y, st))) return rc;
+    if (american) {
+        if ((rc = ensure(c, c->LAM, st))) return rc;
+        if ((rc = ensure(c, c->U0, st))) return rc;
+    }
+    if (dividend && (rc = ensure(c, c->UT, st))) return rc;
+    const size_t n = d.n;
+    if ((rc = ensure(c, c->scoef, pl.n_scoef * n * 8))) return rc;
+    if ((rc = ensure(c, c->b2row, pl.n_b2row * n * 8))) return rc;
+    if ((rc = ensure(c, c->rowc, pl.n_rowc * n * 8))) return rc;
+    if ((rc = ensure(c, c->a2i, pl.n_a2i * n * 8))) return rc;
+    if ((rc = ensure(c, c->pb, pl.n_pb * n * 8))) return rc;
+    if ((rc = ensure(c, c->rinv, pl.n_rinv * n * 8))) return rc;
+    if ((rc = ensure(c, c->rwork, pl.n_rwork * n * 8))) return rc;
+    if ((rc = ensure(c, c->ipar, sizeof(HadiInstPar) * n))) return rc;
+    if ((rc = ensure(c, c->par8, 8 * 8 * n))) return rc;
+
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    HIP_TRY(c, hipMemcpyAsync(c->par8.p, d.par8.data(), 8 * 8 * n, hipMemcpyHostToDevice, s));
+
+    HadiSetupArgs sa;
+    sa.L = L; sa.n_inst = d.n;
+    sa.vec_s = d.d_vec_s; sa.vec_v = d.d_vec_v; sa.delta_s = d.d_delta_s; sa.delta_v = d.d_delta_v;
+    sa.par = ptr<double>(c->par8);
+    sa.r_d = d.r_d; sa.r_f = d.r_f; sa.theta = d.theta;
+    sa.scoef = ptr<double>(c->scoef); sa.b2row = ptr<double>(c->b2row); sa.rowc = ptr<double>(c->rowc);
+    sa.a2i = ptr<double>(c->a2i); sa.pb = ptr<double>(c->pb); sa.rinv = ptr<double>(c->rinv);
+    sa.rwork = ptr<double>(c->rwork); sa.ipar = ptr<HadiInstPar>(c->ipar);
+    hipLaunchKernelGGL(hadi_setup_kernel, dim3(d.n), dim3(256), 0, s, sa);
+
+    const size_t tot = (size_t)L.inst_stride * d.n;
+    hipLaunchKernelGGL(hadi_pack_kernel, dim3(grid1d(tot)), dim3(256), 0, s, L, d.n, d.n_src, d.d_natU, ptr<double>(c->U));
+    if (american) {
+        hipLaunchKernelGGL(hadi_pack_kernel, dim3(grid1d(tot)), dim3(256), 0, s, L, d.n, d.n_src,
+                           d.d_natU0 ? d.d_natU0 : d.d_natU, ptr<double>(c->U0));
+        HIP_TRY(c, hipMemsetAsync(c->LAM.p, 0, st, s));  // lambda_bar <- 0, device_solver.hpp:310-313
+    }
+    HIP_TRY(c, hipGetLastError());
+
+    HadiSweepArgs a;
+    a.U = ptr<double>(c->U); a.Y = ptr<double>(c->Y);
+    a.LAM = american ? ptr<double>(c->LAM) : nullptr;
+    a.U0 = american ? ptr<double>(c->U0) : nullptr;
+    a.scoef = ptr<double>(c->scoef); a.b2row = ptr<double>(c->b2row); a.rowc = ptr<double>(c->rowc);
+    a.pb = ptr<double>(c->pb); a.rinv = ptr<double>(c->rinv); a.ipar = ptr<HadiInstPar>(c->ipar);
+    a.L = L; a.n_inst = d.n; a.R = pl.R; a.ntiles = pl.ntiles; a.ctiles = pl.ctiles;
+    a.american = american ? 1 : 0; a.pos_m1 = pl.pos_m1;
+
+    const bool prof = c->profiling != 0;
+    if (prof) {
+        const size_t need = (size_t)4 * d.Nmax;
+        while (c->kev.size() < need) {
+            hipEvent_t e;
+            HIP_TRY(c, hipEventCreate(&e));
+            c->kev.push_back(e);
+        }
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    int cur = 0;
+    for (int nstep = 1; nstep <= d.Nmax; nstep++) {
+        if (dividend) {
+            // device_solver.hpp:426-447,508-516; n*delta_t in floating point decides the step
+            const double t = nstep * d.dt0;
+            if (cur < d.num_div && t <= d.div_dates[cur] && d.div_dates[cur] < (nstep + 1) * d.dt0) {
+                HIP_TRY(c, hipMemcpyAsync(c->UT.p, c->U.p, st, hipMemcpyDeviceToDevice, s));
+                const size_t npts = (size_t)d.n * L.nrows * (L.m1 + 1);
+                hipLaunchKernelGGL(hadi_dividend_kernel, dim3(grid1d(npts)), dim3(256), 0, s, L, d.n, d.d_vec_s,
+                                   ptr<double>(c->UT), ptr<double>(c->U), d.div_amounts[cur], d.div_pcts[cur]);
+            }
+            if (cur < d.num_div && t > d.div_dates[cur]) cur++;
+        }
+        if (prof) HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 0], s));
+        switch (L.B) {
+            case 1: launch_pass_a<1>(pl, a, nstep, s); break;
+            case 2: launch_pass_a<2>(pl, a, nstep, s); break;
+            case 4: launch_pass_a<4>(pl, a, nstep, s); break;
+            case 8: launch_pass_a<8>(pl, a, nstep, s); break;
+            default: launch_pass_a<16>(pl, a, nstep, s); break;
+        }
+        if (prof) {
+            HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 1], s));
+            HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 2], s));
+        }
+        hipLaunchKernelGGL(hadi_pass_b, dim3(pl.grid_b), dim3(pl.block_b), 0, s, a, nstep);
+        if (prof) HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 3], s));
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev[2], s));
+    return HADI_OK;
+}
+
+int finish_timing(Ctx *c, const SweepDesc &d, const HadiPlan &pl) {
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipEventRecord(c->ev[3], s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    float ms = 0;
+    hadi_timing &t = c->timing;
+    t = hadi_timing{};
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); t.setup_ms = ms;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); t.sweep_ms = ms;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); t.finish_ms = ms;
+    long long ps = 0;
+    const long long m = (long long)(d.m1 + 1) * (d.m2 + 1);
+    for (int k = 0; k < d.n; k++) ps += m * (long long)d.par8[(size_t)k * 8 + 5];
+    t.point_steps = ps;
+    if (c->profiling) {
+        for (int k = 0; k < d.Nmax; k++) {
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[4 * k], c->kev[4 * k + 1])); t.pass_a_ms += ms;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[4 * k + 2], c->kev[4 * k + 3])); t.pass_b_ms += ms;
+        }
+        t.pass_a_launches = d.Nmax;
+        t.pass_b_launches = d.Nmax;
+    }
+    (void)pl;
+    return HADI_OK;
+}
+
+// Brings an array argument to the device (staging host memory into `buf`).
+int to_device(Ctx *c, int memspace, const double *src, size_t count, DevBuf &buf, const double **out) {
+    if (!src) { *out = nullptr; return HADI_OK; }
+    if (memspace == HADI_MEM_DEVICE) { *out = src; return HADI_OK; }
+    int rc = ensure(c, buf, count * sizeof(double));
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(buf.p, src, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    *out = ptr<double>(buf);
+    return HADI_OK;
+}
+
+int from_device(Ctx *c, int memspace, double *dst, const double *dsrc, size_t count) {
+    HIP_TRY(c, hipMemcpyAsync(dst, dsrc, count * sizeof(double),
+                              memspace == HADI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                              c->stream));
+    return HADI_OK;
+}
+
+int check_problem(Ctx *c, const hadi_problem *p, bool need_U, bool need_vgrid) {
+    if (!c) return HADI_ERR_INVALID;
+    if (!p) return fail(c, HADI_ERR_INVALID, "problem is NULL");
+    if (p->n_instances < 1) return fail(c, HADI_ERR_INVALID, "n_instances must be >= 1");
+    if (p->variant < HADI_EU || p->variant > HADI_AM_DIV) return fail(c, HADI_ERR_INVALID, "bad variant %d", p->variant);
+    if (p->memspace != HADI_MEM_HOST && p->memspace != HADI_MEM_DEVICE)
+        return fail(c, HADI_ERR_INVALID, "bad memspace %d", p->memspace);
+    if (!p->vec_s || !p->delta_s) return fail(c, HADI_ERR_INVALID, "vec_s / delta_s missing");
+    if (need_vgrid && (!p->vec_v || !p->delta_v)) return fail(c, HADI_ERR_INVALID, "vec_v / delta_v missing");
+    if (need_U && !p->U) return fail(c, HADI_ERR_INVALID, "U missing");
+    if (!p->N_i && p->N < 1) return fail(c, HADI_ERR_INVALID, "N must be >= 1");
+    if (!p->delta_t_i && !(p->delta_t > 0)) return fail(c, HADI_ERR_INVALID, "delta_t must be > 0");
+    const bool dividend = p->variant == HADI_DIV || p->variant == HADI_AM_DIV;
+    if (dividend && p->num_dividends > 0 && (!p->dividend_dates || !p->dividend_amounts || !p->dividend_percentages))
+        return fail(c, HADI_ERR_INVALID, "dividend arrays missing");
+    if (p->num_dividends < 0) return fail(c, HADI_ERR_INVALID, "num_dividends < 0");
+    return HADI_OK;
+}
+
+// Fills the per-instance parameter rows for `groups` copies of the caller's batch.
+void fill_par(const hadi_problem *p, SweepDesc &d, int groups) {
+    const int n0 = p->n_instances;
+    d.par8.assign((size_t)n0 * groups * 8, 0.0);
+    d.Nmax = 0;
+    d.uniform_steps = !(p->N_i || p->delta_t_i);
+    d.dt0 = p->delta_t;
+    for (int g = 0; g < groups; g++)
+        for (int k = 0; k < n0; k++) {
+            double *r = &d.par8[((size_t)g * n0 + k) * 8];
+            r[0] = p->rho_i ? p->rho_i[k] : p->rho;
+            r[1] = p->sigma_i ? p->sigma_i[k] : p->sigma;
+            r[2] = p->kappa_i ? p->kappa_i[k] : p->kappa;
+            r[3] = p->eta_i ? p->eta_i[k] : p->eta;
+            r[4] = p->delta_t_i ? p->delta_t_i[k] : p->delta_t;
+            const int N = p->N_i ? p->N_i[k] : p->N;
+            r[5] = (double)N;
+            d.Nmax = std::max(d.Nmax, N);
+        }
+}
+
+void fill_common(const hadi_problem *p, SweepDesc &d) {
+    d.m1 = p->m1; d.m2 = p->m2; d.variant = p->variant;
+    d.theta = p->theta; d.r_d = p->r_d; d.r_f = p->r_f;
+    const bool dividend = p->variant == HADI_DIV || p->variant == HADI_AM_DIV;
+    d.num_div = dividend ? p->num_dividends : 0;
+    d.div_dates = p->dividend_dates; d.div_amounts = p->dividend_amounts; d.div_pcts = p->dividend_percentages;
+}
+
+// Shared driver of hadi_DO_timestepping / hadi_parallel_DO_solve / hadi_compute_base_prices*.
+int solve_common(Ctx *c, const hadi_problem *p, bool rebuild_v, bool pick, double S_0, double V_0, double *prices_out) {
+    int rc = check_problem(c, p, true, !rebuild_v);
+    if (rc) return rc;
+    const int n = p->n_instances, m1 = p->m1, m2 = p->m2;
+    if (m1 < 2 || m2 < 3) return fail(c, HADI_ERR_UNSUPPORTED, "grid %dx%d too small", m1, m2);
+    const size_t m = (size_t)(m1 + 1) * (m2 + 1);
+    SweepDesc d;
+    fill_common(p, d);
+    d.n = n; d.n_src = n;
+    fill_par(p, d, 1);
+    if ((rc = to_device(c, p->memspace, p->vec_s, (size_t)n * (m1 + 1), c->g_s, &d.d_vec_s))) return rc;
+    if ((rc = to_device(c, p->memspace, p->delta_s, (size_t)n * m1, c->g_ds, &d.d_delta_s))) return rc;
+    if (rebuild_v) {
+        // every instance gets the v-grid rebuilt for V_0 (jacobian_computation.cpp:253, V = 5, d = 5/500)
+        std::vector<double> hv(m2 + 1), hdv(m2);
+        build_v(m2, V_0, 5.0, 5.0 / 500, hv.data(), hdv.data());
+        if ((rc = ensure(c, c->src_v, (m2 + 1) * 8)) || (rc = ensure(c, c->src_dv, m2 * 8))) return rc;
+        if ((rc = ensure(c, c->g_v, (size_t)n * (m2 + 1) * 8)) || (rc = ensure(c, c->g_dv, (size_t)n * m2 * 8))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->src_v.p, hv.data(), (m2 + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->src_dv.p, hdv.data(), m2 * 8, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(hadi_bcast_rows_kernel, dim3(grid1d((size_t)n * (m2 + 1))), dim3(256), 0, c->stream, m2 + 1, n,
+                           ptr<double>(c->src_v), (const int *)nullptr, ptr<double>(c->g_v));
+        hipLaunchKernelGGL(hadi_bcast_rows_kernel, dim3(grid1d((size_t)n * m2)), dim3(256), 0, c->stream, m2, n,
+                           ptr<double>(c->src_dv), (const int *)nullptr, ptr<double>(c->g_dv));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // hv/hdv leave scope
+        d.d_vec_v = ptr<double>(c->g_v);
+        d.d_delta_v = ptr<double>(c->g_dv);
+    } else {
+        if ((rc = to_device(c, p->memspace, p->vec_v, (size_t)n * (m2 + 1), c->g_v, &d.d_vec_v))) return rc;
+        if ((rc = to_device(c, p->memspace, p->delta_v, (size_t)n * m2, c->g_dv, &d.d_delta_v))) return rc;
+    }
+    if ((rc = to_device(c, p->memspace, p->U, n * m, c->natU, &d.d_natU))) return rc;
+    if ((rc = to_device(c, p->memspace, p->U_0, n * m, c->natU0, &d.d_natU0))) return rc;
+
+    HadiPlan pl;
+    if ((rc = run_sweep(c, d, pl))) return rc;
+
+    // solution back to the caller's U (natural layout)
+    double *d_out;
+    if (p->memspace == HADI_MEM_DEVICE) d_out = p->U;
+    else {
+        if ((rc = ensure(c, c->natOut, n * m * 8))) return rc;
+        d_out = ptr<double>(c->natOut);
+    }
+    hipLaunchKernelGGL(hadi_unpack_kernel, dim3(grid1d(n * m)), dim3(256), 0, c->stream, pl.L, n, ptr<double>(c->U), d_out);
+    if (p->memspace == HADI_MEM_HOST && (rc = from_device(c, p->memspace, p->U, d_out, n * m))) return rc;
+    const bool american = p->variant == HADI_AM || p->variant == HADI_AM_DIV;
+    if (american && p->lambda_bar) {
+        double *d_l;
+        if (p->memspace == HADI_MEM_DEVICE) d_l = p->lambda_bar;
+        else {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            d_l = ptr<double>(c->natOut);
+        }
+        hipLaunchKernelGGL(hadi_unpack_kernel, dim3(grid1d(n * m)), dim3(256), 0, c->stream, pl.L, n, ptr<double>(c->LAM), d_l);
+        if (p->memspace == HADI_MEM_HOST && (rc = from_device(c, p->memspace, p->lambda_bar, d_l, n * m))) return rc;
+    }
+    std::vector<int> hstatus;
+    if (pick) {
+        if ((rc = ensure(c, c->prices, n * 8)) || (rc = ensure(c, c->status, n * sizeof(int)))) return rc;
+        hipLaunchKernelGGL(hadi_pick_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, pl.L, n, d.d_vec_s, d.d_vec_v,
+                           ptr<double>(c->U), S_0, (const double *)nullptr, V_0, ptr<double>(c->prices), 1,
+                           ptr<int>(c->status));
+        if ((rc = from_device(c, p->memspace, prices_out, ptr<double>(c->prices), n))) return rc;
+        hstatus.resize(n);
+        HIP_TRY(c, hipMemcpyAsync(hstatus.data(), c->status.p, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipGetLastError());
+    if ((rc = finish_timing(c, d, pl))) return rc;
+    for (int k = 0; k < (int)hstatus.size(); k++)
+        if (hstatus[k]) return fail(c, HADI_ERR_NOT_ON_GRID, "S_0 = %.17g is not a node of instance %d's s-grid", S_0, k);
+    return HADI_OK;
+}
+
+// compute_jacobian*: the reference runs 6 solves one after the other inside each team
+// (jacobian_computation.cpp:232-363); here they are 6n independent instances of ONE batched sweep:
+// group 0 = base, 1..4 = kappa, eta, sigma, rho + eps, 5 = v-grid rebuilt for V_0 + eps.
+int jacobian_common(Ctx *c, const hadi_problem *p, double S_0, double V_0, double eps, double *J, double *base_prices) {
+    int rc = check_problem(c, p, false, false);
+    if (rc) return rc;
+    if (!p->U_0) return fail(c, HADI_ERR_INVALID, "U_0 (initial condition) is required for the Jacobian");
+    if (!J || !base_prices) return fail(c, HADI_ERR_INVALID, "J / base_prices missing");
+    const int n0 = p->n_instances, m1 = p->m1, m2 = p->m2, G = 6;
+    if (m1 < 2 || m2 < 3) return fail(c, HADI_ERR_UNSUPPORTED, "grid %dx%d too small", m1, m2);
+    const int n = n0 * G;
+    const size_t m = (size_t)(m1 + 1) * (m2 + 1);
+    SweepDesc d;
+    fill_common(p, d);
+    d.n = n; d.n_src = n0;
+    fill_par(p, d, G);
+    for (int k = 0; k < n0; k++) {
+        d.par8[((size_t)1 * n0 + k) * 8 + 2] += eps;  // kappa
+        d.par8[((size_t)2 * n0 + k) * 8 + 3] += eps;  // eta
+        d.par8[((size_t)3 * n0 + k) * 8 + 1] += eps;  // sigma
+        d.par8[((size_t)4 * n0 + k) * 8 + 0] += eps;  // rho
+    }
+    // s-grids: replicate the caller's rows into the 6 groups
+    const double *src_s, *src_ds;
+    if ((rc = to_device(c, p->memspace, p->vec_s, (size_t)n0 * (m1 + 1), c->natU, &src_s))) return rc;
+    if ((rc = to_device(c, p->memspace, p->delta_s, (size_t)n0 * m1, c->natOut, &src_ds))) return rc;
+    std::vector<int> sel_a(n), sel_b(n);
+    std::vector<double> v0i(n);
+    for (int g = 0; g < G; g++)
+        for (int k = 0; k < n0; k++) {
+            sel_a[g * n0 + k] = k;
+            sel_b[g * n0 + k] = (g == 5) ? 1 : 0;
+            v0i[g * n0 + k] = (g == 5) ? V_0 + eps : V_0;
+        }
+    std::vector<double> hv(2 * (m2 + 1)), hdv(2 * m2);
+    build_v(m2, V_0, 5.0, 5.0 / 500, hv.data(), hdv.data());
+    build_v(m2, V_0 + eps, 5.0, 5.0 / 500, hv.data() + m2 + 1, hdv.data() + m2);
+    if ((rc = ensure(c, c->sel_a, n * sizeof(int))) || (rc = ensure(c, c->sel_b, n * sizeof(int))) ||
+        (rc = ensure(c, c->v0_i, n * 8)) || (rc = ensure(c, c->src_v, 2 * (m2 + 1) * 8)) ||
+        (rc = ensure(c, c->src_dv, 2 * m2 * 8)) || (rc = ensure(c, c->g_s, (size_t)n * (m1 + 1) * 8)) ||
+        (rc = ensure(c, c->g_ds, (size_t)n * m1 * 8)) || (rc = ensure(c, c->g_v, (size_t)n * (m2 + 1) * 8)) ||
+        (rc = ensure(c, c->g_dv, (size_t)n * m2 * 8)))
+        return rc;
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(c->sel_a.p, sel_a.data(), n * sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->sel_b.p, sel_b.data(), n * sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->v0_i.p, v0i.data(), n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->src_v.p, hv.data(), 2 * (m2 + 1) * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->src_dv.p, hdv.data(), 2 * m2 * 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(hadi_bcast_rows_kernel, dim3(grid1d((size_t)n * (m1 + 1))), dim3(256), 0, s, m1 + 1, n, src_s,
+                       ptr<int>(c->sel_a), ptr<double>(c->g_s));
+    hipLaunchKernelGGL(hadi_bcast_rows_kernel, dim3(grid1d((size_t)n * m1)), dim3(256), 0, s, m1, n, src_ds,
+                       ptr<int>(c->sel_a), ptr<double>(c->g_ds));
+    hipLaunchKernelGGL(hadi_bcast_rows_kernel, dim3(grid1d((size_t)n * (m2 + 1))), dim3(256), 0, s, m2 + 1, n,
+                       ptr<double>(c->src_v), ptr<int>(c->sel_b), ptr<double>(c->g_v));
+    hipLaunchKernelGGL(hadi_bcast_rows_kernel, dim3(grid1d((size_t)n * m2)), dim3(256), 0, s, m2, n,
+                       ptr<double>(c->src_dv), ptr<int>(c->sel_b), ptr<double>(c->g_dv));
+    HIP_TRY(c, hipStreamSynchronize(s));  // host vectors + natU/natOut staging are reused below
+    d.d_vec_s = ptr<double>(c->g_s); d.d_delta_s = ptr<double>(c->g_ds);
+    d.d_vec_v = ptr<double>(c->g_v); d.d_delta_v = ptr<double>(c->g_dv);
+    // every solve starts from U_0 (jacobian_computation.cpp:307-309); payoff for American = U_0 too
+    if ((rc = to_device(c, p->memspace, p->U_0, n0 * m, c->natU0, &d.d_natU))) return rc;
+    d.d_natU0 = d.d_natU;
+
+    HadiPlan pl;
+    if ((rc = run_sweep(c, d, pl))) return rc;
+    if ((rc = ensure(c, c->prices, n * 8)) || (rc = ensure(c, c->status, n * sizeof(int)))) return rc;
+    hipLaunchKernelGGL(hadi_pick_kernel, dim3((n + 63) / 64), dim3(64), 0, s, pl.L, n, d.d_vec_s, d.d_vec_v,
+                       ptr<double>(c->U), S_0, ptr<double>(c->v0_i), V_0, ptr<double>(c->prices), 1, ptr<int>(c->status));
+    std::vector<double> hp(n);
+    std::vector<int> hs(n);
+    HIP_TRY(c, hipMemcpyAsync(hp.data(), c->prices.p, n * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(hs.data(), c->status.p, n * sizeof(int), hipMemcpyDeviceToHost, s));
+    if ((rc = finish_timing(c, d, pl))) return rc;
+    for (int k = 0; k < n0; k++)
+        if (hs[k]) return fail(c, HADI_ERR_NOT_ON_GRID, "S_0 = %.17g is not a node of instance %d's s-grid", S_0, k);
+    // J(k, param) = (pert - base) / eps, jacobian_computation.cpp:329,360
+    std::vector<double> hJ((size_t)n0 * 5), hb(n0);
+    for (int k = 0; k < n0; k++) {
+        hb[k] = hp[k];
+        for (int g = 1; g <= 5; g++) hJ[(size_t)k * 5 + (g - 1)] = (hp[(size_t)g * n0 + k] - hp[k]) / eps;
+    }
+    if (p->memspace == HADI_MEM_DEVICE) {
+        HIP_TRY(c, hipMemcpy(J, hJ.data(), hJ.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(base_prices, hb.data(), hb.size() * 8, hipMemcpyHostToDevice));
+    } else {
+        std::memcpy(J, hJ.data(), hJ.size() * 8);
+        std::memcpy(base_prices, hb.data(), hb.size() * 8);
+    }
+    return HADI_OK;
+}
+
+int with_variant(hadi_ctx *ctx, const hadi_problem *p, int variant, hadi_problem *tmp) {
+    if (!ctx) return HADI_ERR_INVALID;
+    if (!p) return fail(reinterpret_cast<Ctx *>(ctx), HADI_ERR_INVALID, "problem is NULL");
+    *tmp = *p;
+    tmp->variant = variant;
+    return HADI_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int hadi_version(void) { return HADI_VERSION_MAJOR * 100 + HADI_VERSION_MINOR; }
+
+const char *hadi_status_string(int s) {
+    switch (s) {
+        case HADI_OK: return "ok";
+        case HADI_ERR_INVALID: return "invalid argument";
+        case HADI_ERR_UNSUPPORTED: return "unsupported grid shape";
+        case HADI_ERR_HIP: return "HIP runtime error";
+        case HADI_ERR_NOT_ON_GRID: return "S_0 is not a grid node";
+        case HADI_ERR_NO_DEVICE: return "no usable gfx950 GPU (libhadi has no CPU path)";
+        case HADI_ERR_ALLOC: return "device allocation failed";
+        default: return "unknown";
+    }
+}
+
+int hadi_create(hadi_ctx **out, int device_id) {
+    if (!out) return HADI_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1) return HADI_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= count) return HADI_ERR_INVALID;
+    if (hipSetDevice(device_id) != hipSuccess) return HADI_ERR_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return HADI_ERR_HIP;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return HADI_ERR_NO_DEVICE;  // code object is gfx950-only
+    Ctx *c = new Ctx;
+    c->device = device_id;
+    c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->name = prop.name;
+    c->arch = prop.gcnArchName;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return HADI_ERR_HIP; }
+    for (auto &e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) { delete c; return HADI_ERR_HIP; }
+    *out = reinterpret_cast<hadi_ctx *>(c);
+    return HADI_OK;
+}
+
+int hadi_destroy(hadi_ctx *ctx) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return HADI_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->U, &c->Y, &c->LAM, &c->U0, &c->UT, &c->scoef, &c->b2row, &c->rowc, &c->a2i, &c->pb,
+                      &c->rinv, &c->rwork, &c->ipar, &c->par8, &c->g_s, &c->g_v, &c->g_ds, &c->g_dv, &c->src_v,
+                      &c->src_dv, &c->sel_a, &c->sel_b, &c->v0_i, &c->natU, &c->natU0, &c->natOut, &c->prices,
+                      &c->status};
+    for (DevBuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (auto e : c->kev) (void)hipEventDestroy(e);
+    for (auto e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return HADI_OK;
+}
+
+const char *hadi_last_error(const hadi_ctx *ctx) {
+    const Ctx *c = reinterpret_cast<const Ctx *>(ctx);
+    return c ? c->err.c_str() : "null handle";
+}
+
+int hadi_set_profiling(hadi_ctx *ctx, int enabled) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return HADI_ERR_INVALID;
+    c->profiling = enabled ? 1 : 0;
+    return HADI_OK;
+}
+
+int hadi_get_timing(const hadi_ctx *ctx, hadi_timing *out) {
+    const Ctx *c = reinterpret_cast<const Ctx *>(ctx);
+    if (!c || !out) return HADI_ERR_INVALID;
+    *out = c->timing;
+    return HADI_OK;
+}
+
+int hadi_device_info(const hadi_ctx *ctx, char *name, int name_len, int *compute_units, char *arch, int arch_len) {
+    const Ctx *c = reinterpret_cast<const Ctx *>(ctx);
+    if (!c) return HADI_ERR_INVALID;
+    if (name && name_len > 0) std::snprintf(name, name_len, "%s", c->name.c_str());
+    if (arch && arch_len > 0) std::snprintf(arch, arch_len, "%s", c->arch.c_str());
+    if (compute_units) *compute_units = c->cu_count;
+    return HADI_OK;
+}
+
+void *hadi_stream(hadi_ctx *ctx) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    return c ? (void *)c->stream : nullptr;
+}
+
+// ---- grids ------------------------------------------------------------------------------------------
+int hadi_make_grid(int m1, double S, double S_0, double K, double cc, int m2, double V, double V_0, double d,
+                   double *vec_s, double *vec_v, double *delta_s, double *delta_v) {
+    if (m1 < 1 || m2 < 1 || !vec_s || !vec_v || !delta_s || !delta_v) return HADI_ERR_INVALID;
+    const double lo = std::asinh(-K / cc);
+    const double Delta_xi = (1.0 / m1) * (std::asinh((S - K) / cc) - lo);
+    for (int i = 0; i <= m1; i++) vec_s[i] = K + cc * std::sinh(lo + i * Delta_xi);
+    sorted_insert_drop_largest(vec_s, m1 + 1, S_0);
+    for (int i = 0; i < m1; i++) delta_s[i] = vec_s[i + 1] - vec_s[i];
+    build_v(m2, V_0, V, d, vec_v, delta_v);
+    return HADI_OK;
+}
+
+int hadi_rebuild_variance(int m2, double V_0_new, double V, double d, double *vec_v, double *delta_v) {
+    if (m2 < 1 || !vec_v || !delta_v) return HADI_ERR_INVALID;
+    build_v(m2, V_0_new, V, d, vec_v, delta_v);
+    return HADI_OK;
+}
+
+int hadi_find_s_index(int m1, const double *vec_s, double S_0) {
+    for (int i = 0; i <= m1; i++)
+        if (std::fabs(vec_s[i] - S_0) < 1e-10) return i;
+    return -1;
+}
+
+int hadi_find_v_index(int m2, const double *vec_v, double V_0) {
+    for (int i = 0; i <= m2; i++)
+        if (std::fabs(vec_v[i] - V_0) < 1e-10) return i;
+    return 0;
+}
+
+// ---- hot path ------------------------------------------------------------------------------------------
+int hadi_DO_timestepping(hadi_ctx *ctx, const hadi_problem *p) {
+    return solve_common(reinterpret_cast<Ctx *>(ctx), p, false, false, 0.0, 0.0, nullptr);
+}
+
+int hadi_parallel_DO_solve(hadi_ctx *ctx, const hadi_problem *p, double S_0, double V_0, double *base_prices) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (c && !base_prices) return fail(c, HADI_ERR_INVALID, "base_prices missing");
+    return solve_common(c, p, false, true, S_0, V_0, base_prices);
+}
+
+int hadi_compute_base_prices(hadi_ctx *ctx, const hadi_problem *p, double S_0, double V_0, double *base_prices) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (c && !base_prices) return fail(c, HADI_ERR_INVALID, "base_prices missing");
+    return solve_common(c, p, true, true, S_0, V_0, base_prices);
+}
+
+#define HADI_VARIANT_WRAPPERS(suffix, variant)                                                                   \
+    int hadi_compute_base_prices_##suffix(hadi_ctx *ctx, const hadi_problem *p, double S_0, double V_0,          \
+                                          double *base_prices) {                                                 \
+        hadi_problem t;                                                                                          \
+        int rc = with_variant(ctx, p, variant, &t);                                                              \
+        return rc ? rc : hadi_compute_base_prices(ctx, &t, S_0, V_0, base_prices);                               \
+    }                                                                                                            \
+    int hadi_compute_jacobian_##suffix(hadi_ctx *ctx, const hadi_problem *p, double S_0, double V_0, double eps, \
+                                       double *J, double *base_prices) {                                         \
+        hadi_problem t;                                                                                          \
+        int rc = with_variant(ctx, p, variant, &t);                                                              \
+        return rc ? rc : hadi_compute_jacobian(ctx, &t, S_0, V_0, eps, J, base_prices);                          \
+    }
+
+int hadi_compute_jacobian(hadi_ctx *ctx, const hadi_problem *p, double S_0, double V_0, double eps, double *J,
+                          double *base_prices) {
+    return jacobian_common(reinterpret_cast<Ctx *>(ctx), p, S_0, V_0, eps, J, base_prices);
+}
+
+HADI_VARIANT_WRAPPERS(american, HADI_AM)
+HADI_VARIANT_WRAPPERS(dividends, HADI_DIV)
+HADI_VARIANT_WRAPPERS(american_dividends, HADI_AM_DIV)
+
+// ---- Levenberg-Marquardt normal equations (jacobian_computation.cpp:20-195) ---------------------------
+int hadi_lm_partials(int n, const double *J, const double *r, double *out) {
+    if (n < 0 || !out || (n > 0 && (!J || !r))) return HADI_ERR_INVALID;
+    for (int k = 0; k < 31; k++) out[k] = 0.0;
+    for (int i = 0; i < 5; i++)
+        for (int j = 0; j < 5; j++) {
+            double s = 0.0;
+            for (int k = 0; k < n; k++) s += J[(size_t)k * 5 + i] * J[(size_t)k * 5 + j];
+            out[i * 5 + j] = s;
+        }
+    for (int i = 0; i < 5; i++) {
+        double s = 0.0;
+        for (int k = 0; k < n; k++) s += J[(size_t)k * 5 + i] * r[k];
+        out[25 + i] = s;
+    }
+    double s2 = 0.0;
+    for (int k = 0; k < n; k++) s2 += r[k] * r[k];
+    out[30] = s2;
+    return HADI_OK;
+}
+
+int hadi_lm_solve(const double *partial31, double lambda, double *delta5) {
+    if (!partial31 || !delta5) return HADI_ERR_INVALID;
+    constexpr int NP = 5;
+    double A[NP * NP], b[NP];
+    for (int i = 0; i < NP * NP; i++) A[i] = partial31[i];
+    for (int i = 0; i < NP; i++) {
+        A[i * NP + i] *= (1.0 + lambda);  // jacobian_computation.cpp:136-138
+        b[i] = partial31[25 + i];
+    }
+    for (int k = 0; k < NP; k++) {  // partial-pivot elimination, jacobian_computation.cpp:44-83
+        int piv = k;
+        double best = std::fabs(A[k * NP + k]);
+        for (int r = k + 1; r < NP; r++)
+            if (std::fabs(A[r * NP + k]) > best) { best = std::fabs(A[r * NP + k]); piv = r; }
+        if (piv != k) {
+            for (int col = 0; col < NP; col++) std::swap(A[k * NP + col], A[piv * NP + col]);
+            std::swap(b[k], b[piv]);
+        }
+        const double pv = A[k * NP + k];
+        for (int col = k + 1; col < NP; col++) A[k * NP + col] /= pv;
+        b[k] /= pv;
+        A[k * NP + k] = 1.0;
+        for (int i = k + 1; i < NP; i++) {
+            const double f = A[i * NP + k];
+            for (int col = k + 1; col < NP; col++) A[i * NP + col] -= f * A[k * NP + col];
+            b[i] -= f * b[k];
+            A[i * NP + k] = 0.0;
+        }
+    }
+    for (int k = NP - 1; k >= 0; k--) {
+        double v = b[k];
+        for (int col = k + 1; col < NP; col++) v -= A[k * NP + col] * b[col];
+        b[k] = v;
+    }
+    for (int i = 0; i < NP; i++) delta5[i] = b[i];
+    return HADI_OK;
+}
+
+int hadi_compute_parameter_update(int n, const double *J, const double *r, double lambda, double *delta5) {
+    double part[31];
+    int rc = hadi_lm_partials(n, J, r, part);
+    if (rc) return rc;
+    return hadi_lm_solve(part, lambda, delta5);
+}
+
+}  // extern "C"

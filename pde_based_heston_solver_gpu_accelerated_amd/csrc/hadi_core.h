@@ -1,0 +1,311 @@
+// hadi_core.h -- internal HBM layout and per-instance operator tables of libhadi.
+//
+// Everything the reference stores per grid point (A0 9 values/pt, A1 7 arrays, A2 13 arrays,
+// 4 dense boundary vectors: hes_a0_kernels.hpp:22, hes_a1_kernels.hpp:21-30,
+// hes_a2_shuffled_kernels.hpp:58-75, hes_boundary_kernels.hpp:11-14) is kept here in
+// O(m1 + m2) numbers per instance, because
+//   A0(i,j;k,l) = rho*sigma * [s_i beta_s(i-1,k)] * [v_j beta_v(j-1,l)]      (separable)
+//   A1(i,j;k)   = v_j * [1/2 s_i^2 delta_s(i-1,k)] + (r_d-r_f) * [s_i beta_s(i-1,k)] (- 1/2 r_d)
+//   A2(j;.)     does not depend on i
+//   b1, b2      are sparse (one entry per v-row / the last v-row), b0 == 0.
+// The functions are HADI_HD so tests can check the tables on the CPU against the oracle; the
+// product only ever runs them inside hadi_setup_kernel on the GPU.
+#pragma once
+#include "hadi_device.h"
+
+#define HADI_RC 16   // doubles per v-row in the row table
+#define HADI_PBW 12  // doubles per v-row in the column-pass table
+#define HADI_MAX_P 8 // max chunks (waves) per column in the column pass
+#define HADI_LC 65   // max rows per chunk in the column pass
+
+struct HadiLayout {
+    int m1, m2, nrows;  // nrows = m2 + 1
+    int B;              // grid points per lane in the row pass: i = 1 + B*lane + r
+    int rowp;           // row pitch in doubles: 64*B + 8 (slot 64*B holds i = 0, 7 zero pads)
+    int P;              // chunks per column in the column pass
+    long long inst_stride;  // rowp * nrows
+};
+
+// Storage position of s-index i inside a row.  Lane `l` of the row pass owns i = 1+B*l .. B*l+B
+// and fetches them as B/2 coalesced 16-byte loads: pair q of lane l sits at q*128 + 2*l.
+HADI_HD inline int hadi_pos(int B, int i) {
+    if (i == 0) return 64 * B;
+    const int e = i - 1;
+    if (B == 1) return e;
+    const int lane = e / B, r = e % B;
+    return (r >> 1) * 128 + 2 * lane + (r & 1);
+}
+
+HADI_HD inline int hadi_pick_B(int m1) {
+    int B = 1;
+    while (64 * B < m1) B *= 2;
+    return B;
+}
+
+HADI_HD inline void hadi_chunk(int nrows, int P, int p, int *ja, int *len) {
+    const int base = nrows / P, rem = nrows % P;
+    *ja = p * base + (p < rem ? p : rem);
+    *len = base + (p < rem ? 1 : 0);
+}
+
+struct HadiInstPar {
+    double dt, thdt;   // delta_t, theta*delta_t
+    double q;          // r_d - r_f
+    double half_rd;    // 0.5*r_d
+    double r_f;
+    int N;             // time steps of this instance
+    int idx_s, idx_v;  // price node (filled by the pick step), -1 if S_0 is off-grid
+    int pad;
+};
+
+// ---- coeff.hpp:24-126 ------------------------------------------------------------------------
+HADI_HD inline double hadi_fd_delta(const double *D, int i, int pos) {
+    if (pos == -1) return 2 / (D[i] * (D[i] + D[i + 1]));
+    if (pos == 0) return -2 / (D[i] * D[i + 1]);
+    return 2 / (D[i + 1] * (D[i] + D[i + 1]));
+}
+HADI_HD inline double hadi_fd_beta(const double *D, int i, int pos) {
+    if (pos == -1) return -D[i + 1] / (D[i] * (D[i] + D[i + 1]));
+    if (pos == 0) return (D[i + 1] - D[i]) / (D[i] * D[i + 1]);
+    return D[i] / (D[i + 1] * (D[i] + D[i + 1]));
+}
+HADI_HD inline double hadi_fd_alpha(const double *D, int i, int pos) {
+    if (pos == -2) return D[i] / (D[i - 1] * (D[i - 1] + D[i]));
+    if (pos == -1) return (-D[i - 1] - D[i]) / (D[i - 1] * D[i]);
+    return (D[i - 1] + 2 * D[i]) / (D[i] * (D[i - 1] + D[i]));
+}
+HADI_HD inline double hadi_fd_gamma(const double *D, int i, int pos) {
+    if (pos == 0) return (-2 * D[i + 1] - D[i + 2]) / (D[i + 1] * (D[i + 1] + D[i + 2]));
+    if (pos == 1) return (D[i + 1] + D[i + 2]) / (D[i + 1] * D[i + 2]);
+    return -D[i + 1] / (D[i + 2] * (D[i + 1] + D[i + 2]));
+}
+
+// Row r of the explicit A2 operator, accumulated in the reference's order
+// (hes_a2_shuffled_kernels.hpp:122-152): the upwind block of iteration j = r-1 lands on row r
+// BEFORE iteration r adds the reaction term and its own stencil.  out = {lo2, lo, mn, up, up2}.
+HADI_HD inline void hadi_a2_row(int r, int m2, const double *vv, const double *dv, double r_d,
+                                double kappa, double eta, double sigma, double *out) {
+    double lo2 = 0.0, lo = 0.0, mn = 0.0, up = 0.0, up2 = 0.0;
+    const int j = r - 1;
+    if (j >= 1 && j < m2 - 1 && vv[j] > 1.0) {
+        const double temp = kappa * (eta - vv[j]);
+        const double temp2 = 0.5 * sigma * sigma * vv[j];
+        lo2 += temp * hadi_fd_alpha(dv, j, -2);
+        lo += temp * hadi_fd_alpha(dv, j, -1);
+        mn += temp * hadi_fd_alpha(dv, j, 0);
+        lo += temp2 * hadi_fd_delta(dv, j - 1, -1);
+        mn += temp2 * hadi_fd_delta(dv, j - 1, 0);
+        up += temp2 * hadi_fd_delta(dv, j - 1, 1);
+    }
+    if (r < m2 - 1) {
+        const double temp = kappa * (eta - vv[r]);
+        const double temp2 = 0.5 * sigma * sigma * vv[r];
+        mn += -0.5 * r_d;
+        if (r == 0) {
+            mn += temp * hadi_fd_gamma(dv, 0, 0);
+            up += temp * hadi_fd_gamma(dv, 0, 1);
+            up2 += temp * hadi_fd_gamma(dv, 0, 2);
+        } else {
+            lo += temp * hadi_fd_beta(dv, r - 1, -1) + temp2 * hadi_fd_delta(dv, r - 1, -1);
+            mn += temp * hadi_fd_beta(dv, r - 1, 0) + temp2 * hadi_fd_delta(dv, r - 1, 0);
+            up += temp * hadi_fd_beta(dv, r - 1, 1) + temp2 * hadi_fd_delta(dv, r - 1, 1);
+        }
+    }
+    out[0] = lo2; out[1] = lo; out[2] = mn; out[3] = up; out[4] = up2;
+}
+
+// Inputs of one instance's setup.
+struct HadiSetupIn {
+    const double *vec_s, *vec_v, *delta_s, *delta_v;  // this instance's grid
+    double r_d, r_f, rho, sigma, kappa, eta, theta, dt;
+    int N;
+};
+
+// Output tables of one instance (all device pointers, already offset to the instance).
+struct HadiTables {
+    double *scoef;   // [6][64*B]   B_k = s_i beta_s(i-1,k), D_k = 1/2 s_i^2 delta_s(i-1,k), k=-1,0,1
+    double *b2row;   // [rowp]      -1/2 r_d s_i E in state layout (hes_boundary_kernels.hpp:62-66)
+    double *rowc;    // [nrows][HADI_RC]
+    double *a2i;     // [5][nrows]  implicit A2 diagonals by row: l2, l1, m, u1, u2
+    double *pb;      // [nrows][HADI_PBW]  column-pass factorisation + spikes
+    double *rinv;    // [4P][4P]    inverse of the SPIKE reduced matrix (P > 1)
+    double *rwork;   // [4P][8P]    Gauss-Jordan work area
+    HadiInstPar *ipar;
+};
+
+// rowc columns
+enum { RC_V = 0, RC_WM = 1, RC_WZ = 2, RC_WP = 3, RC_L2 = 4, RC_L1 = 5, RC_M = 6, RC_U1 = 7, RC_U2 = 8,
+       RC_B1VAL = 9, RC_B1COL = 10, RC_LAST = 11 };
+// pb columns: forward  y_k = (rhs_k - PB_L y_{k-1} - PB_L2 y_{k-2}) * PB_Q
+//             backward x_k = y_k - PB_C x_{k+1} - PB_C2 x_{k+2}
+//             spikes   x_k -= PB_V0 tl0 + PB_V1 tl1 + PB_W0 tr0 + PB_W1 tr1
+enum { PB_L = 0, PB_L2 = 1, PB_Q = 2, PB_C = 3, PB_C2 = 4, PB_V0 = 5, PB_V1 = 6, PB_W0 = 7, PB_W1 = 8 };
+
+struct HadiNoSync { HADI_HD void operator()() const {} };
+
+// Builds every table of one instance.  Work is split over `nth` cooperating threads
+// (tid = 0..nth-1) with `sync()` between phases; nth = 1 with HadiNoSync runs it serially.
+template <class Sync>
+HADI_HD inline void hadi_setup_instance(const HadiLayout &L, const HadiSetupIn &in, const HadiTables &t,
+                                        int tid, int nth, Sync sync) {
+    const int m1 = L.m1, m2 = L.m2, nrows = L.nrows, B = L.B, nslot = 64 * B;
+    const double E = exp(-in.r_f * in.dt * (in.N - 1));  // hes_boundary_kernels.hpp:56
+    const double thdt = in.theta * in.dt;
+
+    if (tid == 0) {
+        HadiInstPar ip;
+        ip.dt = in.dt; ip.thdt = thdt; ip.q = in.r_d - in.r_f; ip.half_rd = 0.5 * in.r_d; ip.r_f = in.r_f;
+        ip.N = in.N; ip.idx_s = -1; ip.idx_v = 0; ip.pad = 0;
+        *t.ipar = ip;
+    }
+    // --- s-direction coefficients (hes_a0_kernels.hpp:37-49, hes_a1_kernels.hpp:69-91) ---------
+    for (int k = tid; k < 6 * nslot; k += nth) t.scoef[k] = 0.0;
+    for (int k = tid; k < L.rowp; k += nth) t.b2row[k] = 0.0;
+    sync();
+    for (int i = tid + 1; i < m1; i += nth) {
+        const double s = in.vec_s[i];
+        const int pos = hadi_pos(B, i);
+        for (int k = -1; k <= 1; k++) {
+            t.scoef[(k + 1) * nslot + pos] = s * hadi_fd_beta(in.delta_s, i - 1, k);
+            t.scoef[(k + 4) * nslot + pos] = 0.5 * s * s * hadi_fd_delta(in.delta_s, i - 1, k);
+        }
+    }
+    for (int i = tid; i <= m1; i += nth) t.b2row[hadi_pos(B, i)] = -0.5 * in.r_d * in.vec_s[i] * E;
+    // --- v-rows: A0 weights, explicit A2, boundary b1 ---------------------------------------------
+    for (int r = tid; r < nrows; r += nth) {
+        double *rc = t.rowc + (size_t)r * HADI_RC;
+        for (int k = 0; k < HADI_RC; k++) rc[k] = 0.0;
+        const double v = in.vec_v[r];
+        rc[RC_V] = v;
+        if (r >= 1 && r <= m2 - 1) {
+            const double c = in.rho * in.sigma * v;
+            rc[RC_WM] = c * hadi_fd_beta(in.delta_v, r - 1, -1);
+            rc[RC_WZ] = c * hadi_fd_beta(in.delta_v, r - 1, 0);
+            rc[RC_WP] = c * hadi_fd_beta(in.delta_v, r - 1, 1);
+        }
+        double a2[5];
+        hadi_a2_row(r, m2, in.vec_v, in.delta_v, in.r_d, in.kappa, in.eta, in.sigma, a2);
+        for (int k = 0; k < 5; k++) rc[RC_L2 + k] = a2[k];
+        rc[RC_B1COL] = -1.0;
+        rc[RC_LAST] = (r == m2) ? 1.0 : 0.0;
+        // implicit diagonals I - theta*dt*A2 (hes_a2_shuffled_kernels.hpp:159-171)
+        t.a2i[0 * nrows + r] = -in.theta * in.dt * a2[0];
+        t.a2i[1 * nrows + r] = -in.theta * in.dt * a2[1];
+        t.a2i[2 * nrows + r] = 1.0 - in.theta * in.dt * a2[2];
+        t.a2i[3 * nrows + r] = -in.theta * in.dt * a2[3];
+        t.a2i[4 * nrows + r] = -in.theta * in.dt * a2[4];
+    }
+    sync();
+    // b1_(m1*(j+1)) (quirk: not idx(m1,j)), hes_boundary_kernels.hpp:54-58.  The host rejects
+    // m2 > m1, so every v-row receives at most one entry.
+    for (int jj = tid; jj <= m2; jj += nth) {
+        const long long idx = (long long)m1 * (jj + 1);
+        const int row = (int)(idx / (m1 + 1)), col = (int)(idx % (m1 + 1));
+        double *rc = t.rowc + (size_t)row * HADI_RC;
+        rc[RC_B1VAL] = (in.r_d - in.r_f) * in.vec_s[m1] * E;
+        rc[RC_B1COL] = (double)col;
+    }
+    // --- column pass: per-chunk pentadiagonal LU + SPIKE vectors ----------------------------------
+    const double *l2 = t.a2i, *l1 = t.a2i + nrows, *dm = t.a2i + 2 * nrows, *u1 = t.a2i + 3 * nrows,
+                 *u2 = t.a2i + 4 * nrows;
+    const int P = L.P;
+    for (int p = tid; p < P; p += nth) {
+        int ja, len;
+        hadi_chunk(nrows, P, p, &ja, &len);
+        double c1 = 0.0, c21 = 0.0;  // c, c2 of row k-1
+        double c0 = 0.0, c20 = 0.0;  // c, c2 of row k-2
+        for (int k = 0; k < len; k++) {
+            const int j = ja + k;
+            double *pb = t.pb + (size_t)j * HADI_PBW;
+            const double e2 = (k >= 2) ? l2[j] : 0.0;          // coupling to k-2 inside the chunk
+            const double Lk = (k >= 1) ? (l1[j] - e2 * c0) : 0.0;
+            const double den = dm[j] - Lk * c1 - e2 * c20;
+            const double q = 1.0 / den;
+            const double uu1 = (k + 1 < len) ? u1[j] : 0.0;
+            const double uu2 = (k + 2 < len) ? u2[j] : 0.0;
+            const double c = (uu1 - Lk * c21) * q;
+            const double c2 = uu2 * q;
+            pb[PB_L] = Lk; pb[PB_L2] = e2; pb[PB_Q] = q; pb[PB_C] = c; pb[PB_C2] = c2;
+            for (int z = PB_V0; z < HADI_PBW; z++) pb[z] = 0.0;
+            c0 = c1; c20 = c21; c1 = c; c21 = c2;
+        }
+    }
+    sync();
+    // spikes: thread (p, w) solves the chunk system for one coupling column.
+    //   V = M_pp^-1 [coupling to the previous chunk's last two unknowns x[ja-2], x[ja-1]]
+    //   W = M_pp^-1 [coupling to the next chunk's first two unknowns x[jb], x[jb+1]]
+    for (int pw = tid; pw < 4 * P; pw += nth) {
+        const int p = pw >> 2, w = pw & 3;
+        int ja, len;
+        hadi_chunk(nrows, P, p, &ja, &len);
+        if ((w < 2 && p == 0) || (w >= 2 && p == P - 1)) continue;
+        const int jb = ja + len;
+        // forward sweep with rhs given on the fly
+        double y1 = 0.0, y0 = 0.0;  // y_{k-1}, y_{k-2}
+        for (int k = 0; k < len; k++) {
+            const int j = ja + k;
+            double rhs = 0.0;
+            if (w == 0 && k == 0) rhs = l2[ja];
+            if (w == 1 && k == 0) rhs = l1[ja];
+            if (w == 1 && k == 1) rhs = l2[ja + 1];
+            if (w == 2 && k == len - 2) rhs = u2[jb - 2];
+            if (w == 2 && k == len - 1) rhs = u1[jb - 1];
+            if (w == 3 && k == len - 1) rhs = u2[jb - 1];
+            double *pb = t.pb + (size_t)j * HADI_PBW;
+            const double y = (rhs - pb[PB_L] * y1 - pb[PB_L2] * y0) * pb[PB_Q];
+            pb[PB_V0 + w] = y;
+            y0 = y1; y1 = y;
+        }
+        double x1 = 0.0, x2 = 0.0;  // x_{k+1}, x_{k+2}
+        for (int k = len - 1; k >= 0; k--) {
+            double *pb = t.pb + (size_t)(ja + k) * HADI_PBW;
+            const double x = pb[PB_V0 + w] - pb[PB_C] * x1 - pb[PB_C2] * x2;
+            pb[PB_V0 + w] = x;
+            x2 = x1; x1 = x;
+        }
+    }
+    sync();
+    if (P > 1) {
+        // Reduced system R t = z on the 4P interface unknowns {first2, last2} of every chunk;
+        // invert it once by Gauss-Jordan (R = I + small couplings, cond ~ 3: no pivoting needed).
+        const int n4 = 4 * P, ldw = 2 * n4;
+        double *Wk = t.rwork;
+        for (int e = tid; e < n4 * ldw; e += nth) {
+            const int r = e / ldw, c = e % ldw;
+            Wk[e] = (c == r || c == n4 + r) ? 1.0 : 0.0;
+        }
+        sync();
+        for (int pq = tid; pq < n4; pq += nth) {
+            const int p = pq >> 2, qd = pq & 3;
+            int ja, len;
+            hadi_chunk(nrows, P, p, &ja, &len);
+            const int lrow = (qd == 0) ? 0 : (qd == 1) ? 1 : (qd == 2) ? len - 2 : len - 1;
+            const double *pb = t.pb + (size_t)(ja + lrow) * HADI_PBW;
+            if (p > 0) {
+                Wk[pq * ldw + 4 * (p - 1) + 2] += pb[PB_V0];
+                Wk[pq * ldw + 4 * (p - 1) + 3] += pb[PB_V1];
+            }
+            if (p < P - 1) {
+                Wk[pq * ldw + 4 * (p + 1) + 0] += pb[PB_W0];
+                Wk[pq * ldw + 4 * (p + 1) + 1] += pb[PB_W1];
+            }
+        }
+        sync();
+        for (int k = 0; k < n4; k++) {
+            const double piv = 1.0 / Wk[k * ldw + k];
+            sync();
+            for (int c = tid; c < ldw; c += nth) Wk[k * ldw + c] *= piv;
+            sync();
+            for (int e = tid; e < n4 * ldw; e += nth) {
+                const int r = e / ldw, c = e % ldw;
+                if (r != k && c != k) Wk[e] -= Wk[r * ldw + k] * Wk[k * ldw + c];
+            }
+            sync();
+            for (int r = tid; r < n4; r += nth)
+                if (r != k) Wk[r * ldw + k] = 0.0;
+            sync();
+        }
+        for (int e = tid; e < n4 * n4; e += nth) t.rinv[e] = Wk[(e / n4) * ldw + n4 + (e % n4)];
+    }
+    sync();
+}

@@ -1,0 +1,593 @@
+// hadi_kernels.h -- the gfx950 kernels of the Douglas ADI sweep.
+//
+// One Douglas step (device_solver.hpp:226-265) = two streaming passes over the state:
+//
+//   pass A (row pass, hadi_pass_a<B>): one 64-lane wavefront marches over R consecutive v-rows of
+//     one instance.  Lane l keeps the B s-nodes i = 1+B*l .. B*l+B of five v-rows in registers
+//     (rolling window), so the 9-point A0 stencil, the A1 3-point and the A2 5-point products
+//     (hes_a0_kernels.hpp:59-94, hes_a1_kernels.hpp:111-135, hes_a2_shuffled_kernels.hpp:180-239)
+//     need no LDS; it forms Y0 (device_solver.hpp:236-250), solves the A1 tridiagonal system of
+//     the row (hes_a1_kernels.hpp:139-161) with a wavefront-parallel partition method
+//     (in-lane Thomas on B-1 interior unknowns + parallel cyclic reduction over the 64 interface
+//     unknowns via cross-lane shuffles) and writes the A2 right-hand side (device_solver.hpp:254-260).
+//     Reads U once (+4 halo rows per tile), writes Y once: 16 B per point.
+//
+//   pass B (column pass, hadi_pass_b): lane <-> one s-column, so every v-row is read fully
+//     coalesced and the reference's shuffle/unshuffle transposes (hes_a2_shuffled_kernels.hpp:12-44)
+//     do not exist.  The pentadiagonal system (hes_a2_shuffled_kernels.hpp:243-299) has the same
+//     matrix for every column and time step, so its factorisation is precomputed per instance
+//     (hadi_core.h); the v-rows are cut into P chunks, one wavefront each, whose local solves run
+//     in registers and are coupled by a SPIKE reduced system exchanged through LDS.  Applies the
+//     American projection (device_solver.hpp:358-372).  Reads Y once, writes U once: 16 B per point.
+//
+// No MFMA: ~75 flop per 32 B.
+#pragma once
+#include "hadi_core.h"
+
+struct HadiSweepArgs {
+    // state, internal layout [inst][row][rowp]
+    double *U;         // solution
+    double *Y;         // A2 right-hand side between the passes
+    double *LAM;       // lambda_bar (American) or nullptr
+    const double *U0;  // payoff (American) or nullptr
+    // tables
+    const double *scoef, *b2row, *rowc, *pb, *rinv;
+    const HadiInstPar *ipar;
+    HadiLayout L;
+    int n_inst;
+    int R, ntiles;   // pass A: rows per wave, tiles per instance
+    int ctiles;      // pass B: 64-column tiles per instance
+    int american;
+    int pos_m1;      // storage position of i = m1 (lambda_bar is forced to 0 there)
+};
+
+// Blocks b and b+8 share an XCD (and its L2).  Map the dispatch index so that consecutive logical
+// ids -- neighbouring row tiles of one instance, which share halo rows -- land on the same XCD.
+HADI_DEV HADI_FORCEINLINE int hadi_xcd_remap(int bid, int nblk_padded) {
+    const int per = nblk_padded >> 3;
+    return (bid & 7) * per + (bid >> 3);
+}
+
+template <int B>
+HADI_DEV HADI_FORCEINLINE void hadi_load_row(const double *__restrict__ row, int lane, bool valid, double (&u)[B]) {
+    if (!valid) {
+#pragma unroll
+        for (int r = 0; r < B; r++) u[r] = 0.0;
+        return;
+    }
+    if constexpr (B == 1) {
+        u[0] = row[lane];
+    } else {
+#pragma unroll
+        for (int q = 0; q < B / 2; q++) {
+            const double2 t = *reinterpret_cast<const double2 *>(row + q * 128 + 2 * lane);
+            u[2 * q] = t.x;
+            u[2 * q + 1] = t.y;
+        }
+    }
+}
+
+template <int B>
+HADI_DEV HADI_FORCEINLINE void hadi_store_row(double *__restrict__ row, int lane, const double (&u)[B]) {
+    if constexpr (B == 1) {
+        row[lane] = u[0];
+    } else {
+#pragma unroll
+        for (int q = 0; q < B / 2; q++) {
+            double2 t;
+            t.x = u[2 * q];
+            t.y = u[2 * q + 1];
+            *reinterpret_cast<double2 *>(row + q * 128 + 2 * lane) = t;
+        }
+    }
+}
+
+// B-weighted s-derivative of one row: sb[r] = Bm[r] u[r-1] + Bz[r] u[r] + Bp[r] u[r+1], with the
+// neighbours of the lane's block fetched from the adjacent lanes (eL/eR are returned for reuse).
+template <int B>
+HADI_DEV HADI_FORCEINLINE void hadi_sderiv(const double (&u)[B], double c0val, int lane, const double (&Bm)[B],
+                                           const double (&Bz)[B], const double (&Bp)[B], double (&sb)[B],
+                                           double &eL, double &eR) {
+    eL = __shfl_up(u[B - 1], 1);
+    if (lane == 0) eL = c0val;
+    eR = __shfl_down(u[0], 1);
+    if (lane == 63) eR = 0.0;
+#pragma unroll
+    for (int r = 0; r < B; r++) {
+        const double uL = (r == 0) ? eL : u[r == 0 ? 0 : r - 1];
+        const double uR = (r == B - 1) ? eR : u[r == B - 1 ? r : r + 1];
+        sb[r] = Bm[r] * uL + Bz[r] * u[r] + Bp[r] * uR;
+    }
+}
+
+template <int B>
+__global__ void __launch_bounds__(64) hadi_pass_a(HadiSweepArgs a, int n) {
+    const int lane = threadIdx.x;
+    const int total = a.n_inst * a.ntiles;
+    const int logical = hadi_xcd_remap(blockIdx.x, gridDim.x);
+    if (logical >= total) return;
+    const int inst = logical / a.ntiles, tile = logical - inst * a.ntiles;
+    const HadiInstPar ip = a.ipar[inst];
+    if (n > ip.N) return;
+    const int nrows = a.L.nrows, rowp = a.L.rowp;
+    const int j0 = tile * a.R;
+    const int j1 = (j0 + a.R < nrows) ? j0 + a.R : nrows;
+    if (j0 >= j1) return;
+
+    const double dt = ip.dt, thdt = ip.thdt, q = ip.q, half_rd = ip.half_rd;
+    const double e_nm1 = exp(ip.r_f * dt * (n - 1));  // device_solver.hpp:238
+    const double e_n = exp(ip.r_f * dt * n);          // device_solver.hpp:246
+
+    const double *__restrict__ Ub = a.U + (size_t)inst * a.L.inst_stride;
+    double *__restrict__ Yb = a.Y + (size_t)inst * a.L.inst_stride;
+    const double *__restrict__ Lb = a.american ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
+    const double *__restrict__ rowc = a.rowc + (size_t)inst * nrows * HADI_RC;
+    const double *__restrict__ sc = a.scoef + (size_t)inst * 6 * 64 * B;
+    const double *__restrict__ b2r = a.b2row + (size_t)inst * rowp;
+    const int c0slot = 64 * B;
+
+    // j- and time-invariant s-coefficients of this lane's B nodes
+    double Bm[B], Bz[B], Bp[B], Dm[B], Dz[B], Dp[B];
+    hadi_load_row<B>(sc + 0 * 64 * B, lane, true, Bm);
+    hadi_load_row<B>(sc + 1 * 64 * B, lane, true, Bz);
+    hadi_load_row<B>(sc + 2 * 64 * B, lane, true, Bp);
+    hadi_load_row<B>(sc + 3 * 64 * B, lane, true, Dm);
+    hadi_load_row<B>(sc + 4 * 64 * B, lane, true, Dz);
+    hadi_load_row<B>(sc + 5 * 64 * B, lane, true, Dp);
+
+    // rolling window of v-rows j-2 .. j+2 (u*) and of column i = 0 (c*); rows outside the grid are 0
+    double um2[B], um1[B], u0[B], up1[B], up2[B];
+    double cm2, cm1, c0, cp1, cp2;
+    auto rowptr = [&](int j) { return Ub + (size_t)j * rowp; };
+    auto inrange = [&](int j) { return j >= 0 && j < nrows; };
+    hadi_load_row<B>(rowptr(j0 - 2), lane, inrange(j0 - 2), um2);
+    hadi_load_row<B>(rowptr(j0 - 1), lane, inrange(j0 - 1), um1);
+    hadi_load_row<B>(rowptr(j0), lane, true, u0);
+    hadi_load_row<B>(rowptr(j0 + 1), lane, inrange(j0 + 1), up1);
+    cm2 = inrange(j0 - 2) ? rowptr(j0 - 2)[c0slot] : 0.0;
+    cm1 = inrange(j0 - 1) ? rowptr(j0 - 1)[c0slot] : 0.0;
+    c0 = rowptr(j0)[c0slot];
+    cp1 = inrange(j0 + 1) ? rowptr(j0 + 1)[c0slot] : 0.0;
+
+    // B-weighted s-derivatives of rows j-1, j, j+1 (A0 needs all three, A1 the middle one's edges)
+    double sbm[B], sb0[B], sbp[B];
+    double eL0, eR0, eLp, eRp, eTmpL, eTmpR;
+    hadi_sderiv<B>(um1, cm1, lane, Bm, Bz, Bp, sbm, eTmpL, eTmpR);
+    hadi_sderiv<B>(u0, c0, lane, Bm, Bz, Bp, sb0, eL0, eR0);
+    hadi_sderiv<B>(up1, cp1, lane, Bm, Bz, Bp, sbp, eLp, eRp);
+
+    for (int j = j0; j < j1; j++) {
+        // prefetch row j+2 (consumed by A2 now, becomes the centre row two iterations later)
+        hadi_load_row<B>(rowptr(j + 2), lane, inrange(j + 2), up2);
+        cp2 = inrange(j + 2) ? rowptr(j + 2)[c0slot] : 0.0;
+        double lam[B];
+        double lamc0 = 0.0;
+        if (a.american) {
+            hadi_load_row<B>(Lb + (size_t)j * rowp, lane, true, lam);
+            lamc0 = Lb[(size_t)j * rowp + c0slot];
+        }
+
+        const double *__restrict__ rc = rowc + (size_t)j * HADI_RC;
+        const double v = rc[RC_V];
+        const double wm = rc[RC_WM], wz = rc[RC_WZ], wp = rc[RC_WP];
+        const double a2l2 = rc[RC_L2], a2l1 = rc[RC_L1], a2m = rc[RC_M], a2u1 = rc[RC_U1], a2u2 = rc[RC_U2];
+        const double b1val = rc[RC_B1VAL];
+        const int b1col = (int)rc[RC_B1COL];
+        const bool last = rc[RC_LAST] != 0.0;
+        // b1 sits at s-index b1col of this row: which lane / slot is that?
+        const int b1e = b1col - 1;
+        const int b1lane = (b1col >= 1) ? b1e / B : -1;
+        const int b1r = (b1col >= 1) ? b1e - b1lane * B : -1;
+
+        // ---- column i = 0 (A0 and A1 rows are zero there; only A2 and the boundary act) --------
+        const double a2c0 = a2l2 * cm2 + a2l1 * cm1 + a2m * c0 + a2u1 * cp1 + a2u2 * cp2;
+        const double b1c0 = (b1col == 0) ? b1val : 0.0;
+        const double b2c0 = last ? b2r[c0slot] : 0.0;
+        double y0c0 = c0 + dt * (a2c0 + (b1c0 + b2c0) * e_nm1 + lamc0);
+        y0c0 = y0c0 + thdt * (b1c0 * e_n - (0.0 + b1c0 * e_nm1));
+        const double x0 = y0c0;  // A1 row 0 is the identity (hes_a1_kernels.hpp:56-61)
+        const double yout_c0 = x0 + thdt * (b2c0 * e_n - (a2c0 + b2c0 * e_nm1));
+
+        // ---- explicit stage on the lane's B nodes --------------------------------------------------
+        double b2v[B];
+        hadi_load_row<B>(b2r, lane, last, b2v);
+        double A2U[B], d[B], il[B], im[B], iu[B];
+#pragma unroll
+        for (int r = 0; r < B; r++) {
+            const double uL = (r == 0) ? eL0 : u0[r == 0 ? 0 : r - 1];
+            const double uR = (r == B - 1) ? eR0 : u0[r == B - 1 ? r : r + 1];
+            const double lo = fma(v, Dm[r], q * Bm[r]);
+            const double mn = fma(v, Dz[r], fma(q, Bz[r], -half_rd));
+            const double up = fma(v, Dp[r], q * Bp[r]);
+            const double A1U = lo * uL + mn * u0[r] + up * uR;
+            const double A0U = wm * sbm[r] + wz * sb0[r] + wp * sbp[r];
+            A2U[r] = a2l2 * um2[r] + a2l1 * um1[r] + a2m * u0[r] + a2u1 * up1[r] + a2u2 * up2[r];
+            const double b1h = (lane == b1lane && r == b1r) ? b1val : 0.0;
+            double S = A0U + A1U + A2U[r] + (b1h + b2v[r]) * e_nm1;
+            if (a.american) S += lam[r];
+            double y = u0[r] + dt * S;
+            y = y + thdt * (b1h * e_n - (A1U + b1h * e_nm1));
+            d[r] = y;
+            il[r] = -thdt * lo;
+            im[r] = 1.0 - thdt * mn;
+            iu[r] = -thdt * up;
+        }
+        // x_0 is known: move it to the right-hand side of the first unknown
+        if (lane == 0) {
+            d[0] -= il[0] * x0;
+            il[0] = 0.0;
+        }
+
+        // ---- A1 solve: in-lane Thomas on r = 0..B-2 against both interfaces ------------------------
+        //   x[r] = y[r] - XL*p[r] - X*g[r],  XL = interface unknown of lane-1, X = own x[B-1]
+        constexpr int NB = B - 1;
+        double ys[B], ps[B], gs[B], invt[B];  // sized B so B == 1 compiles; entries [0..NB) used
+        double ra, rb, rcc, rf;
+        if constexpr (NB > 0) {
+            invt[0] = hadi_rcp(im[0]);
+            ys[0] = d[0];
+            ps[0] = il[0];
+#pragma unroll
+            for (int r = 1; r < NB; r++) {
+                const double w = il[r] * invt[r - 1];
+                invt[r] = hadi_rcp(fma(-w, iu[r - 1], im[r]));
+                ys[r] = fma(-w, ys[r - 1], d[r]);
+                ps[r] = -w * ps[r - 1];
+            }
+            gs[NB - 1] = iu[NB - 1] * invt[NB - 1];
+            ys[NB - 1] *= invt[NB - 1];
+            ps[NB - 1] *= invt[NB - 1];
+#pragma unroll
+            for (int r = NB - 2; r >= 0; r--) {
+                ys[r] = fma(-iu[r], ys[r + 1], ys[r]) * invt[r];
+                ps[r] = fma(-iu[r], ps[r + 1], ps[r]) * invt[r];
+                gs[r] = -iu[r] * gs[r + 1] * invt[r];
+            }
+            // interface row of this lane couples to XL, X and the next lane's X
+            const double p0n = __shfl_down(ps[0], 1);
+            const double g0n = __shfl_down(gs[0], 1);
+            const double y0n = __shfl_down(ys[0], 1);
+            ra = -il[B - 1] * ps[NB - 1];
+            rb = im[B - 1] - il[B - 1] * gs[NB - 1] - iu[B - 1] * p0n;
+            rcc = -iu[B - 1] * g0n;
+            rf = d[B - 1] - il[B - 1] * ys[NB - 1] - iu[B - 1] * y0n;
+        } else {
+            ra = il[0];
+            rb = im[0];
+            rcc = iu[0];
+            rf = d[0];
+        }
+        // ---- parallel cyclic reduction over the 64 interface unknowns (normalised rows) -----------
+        {
+            const double rinv0 = hadi_rcp(rb);
+            ra *= rinv0;
+            rcc *= rinv0;
+            rf *= rinv0;
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) {
+                const double aL = __shfl_up(ra, s), cL = __shfl_up(rcc, s), fL = __shfl_up(rf, s);
+                const double aR = __shfl_down(ra, s), cR = __shfl_down(rcc, s), fR = __shfl_down(rf, s);
+                // lanes without a partner at distance s have ra == 0 (left) / rcc == 0 (right), so
+                // the wrapped values they fetch are multiplied by zero
+                const double bn = 1.0 - ra * cL - rcc * aR;
+                const double rn = hadi_rcp(bn);
+                const double fn = (rf - ra * fL - rcc * fR) * rn;
+                const double an = (lane >= s) ? (-ra * aL) * rn : 0.0;
+                const double cn = (lane + s < 64) ? (-rcc * cR) * rn : 0.0;
+                ra = an;
+                rcc = cn;
+                rf = fn;
+            }
+        }
+        const double X = rf;
+        double XL = __shfl_up(X, 1);
+        if (lane == 0) XL = 0.0;
+
+        // ---- Y1 -> right-hand side of the A2 solve (device_solver.hpp:254-260) and store --------
+        double yo[B];
+#pragma unroll
+        for (int r = 0; r < B; r++) {
+            double x;
+            if (r < NB) x = ys[r] - XL * ps[r] - X * gs[r];
+            else x = X;
+            yo[r] = x + thdt * (b2v[r] * e_n - (A2U[r] + b2v[r] * e_nm1));
+        }
+        hadi_store_row<B>(Yb + (size_t)j * rowp, lane, yo);
+        if (lane == 0) Yb[(size_t)j * rowp + c0slot] = yout_c0;
+
+        // ---- roll the window ---------------------------------------------------------------------
+#pragma unroll
+        for (int r = 0; r < B; r++) {
+            um2[r] = um1[r];
+            um1[r] = u0[r];
+            u0[r] = up1[r];
+            up1[r] = up2[r];
+            sbm[r] = sb0[r];
+            sb0[r] = sbp[r];
+        }
+        cm2 = cm1; cm1 = c0; c0 = cp1; cp1 = cp2;
+        eL0 = eLp; eR0 = eRp;
+        if (j + 1 < j1) hadi_sderiv<B>(up1, cp1, lane, Bm, Bz, Bp, sbp, eLp, eRp);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass B.  Block = P wavefronts (P*64 threads) <-> 64 storage columns of one instance; wavefront p
+// owns v-rows [ja, ja+len) and keeps its y/x values in registers.
+__global__ void __launch_bounds__(64 * HADI_MAX_P) hadi_pass_b(HadiSweepArgs a, int n) {
+    __shared__ double zsh[HADI_MAX_P * 4 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int P = a.L.P;
+    const int inst = blockIdx.x / a.ctiles, ctile = blockIdx.x - inst * a.ctiles;
+    const HadiInstPar ip = a.ipar[inst];
+    if (n > ip.N) return;  // whole block: uniform
+    const int nrows = a.L.nrows, rowp = a.L.rowp;
+    const int col = ctile * 64 + lane;
+    const bool valid = col < rowp;
+    const int colc = valid ? col : rowp - 1;  // clamp: inactive lanes compute on a valid address, never store
+    int ja, len;
+    hadi_chunk(nrows, P, wave, &ja, &len);
+
+    const double *__restrict__ Yb = a.Y + (size_t)inst * a.L.inst_stride + colc;
+    double *__restrict__ Ub = a.U + (size_t)inst * a.L.inst_stride + colc;
+    const double *__restrict__ pb = a.pb + ((size_t)inst * nrows + ja) * HADI_PBW;
+
+    double y[HADI_LC];
+#pragma unroll
+    for (int k = 0; k < HADI_LC; k++) y[k] = (k < len) ? Yb[(size_t)(ja + k) * rowp] : 0.0;
+
+    // forward elimination with the chunk-local factorisation
+    {
+        double ym1 = 0.0, ym2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < HADI_LC; k++) {
+            if (k < len) {
+                const double *__restrict__ t = pb + (size_t)k * HADI_PBW;
+                const double yk = (y[k] - t[PB_L] * ym1 - t[PB_L2] * ym2) * t[PB_Q];
+                y[k] = yk;
+                ym2 = ym1;
+                ym1 = yk;
+            }
+        }
+    }
+    // back substitution; remember the chunk's first two / last two unknowns for the reduced system
+    double zl0 = 0.0, zl1 = 0.0;
+    {
+        double xp1 = 0.0, xp2 = 0.0;
+#pragma unroll
+        for (int k = HADI_LC - 1; k >= 0; k--) {
+            if (k < len) {
+                const double *__restrict__ t = pb + (size_t)k * HADI_PBW;
+                const double xk = y[k] - t[PB_C] * xp1 - t[PB_C2] * xp2;
+                y[k] = xk;
+                xp2 = xp1;
+                xp1 = xk;
+                if (k == len - 1) zl1 = xk;
+                if (k == len - 2) zl0 = xk;
+            }
+        }
+    }
+    if (P > 1) {
+        zsh[(wave * 4 + 0) * 64 + lane] = y[0];
+        zsh[(wave * 4 + 1) * 64 + lane] = y[1];
+        zsh[(wave * 4 + 2) * 64 + lane] = zl0;
+        zsh[(wave * 4 + 3) * 64 + lane] = zl1;
+        __syncthreads();
+        // t = Rinv z : this chunk needs the previous chunk's last two and the next chunk's first two
+        const int n4 = 4 * P;
+        const double *__restrict__ Ri = a.rinv + (size_t)inst * n4 * n4;
+        double tl0 = 0.0, tl1 = 0.0, tr0 = 0.0, tr1 = 0.0;
+        const int rl0 = (wave > 0) ? 4 * (wave - 1) + 2 : 0, rr0 = (wave < P - 1) ? 4 * (wave + 1) : 0;
+        for (int m = 0; m < n4; m++) {
+            const double z = zsh[m * 64 + lane];
+            tl0 = fma(Ri[(size_t)rl0 * n4 + m], z, tl0);
+            tl1 = fma(Ri[(size_t)(rl0 + 1) * n4 + m], z, tl1);
+            tr0 = fma(Ri[(size_t)rr0 * n4 + m], z, tr0);
+            tr1 = fma(Ri[(size_t)(rr0 + 1) * n4 + m], z, tr1);
+        }
+        // spikes are zero where there is no neighbour (first chunk: V = 0, last chunk: W = 0)
+#pragma unroll
+        for (int k = 0; k < HADI_LC; k++) {
+            if (k < len) {
+                const double *__restrict__ t = pb + (size_t)k * HADI_PBW;
+                y[k] = y[k] - t[PB_V0] * tl0 - t[PB_V1] * tl1 - t[PB_W0] * tr0 - t[PB_W1] * tr1;
+            }
+        }
+    }
+    if (!a.american) {
+#pragma unroll
+        for (int k = 0; k < HADI_LC; k++)
+            if (k < len && valid) Ub[(size_t)(ja + k) * rowp] = y[k];
+    } else {
+        // Ikonen-Toivanen projection, device_solver.hpp:358-372
+        double *__restrict__ Lb = a.LAM + (size_t)inst * a.L.inst_stride + colc;
+        const double *__restrict__ P0 = a.U0 + (size_t)inst * a.L.inst_stride + colc;
+        const double dt = ip.dt;
+        const bool is_smax = (col == a.pos_m1);
+#pragma unroll
+        for (int k = 0; k < HADI_LC; k++) {
+            if (k < len) {
+                const size_t off = (size_t)(ja + k) * rowp;
+                const double U_bar = y[k];
+                const double lamv = Lb[off];
+                const double pay = P0[off];
+                const double un = fmax(U_bar - dt * lamv, pay);
+                double ln = fmax(0.0, lamv + (pay - U_bar) / dt);
+                if (is_smax) ln = 0.0;
+                if (valid) {
+                    Ub[off] = un;
+                    Lb[off] = ln;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Setup: one block per instance builds all operator tables (replaces bounds.initialize and the three
+// build_matrix calls at the top of every reference launcher, e.g. jacobian_computation.cpp:255-261).
+struct HadiSetupArgs {
+    HadiLayout L;
+    int n_inst;
+    const double *vec_s, *vec_v, *delta_s, *delta_v;  // [n][..] natural arrays (device)
+    const double *par;  // [n][8]: rho, sigma, kappa, eta, dt, N (as double), spare, spare
+    double r_d, r_f, theta;
+    double *scoef, *b2row, *rowc, *a2i, *pb, *rinv, *rwork;
+    HadiInstPar *ipar;
+};
+
+struct HadiBlockSync {
+    HADI_DEV void operator()() const { __syncthreads(); }
+};
+
+__global__ void __launch_bounds__(256) hadi_setup_kernel(HadiSetupArgs s) {
+    const int inst = blockIdx.x;
+    if (inst >= s.n_inst) return;
+    const HadiLayout &L = s.L;
+    HadiSetupIn in;
+    in.vec_s = s.vec_s + (size_t)inst * (L.m1 + 1);
+    in.vec_v = s.vec_v + (size_t)inst * (L.m2 + 1);
+    in.delta_s = s.delta_s + (size_t)inst * L.m1;
+    in.delta_v = s.delta_v + (size_t)inst * L.m2;
+    const double *par = s.par + (size_t)inst * 8;
+    in.rho = par[0]; in.sigma = par[1]; in.kappa = par[2]; in.eta = par[3];
+    in.dt = par[4]; in.N = (int)par[5];
+    in.r_d = s.r_d; in.r_f = s.r_f; in.theta = s.theta;
+    HadiTables t;
+    const int n4 = 4 * L.P;
+    t.scoef = s.scoef + (size_t)inst * 6 * 64 * L.B;
+    t.b2row = s.b2row + (size_t)inst * L.rowp;
+    t.rowc = s.rowc + (size_t)inst * L.nrows * HADI_RC;
+    t.a2i = s.a2i + (size_t)inst * 5 * L.nrows;
+    t.pb = s.pb + (size_t)inst * L.nrows * HADI_PBW;
+    t.rinv = s.rinv + (size_t)inst * n4 * n4;
+    t.rwork = s.rwork + (size_t)inst * n4 * 2 * n4;
+    t.ipar = s.ipar + inst;
+    hadi_setup_instance(L, in, t, (int)threadIdx.x, (int)blockDim.x, HadiBlockSync());
+}
+
+// ------------------------------------------------------------------------------------------------
+// Layout conversion natural [inst][j][i] <-> internal [inst][j][pos(i)] (pads written as 0).
+// Instance k of the internal array reads natural instance k % n_src (a Jacobian batch replicates U_0).
+__global__ void __launch_bounds__(256) hadi_pack_kernel(HadiLayout L, int n_inst, int n_src,
+                                                        const double *__restrict__ nat, double *__restrict__ internal) {
+    const size_t total = (size_t)n_inst * L.nrows * L.rowp;
+    const size_t m = (size_t)(L.m1 + 1) * L.nrows;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int slot = (int)(e % L.rowp);
+        const size_t rowid = e / L.rowp;
+        const int j = (int)(rowid % L.nrows);
+        const size_t inst = rowid / L.nrows;
+        // invert pos(): slot -> i
+        int i;
+        if (slot == 64 * L.B) i = 0;
+        else if (slot > 64 * L.B) i = -1;
+        else if (L.B == 1) i = slot + 1;
+        else {
+            const int qq = slot >> 7, rem = slot & 127, lane = rem >> 1, r = 2 * qq + (rem & 1);
+            i = 1 + L.B * lane + r;
+        }
+        double v = 0.0;
+        if (i >= 0 && i <= L.m1) v = nat[(inst % (size_t)n_src) * m + (size_t)j * (L.m1 + 1) + i];
+        internal[e] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) hadi_unpack_kernel(HadiLayout L, int n_inst, const double *__restrict__ internal,
+                                                          double *__restrict__ nat) {
+    const size_t m = (size_t)(L.m1 + 1) * L.nrows;
+    const size_t total = (size_t)n_inst * m;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e % (L.m1 + 1));
+        const size_t rowid = e / (L.m1 + 1);
+        const int j = (int)(rowid % L.nrows);
+        const size_t inst = rowid / L.nrows;
+        nat[e] = internal[inst * L.inst_stride + (size_t)j * L.rowp + hadi_pos(L.B, i)];
+    }
+}
+
+__global__ void __launch_bounds__(256) hadi_fill_kernel(double *__restrict__ p, size_t n, double v) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) p[e] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Discrete dividend jump (device_solver.hpp:448-504) on the internal layout: U <- interp(UT) where
+// UT is a copy of U taken before the jump.  One thread per (row, s-node); the reference's linear
+// search "first k with s_k > new_s" is a binary search on the ascending s-grid.
+__global__ void __launch_bounds__(256) hadi_dividend_kernel(HadiLayout L, int n_inst, const double *__restrict__ vec_s,
+                                                            const double *__restrict__ UT, double *__restrict__ U,
+                                                            double amount, double pct) {
+    const int m1 = L.m1;
+    const size_t per = (size_t)L.nrows * (m1 + 1);
+    const size_t total = (size_t)n_inst * per;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e % (m1 + 1));
+        const size_t rowid = e / (m1 + 1);
+        const int j = (int)(rowid % L.nrows);
+        const size_t inst = rowid / L.nrows;
+        const double *__restrict__ s = vec_s + inst * (m1 + 1);
+        const double *__restrict__ src = UT + inst * L.inst_stride + (size_t)j * L.rowp;
+        const double old_s = s[i];
+        const double new_s = old_s * (1.0 - pct) - amount;
+        double out = 0.0;
+        if (new_s > 0) {
+            // idx = first k in [0, m1] with s[k] > new_s, 0 if none
+            int lo = 0, hi = m1 + 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s[mid] > new_s) hi = mid;
+                else lo = mid + 1;
+            }
+            const int idx = (lo <= m1) ? lo : 0;
+            if (idx > 0) {
+                const double s_low = s[idx - 1], s_high = s[idx];
+                const double weight = (new_s - s_low) / (s_high - s_low);
+                const double val_low = src[hadi_pos(L.B, idx - 1)], val_high = src[hadi_pos(L.B, idx)];
+                out = (1.0 - weight) * val_low + weight * val_high;
+            } else {
+                out = src[hadi_pos(L.B, 0)];
+            }
+        }
+        U[inst * L.inst_stride + (size_t)j * L.rowp + hadi_pos(L.B, i)] = out;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Price pick (jacobian_computation.cpp:275-288): first s-node with |s_i - S_0| < 1e-10, first
+// v-node with |v_j - V_0| < 1e-10 (0 if none, grid_pod.hpp:76-87).  status[inst] = 1 if S_0 is off-grid.
+__global__ void __launch_bounds__(64) hadi_pick_kernel(HadiLayout L, int n_inst, const double *__restrict__ vec_s,
+                                                       const double *__restrict__ vec_v, const double *__restrict__ U,
+                                                       double S_0, const double *__restrict__ V0_i, double V_0,
+                                                       double *__restrict__ prices, int price_stride,
+                                                       int *__restrict__ status) {
+    const int inst = blockIdx.x * blockDim.x + threadIdx.x;
+    if (inst >= n_inst) return;
+    const double *s = vec_s + (size_t)inst * (L.m1 + 1);
+    const double *v = vec_v + (size_t)inst * (L.m2 + 1);
+    const double v0 = V0_i ? V0_i[inst] : V_0;
+    int is = -1, iv = 0;
+    for (int i = 0; i <= L.m1; i++)
+        if (fabs(s[i] - S_0) < 1e-10) { is = i; break; }
+    for (int j = 0; j <= L.m2; j++)
+        if (fabs(v[j] - v0) < 1e-10) { iv = j; break; }
+    if (is < 0) {
+        status[inst] = 1;
+        prices[(size_t)inst * price_stride] = nan("");
+        return;
+    }
+    status[inst] = 0;
+    prices[(size_t)inst * price_stride] = U[(size_t)inst * L.inst_stride + (size_t)iv * L.rowp + hadi_pos(L.B, is)];
+}
+
+// Replicate one of `nsrc` source rows (length len) into every instance's row: dst[inst] = src[sel[inst]]
+// (sel == nullptr: src row 0).  Used to hand every instance the v-grid rebuilt for V_0 (or V_0+eps).
+__global__ void __launch_bounds__(256) hadi_bcast_rows_kernel(int len, int n_inst, const double *__restrict__ src,
+                                                              const int *__restrict__ sel, double *__restrict__ dst) {
+    const size_t total = (size_t)n_inst * len;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t inst = e / len;
+        const int k = (int)(e - inst * len);
+        const int sr = sel ? sel[inst] : 0;
+        dst[e] = src[(size_t)sr * len + k];
+    }
+}

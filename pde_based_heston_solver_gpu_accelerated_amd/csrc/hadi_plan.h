@@ -1,0 +1,57 @@
+// hadi_plan.h -- host-side choice of layout and launch geometry for one batch shape.
+#pragma once
+#include "hadi_core.h"
+
+struct HadiPlan {
+    HadiLayout L;
+    int R, ntiles;       // pass A: v-rows per wavefront, wavefront tiles per instance
+    int grid_a;          // pass A grid (64-thread blocks), padded to a multiple of 8 for the XCD remap
+    int ctiles;          // pass B: 64-column tiles per instance
+    int grid_b, block_b; // pass B grid / block (P*64 threads)
+    int pos_m1;
+    // table sizes per instance (doubles)
+    size_t n_scoef, n_b2row, n_rowc, n_a2i, n_pb, n_rinv, n_rwork;
+};
+
+// Returns 0 on success, 1 if the shape is outside what the kernels cover.
+inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan *out) {
+    if (m1 < 2 || m2 < 3 || n_inst < 1) return 1;
+    if (m2 > m1) return 1;           // b1 would put two entries on one v-row (hadi_core.h)
+    if (m1 > 64 * 16) return 1;      // row pass keeps at most 16 nodes per lane
+    HadiPlan p;
+    HadiLayout &L = p.L;
+    L.m1 = m1; L.m2 = m2; L.nrows = m2 + 1;
+    L.B = hadi_pick_B(m1);
+    L.rowp = 64 * L.B + 8;
+    L.P = (L.nrows + HADI_LC - 1) / HADI_LC;
+    if (L.P > HADI_MAX_P) return 1;
+    // every chunk needs >= 2 rows for its first2/last2 interface pairs
+    if (L.P > 1 && L.nrows / L.P < 2) return 1;
+    L.inst_stride = (long long)L.rowp * L.nrows;
+    // Row tiles: as tall as possible (halo re-reads cost 4/R) while the launch still has
+    // >= target_waves wavefronts (256 CUs x 4 SIMDs x a few waves).
+    int ntiles = (target_waves + n_inst - 1) / n_inst;
+    if (ntiles < 1) ntiles = 1;
+    int R = (L.nrows + ntiles - 1) / ntiles;
+    if (R < 2) R = 2;
+    if (R > 40) R = 40;
+    ntiles = (L.nrows + R - 1) / R;
+    R = (L.nrows + ntiles - 1) / ntiles;  // balance
+    p.R = R;
+    p.ntiles = ntiles;
+    const long long total = (long long)n_inst * ntiles;
+    p.grid_a = (int)((total + 7) / 8 * 8);
+    p.ctiles = (L.rowp + 63) / 64;
+    p.grid_b = n_inst * p.ctiles;
+    p.block_b = 64 * L.P;
+    p.pos_m1 = hadi_pos(L.B, m1);
+    p.n_scoef = (size_t)6 * 64 * L.B;
+    p.n_b2row = (size_t)L.rowp;
+    p.n_rowc = (size_t)L.nrows * HADI_RC;
+    p.n_a2i = (size_t)5 * L.nrows;
+    p.n_pb = (size_t)L.nrows * HADI_PBW;
+    p.n_rinv = (size_t)16 * L.P * L.P;
+    p.n_rwork = (size_t)32 * L.P * L.P;
+    *out = p;
+    return 0;
+}

@@ -1,0 +1,310 @@
+"""Host-side mirror of the reference's batched launchers over libhadi's C ABI.
+
+Names, argument order and meaning follow the reference (`parallel_DO_solve`,
+src/device_solver.hpp:52-79; `compute_base_prices*` / `compute_jacobian*`,
+src/jacobian_computation.hpp:43-231); the Kokkos struct arrays that only carry scratch
+(A0/A1/A2 solvers, bounds_d) have no counterpart because the library owns its scratch.
+
+Arrays may be numpy float64 (host memory, staged by the library) or torch CUDA tensors
+(HBM-resident, passed as device pointers).  All arrays of one call must live in the same space.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nat
+from ._native import EU, AM, DIV, AM_DIV, HadiError  # noqa: F401  (re-exported)
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def _is_device(x):
+    return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
+
+
+def _check_array(x, name, count):
+    if _is_device(x):
+        import torch
+        if x.dtype != torch.float64 or not x.is_contiguous():
+            raise ValueError("%s must be a contiguous float64 tensor" % name)
+        if x.numel() != count:
+            raise ValueError("%s has %d elements, expected %d" % (name, x.numel(), count))
+        return C.cast(C.c_void_p(x.data_ptr()), _dp), True
+    if not isinstance(x, np.ndarray) or x.dtype != np.float64 or not x.flags.c_contiguous:
+        raise ValueError("%s must be a C-contiguous float64 numpy array or CUDA tensor" % name)
+    if x.size != count:
+        raise ValueError("%s has %d elements, expected %d" % (name, x.size, count))
+    return x.ctypes.data_as(_dp), False
+
+
+def _host_f64(x):
+    return None if x is None else np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+
+
+class Dividends:
+    """The three dividend views of the reference (device_solver.hpp:409-413)."""
+
+    def __init__(self, dates, amounts, percentages):
+        self.dates, self.amounts, self.percentages = _host_f64(dates), _host_f64(amounts), _host_f64(percentages)
+        if not (len(self.dates) == len(self.amounts) == len(self.percentages)):
+            raise ValueError("dividend arrays differ in length")
+
+    def __len__(self):
+        return len(self.dates)
+
+
+class DOWorkspace:
+    """DO_Workspace<Device> (src/DO_solver_workspace.hpp:4-44).  Only `U` carries data across the
+    boundary (initial condition in, solution out); the reference's other eleven arrays are scratch
+    and live inside the library handle here.  `lambda_bar` is filled by the American variants."""
+
+    def __init__(self, nInstances, total_size, device=None):
+        if device is None:
+            self.U = np.zeros((nInstances, total_size))
+            self.lambda_bar = np.zeros((nInstances, total_size))
+        else:
+            import torch
+            self.U = torch.zeros((nInstances, total_size), dtype=torch.float64, device=device)
+            self.lambda_bar = torch.zeros((nInstances, total_size), dtype=torch.float64, device=device)
+
+
+class HestonADI:
+    """One library handle = one GPU + one HIP stream (the reference's single Kokkos device)."""
+
+    def __init__(self, device_id=0):
+        self._lib = nat.lib()
+        h = C.c_void_p()
+        rc = self._lib.hadi_create(C.byref(h), int(device_id))
+        if rc != nat.HADI_OK:
+            raise HadiError(rc, self._lib.hadi_status_string(rc).decode())
+        self._h = h
+        self.device_id = int(device_id)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.hadi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- introspection ------------------------------------------------------------------------
+    def _raise(self, rc):
+        raise HadiError(rc, self._lib.hadi_last_error(self._h).decode() or self._lib.hadi_status_string(rc).decode())
+
+    def set_profiling(self, enabled):
+        self._lib.hadi_set_profiling(self._h, 1 if enabled else 0)
+
+    def timing(self):
+        t = nat.Timing()
+        self._lib.hadi_get_timing(self._h, C.byref(t))
+        return {k: getattr(t, k) for k, _ in nat.Timing._fields_}
+
+    def device_info(self):
+        name, arch, cu = C.create_string_buffer(256), C.create_string_buffer(64), C.c_int()
+        self._lib.hadi_device_info(self._h, name, 256, C.byref(cu), arch, 64)
+        return {"name": name.value.decode(), "arch": arch.value.decode(), "compute_units": cu.value}
+
+    # ---- problem assembly ---------------------------------------------------------------------
+    def _problem(self, variant, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids,
+                 U=None, U_0=None, lambda_bar=None, dividends=None, per_instance=None, need_vgrid=True):
+        n = grids.Vec_s.shape[0]
+        m = (m1 + 1) * (m2 + 1)
+        p = nat.Problem()
+        keep = []
+        spaces = []
+
+        def arr(x, name, count):
+            ptr, dev = _check_array(x, name, count)
+            spaces.append(dev)
+            keep.append(x)
+            return ptr
+
+        p.n_instances, p.m1, p.m2, p.variant = n, m1, m2, variant
+        p.N, p.delta_t, p.theta = int(N), float(delta_t), float(theta)
+        p.r_d, p.r_f = float(r_d), float(r_f)
+        p.rho, p.sigma, p.kappa, p.eta = float(rho), float(sigma), float(kappa), float(eta)
+        p.vec_s = arr(grids.Vec_s, "Vec_s", n * (m1 + 1))
+        p.delta_s = arr(grids.Delta_s, "Delta_s", n * m1)
+        if need_vgrid:
+            p.vec_v = arr(grids.Vec_v, "Vec_v", n * (m2 + 1))
+            p.delta_v = arr(grids.Delta_v, "Delta_v", n * m2)
+        if U is not None:
+            p.U = arr(U, "U", n * m)
+        if U_0 is not None:
+            p.U_0 = arr(U_0, "U_0", n * m)
+        if lambda_bar is not None:
+            p.lambda_bar = arr(lambda_bar, "lambda_bar", n * m)
+        if len(set(spaces)) > 1:
+            raise ValueError("array arguments mix host and device memory")
+        p.memspace = nat.MEM_DEVICE if spaces and spaces[0] else nat.MEM_HOST
+        if dividends is not None and len(dividends):
+            p.num_dividends = len(dividends)
+            p.dividend_dates = dividends.dates.ctypes.data_as(_dp)
+            p.dividend_amounts = dividends.amounts.ctypes.data_as(_dp)
+            p.dividend_percentages = dividends.percentages.ctypes.data_as(_dp)
+            keep.append(dividends)
+        if per_instance:
+            for key in ("rho_i", "sigma_i", "kappa_i", "eta_i", "delta_t_i"):
+                if per_instance.get(key) is not None:
+                    a = _host_f64(per_instance[key])
+                    if a.size != n:
+                        raise ValueError("%s must have n_instances entries" % key)
+                    keep.append(a)
+                    setattr(p, key, a.ctypes.data_as(_dp))
+            if per_instance.get("N_i") is not None:
+                a = np.ascontiguousarray(np.asarray(per_instance["N_i"], dtype=np.int32))
+                if a.size != n:
+                    raise ValueError("N_i must have n_instances entries")
+                keep.append(a)
+                p.N_i = a.ctypes.data_as(_ip)
+        p._keep = keep
+        return p
+
+    def _out(self, n, cols, like):
+        if _is_device(like):
+            import torch
+            shape = (n,) if cols == 1 else (n, cols)
+            t = torch.empty(shape, dtype=torch.float64, device=like.device)
+            return t, C.c_void_p(t.data_ptr())
+        a = np.empty((n,) if cols == 1 else (n, cols))
+        return a, C.c_void_p(a.ctypes.data)
+
+    # ---- device_DO_timestepping* (src/device_solver.hpp:194-942) -------------------------------
+    def DO_timestepping(self, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids, U,
+                        variant=EU, U_0=None, lambda_bar=None, dividends=None, per_instance=None):
+        """Boundary init + operator build + N Douglas steps on the caller's grids; U is updated in
+        place (initial condition in, solution at T out)."""
+        p = self._problem(variant, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids,
+                          U=U, U_0=U_0, lambda_bar=lambda_bar, dividends=dividends, per_instance=per_instance)
+        rc = self._lib.hadi_DO_timestepping(self._h, C.byref(p))
+        if rc != nat.HADI_OK:
+            self._raise(rc)
+        return U
+
+    # ---- parallel_DO_solve (src/device_solver.hpp:52-185) --------------------------------------
+    def parallel_DO_solve(self, nInstances, S_0, V_0, m1, m2, N, T, delta_t, theta, r_d, r_f, rho, sigma,
+                          kappa, eta, deviceGrids, workspace, base_prices=None):
+        """European sweep + price pick.  (The reference declares S_0, V_0 as `int` here,
+        device_solver.hpp:56-57, which truncates V_0 = 0.04 to 0; they are doubles in this mirror.)"""
+        if deviceGrids.Vec_s.shape[0] != nInstances:
+            raise ValueError("nInstances does not match the grid batch")
+        p = self._problem(EU, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, deviceGrids,
+                          U=workspace.U)
+        out, optr = self._out(nInstances, 1, workspace.U)
+        rc = self._lib.hadi_parallel_DO_solve(self._h, C.byref(p), float(S_0), float(V_0), optr)
+        if rc != nat.HADI_OK:
+            self._raise(rc)
+        if base_prices is not None:
+            base_prices[...] = out
+            return base_prices
+        return out
+
+    # ---- compute_base_prices* (src/jacobian_computation.cpp:368, 629, 922, 1232) ---------------
+    def _base_prices(self, variant, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N,
+                     theta, delta_t, num_strikes, deviceGrids, workspace, U_0=None, dividends=None,
+                     per_instance=None):
+        if total_size != (m1 + 1) * (m2 + 1):
+            raise ValueError("total_size != (m1+1)*(m2+1)")
+        if deviceGrids.Vec_s.shape[0] != num_strikes:
+            raise ValueError("num_strikes does not match the grid batch")
+        p = self._problem(variant, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, deviceGrids,
+                          U=workspace.U, U_0=U_0, lambda_bar=None, dividends=dividends,
+                          per_instance=per_instance, need_vgrid=False)
+        out, optr = self._out(num_strikes, 1, workspace.U)
+        rc = self._lib.hadi_compute_base_prices(self._h, C.byref(p), float(S_0), float(V_0), optr)
+        if rc != nat.HADI_OK:
+            self._raise(rc)
+        return out
+
+    def compute_base_prices(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
+                            delta_t, num_strikes, deviceGrids, workspace, per_instance=None):
+        return self._base_prices(EU, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
+                                 delta_t, num_strikes, deviceGrids, workspace, per_instance=per_instance)
+
+    def compute_base_prices_american(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N,
+                                     theta, delta_t, num_strikes, deviceGrids, U_0, workspace):
+        return self._base_prices(AM, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
+                                 delta_t, num_strikes, deviceGrids, workspace, U_0=U_0)
+
+    def compute_base_prices_dividends(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N,
+                                      theta, delta_t, num_strikes, deviceGrids, workspace, dividends):
+        return self._base_prices(DIV, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
+                                 delta_t, num_strikes, deviceGrids, workspace, dividends=dividends)
+
+    def compute_base_prices_american_dividends(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2,
+                                               total_size, N, theta, delta_t, num_strikes, deviceGrids, U_0,
+                                               workspace, dividends):
+        return self._base_prices(AM_DIV, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N,
+                                 theta, delta_t, num_strikes, deviceGrids, workspace, U_0=U_0, dividends=dividends)
+
+    # ---- compute_jacobian* (src/jacobian_computation.cpp:204, 457, 726, 1031) ------------------
+    def _jacobian(self, variant, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
+                  delta_t, num_strikes, deviceGrids, U_0, eps, dividends=None, per_instance=None):
+        if total_size != (m1 + 1) * (m2 + 1):
+            raise ValueError("total_size != (m1+1)*(m2+1)")
+        p = self._problem(variant, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, deviceGrids,
+                          U=None, U_0=U_0, dividends=dividends, per_instance=per_instance, need_vgrid=False)
+        J, jptr = self._out(num_strikes, 5, U_0)
+        base, bptr = self._out(num_strikes, 1, U_0)
+        rc = self._lib.hadi_compute_jacobian(self._h, C.byref(p), float(S_0), float(V_0), float(eps), jptr, bptr)
+        if rc != nat.HADI_OK:
+            self._raise(rc)
+        return J, base
+
+    def compute_jacobian(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
+                         delta_t, num_strikes, deviceGrids, U_0, eps=1e-6, per_instance=None):
+        """Returns (J [n][5] with columns kappa, eta, sigma, rho, v0; base_prices [n])."""
+        return self._jacobian(EU, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
+                              delta_t, num_strikes, deviceGrids, U_0, eps, per_instance=per_instance)
+
+    def compute_jacobian_american(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N,
+                                  theta, delta_t, num_strikes, deviceGrids, U_0, eps=1e-6):
+        return self._jacobian(AM, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
+                              delta_t, num_strikes, deviceGrids, U_0, eps)
+
+    def compute_jacobian_dividends(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N,
+                                   theta, delta_t, num_strikes, deviceGrids, U_0, dividends, eps=1e-6):
+        return self._jacobian(DIV, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
+                              delta_t, num_strikes, deviceGrids, U_0, eps, dividends=dividends)
+
+    def compute_jacobian_american_dividends(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2,
+                                            total_size, N, theta, delta_t, num_strikes, deviceGrids, U_0,
+                                            dividends, eps=1e-6):
+        return self._jacobian(AM_DIV, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
+                              delta_t, num_strikes, deviceGrids, U_0, eps, dividends=dividends)
+
+
+# ---- LM linear algebra (host; jacobian_computation.cpp:20-195) -------------------------------------
+def lm_partials(J, residuals):
+    """[J^T J (25), J^T r (5), sum r^2 (1)] of this rank's rows: the 31 doubles that are all-reduced."""
+    J, r = _host_f64(J), _host_f64(residuals)
+    out = np.empty(31)
+    rc = nat.lib().hadi_lm_partials(J.shape[0], J.ctypes.data_as(_dp), r.ctypes.data_as(_dp), out.ctypes.data_as(_dp))
+    if rc != nat.HADI_OK:
+        raise HadiError(rc, "hadi_lm_partials")
+    return out
+
+
+def lm_solve(partials31, lam):
+    part = _host_f64(partials31)
+    delta = np.empty(5)
+    rc = nat.lib().hadi_lm_solve(part.ctypes.data_as(_dp), float(lam), delta.ctypes.data_as(_dp))
+    if rc != nat.HADI_OK:
+        raise HadiError(rc, "hadi_lm_solve")
+    return delta
+
+
+def compute_parameter_update(J, residuals, lam):
+    """compute_parameter_update_on_device (jacobian_computation.cpp:107-195)."""
+    return lm_solve(lm_partials(J, residuals), lam)

@@ -1,0 +1,112 @@
+// emu_driver.cpp -- TEST-ONLY.  Runs csrc/hadi_kernels.h (the product's kernel source, unmodified)
+// under the host-thread wave emulator so tests can compare its logic with the oracle without a GPU.
+// Never shipped, never linked into libhadi; see wave_emu.h.
+#define HADI_EMU 1
+#include "hadi_kernels.h"
+#include "hadi_plan.h"
+
+namespace emu {
+thread_local emu_dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+thread_local BlockState *t_block;
+thread_local WaveState *t_wave;
+thread_local int t_lane;
+}  // namespace emu
+
+template <int B>
+static void run_pass_a(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
+    emu::launch(pl.grid_a, 64, [&]() { hadi_pass_a<B>(a, n); });
+}
+
+extern "C" int emu_plan(int m1, int m2, int n_inst, int target_waves, int *out /*B,rowp,P,R,ntiles,ctiles*/) {
+    HadiPlan pl;
+    if (hadi_make_plan(m1, m2, n_inst, target_waves, &pl)) return 1;
+    out[0] = pl.L.B; out[1] = pl.L.rowp; out[2] = pl.L.P; out[3] = pl.R; out[4] = pl.ntiles; out[5] = pl.ctiles;
+    return 0;
+}
+
+// variant bit0 = american, bit1 = dividends.  Arrays natural layout [n][...].
+extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double theta, double r_d, double r_f,
+                         const double *par /*[n][4] rho sigma kappa eta*/, int variant, const double *vec_s,
+                         const double *vec_v, const double *delta_s, const double *delta_v, double *U,
+                         const double *U0, double *lam_out, int target_waves, int ndiv, const double *ddates,
+                         const double *damounts, const double *dpcts, int setup_threads) {
+    HadiPlan pl;
+    if (hadi_make_plan(m1, m2, n_inst, target_waves, &pl)) return 1;
+    const HadiLayout &L = pl.L;
+    const int american = variant & 1, dividend = (variant >> 1) & 1;
+    const size_t st = (size_t)L.inst_stride * n_inst;
+    std::vector<double> dU(st), dY(st), dLAM(american ? st : 0), dU0(american ? st : 0), dUT(dividend ? st : 0);
+    std::vector<double> scoef(pl.n_scoef * n_inst), b2row(pl.n_b2row * n_inst), rowc(pl.n_rowc * n_inst),
+        a2i(pl.n_a2i * n_inst), pb(pl.n_pb * n_inst), rinv(pl.n_rinv * n_inst), rwork(pl.n_rwork * n_inst);
+    std::vector<HadiInstPar> ipar(n_inst);
+    std::vector<double> par8((size_t)n_inst * 8);
+    for (int k = 0; k < n_inst; k++) {
+        for (int z = 0; z < 4; z++) par8[(size_t)k * 8 + z] = par[(size_t)k * 4 + z];
+        par8[(size_t)k * 8 + 4] = dt;
+        par8[(size_t)k * 8 + 5] = (double)N;
+    }
+    HadiSetupArgs s;
+    s.L = L; s.n_inst = n_inst;
+    s.vec_s = vec_s; s.vec_v = vec_v; s.delta_s = delta_s; s.delta_v = delta_v;
+    s.par = par8.data(); s.r_d = r_d; s.r_f = r_f; s.theta = theta;
+    s.scoef = scoef.data(); s.b2row = b2row.data(); s.rowc = rowc.data(); s.a2i = a2i.data();
+    s.pb = pb.data(); s.rinv = rinv.data(); s.rwork = rwork.data(); s.ipar = ipar.data();
+    emu::launch(n_inst, setup_threads, [&]() { hadi_setup_kernel(s); });
+
+    emu::launch(8, 64, [&]() { hadi_pack_kernel(L, n_inst, n_inst, U, dU.data()); });
+    if (american) {
+        emu::launch(8, 64, [&]() { hadi_pack_kernel(L, n_inst, n_inst, U0 ? U0 : U, dU0.data()); });
+        emu::launch(8, 64, [&]() { hadi_fill_kernel(dLAM.data(), st, 0.0); });
+    }
+    HadiSweepArgs a;
+    a.U = dU.data(); a.Y = dY.data(); a.LAM = american ? dLAM.data() : nullptr; a.U0 = american ? dU0.data() : nullptr;
+    a.scoef = scoef.data(); a.b2row = b2row.data(); a.rowc = rowc.data(); a.pb = pb.data(); a.rinv = rinv.data();
+    a.ipar = ipar.data(); a.L = L; a.n_inst = n_inst; a.R = pl.R; a.ntiles = pl.ntiles; a.ctiles = pl.ctiles;
+    a.american = american; a.pos_m1 = pl.pos_m1;
+
+    int cur = 0;
+    for (int n = 1; n <= N; n++) {
+        if (dividend) {  // device_solver.hpp:426-517 (host decides, kernel applies)
+            const double t = n * dt;
+            if (cur < ndiv && t <= ddates[cur] && ddates[cur] < (n + 1) * dt) {
+                dUT = dU;
+                emu::launch(8, 64, [&]() {
+                    hadi_dividend_kernel(L, n_inst, vec_s, dUT.data(), dU.data(), damounts[cur], dpcts[cur]);
+                });
+            }
+            if (cur < ndiv && t > ddates[cur]) cur++;
+        }
+        switch (L.B) {
+            case 1: run_pass_a<1>(pl, a, n); break;
+            case 2: run_pass_a<2>(pl, a, n); break;
+            case 4: run_pass_a<4>(pl, a, n); break;
+            case 8: run_pass_a<8>(pl, a, n); break;
+            case 16: run_pass_a<16>(pl, a, n); break;
+            default: return 2;
+        }
+        emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b(a, n); });
+    }
+    emu::launch(8, 64, [&]() { hadi_unpack_kernel(L, n_inst, dU.data(), U); });
+    if (american && lam_out) emu::launch(8, 64, [&]() { hadi_unpack_kernel(L, n_inst, dLAM.data(), lam_out); });
+    return 0;
+}
+
+// Tables only (serial host evaluation of hadi_setup_instance), for direct comparison with the oracle.
+extern "C" int emu_tables(int m1, int m2, int N, double dt, double theta, double r_d, double r_f, double rho,
+                          double sigma, double kappa, double eta, const double *vec_s, const double *vec_v,
+                          const double *delta_s, const double *delta_v, int target_waves, double *scoef,
+                          double *b2row, double *rowc, double *a2i, double *pb, double *rinv) {
+    HadiPlan pl;
+    if (hadi_make_plan(m1, m2, 1, target_waves, &pl)) return 1;
+    HadiSetupIn in;
+    in.vec_s = vec_s; in.vec_v = vec_v; in.delta_s = delta_s; in.delta_v = delta_v;
+    in.r_d = r_d; in.r_f = r_f; in.rho = rho; in.sigma = sigma; in.kappa = kappa; in.eta = eta;
+    in.theta = theta; in.dt = dt; in.N = N;
+    std::vector<double> rwork(pl.n_rwork);
+    HadiInstPar ip;
+    HadiTables t;
+    t.scoef = scoef; t.b2row = b2row; t.rowc = rowc; t.a2i = a2i; t.pb = pb; t.rinv = rinv;
+    t.rwork = rwork.data(); t.ipar = &ip;
+    hadi_setup_instance(pl.L, in, t, 0, 1, HadiNoSync());
+    return 0;
+}

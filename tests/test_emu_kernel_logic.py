@@ -1,0 +1,135 @@
+"""CPU-only check of the KERNEL SOURCE (csrc/hadi_kernels.h, csrc/hadi_core.h) compiled with g++ against
+the test-only wave emulator in tests/emu: same code, host threads instead of wavefronts.  This is a
+development safety net for layout / indexing / table logic; it proves nothing about the GPU build,
+whose parity tests are the `-m gpu` ones."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+import common as Cm
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+EMU_SO = os.path.join(HERE, "emu", "libhadi_emu.so")
+_dp = C.POINTER(C.c_double)
+
+
+def _P(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    csrc = os.path.join(ROOT, "pde_based_heston_solver_gpu_accelerated_amd", "csrc")
+    srcs = [os.path.join(HERE, "emu", f) for f in ("emu_driver.cpp", "wave_emu.h")] + \
+           [os.path.join(csrc, f) for f in os.listdir(csrc)]
+    if not os.path.exists(EMU_SO) or any(os.path.getmtime(s) > os.path.getmtime(EMU_SO) for s in srcs):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-DHADI_EMU",
+                               "-I" + os.path.join(HERE, "emu"), "-I" + csrc, "-o", EMU_SO,
+                               os.path.join(HERE, "emu", "emu_driver.cpp")])
+    return C.CDLL(EMU_SO)
+
+
+def _run(emu, m1, m2, N, strikes, variant, target_waves, r_f=0.0):
+    n = len(strikes)
+    vs, vv, ds, dv, U0 = Cm.oracle_grids(m1, m2, strikes)
+    p = Cm.oracle_params(m1, m2, N, variant, r_f=r_f)
+    Uo, lamo, _ = O.solve_batch(p, vs, vv, ds, dv, U0, U0, want_lambda=True)
+    U, lam = U0.copy(), np.zeros_like(U0)
+    par = np.tile(np.array([Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA]), (n, 1)).copy()
+    dd = [np.array(x, dtype=np.float64) for x in Cm.DIVS]
+    rc = emu.emu_solve(n, m1, m2, N, C.c_double(Cm.T / N), C.c_double(Cm.THETA), C.c_double(Cm.R_D),
+                       C.c_double(r_f), _P(par), variant, _P(vs), _P(vv), _P(ds), _P(dv), _P(U), _P(U0), _P(lam),
+                       target_waves, len(dd[0]), _P(dd[0]), _P(dd[1]), _P(dd[2]), 64)
+    assert rc == 0
+    scale = np.abs(Uo).max()
+    assert np.abs(U - Uo).max() < 1e-11 * scale
+    if lamo is not None:
+        assert np.abs(lam - lamo).max() < 1e-9 * max(1.0, np.abs(lamo).max())
+
+
+def test_row_pass_one_node_per_lane_and_r_f(emu):
+    _run(emu, 40, 12, 3, [90.0, 110.0], O.EU, 8, r_f=0.01)
+
+
+def test_row_pass_two_nodes_per_lane(emu):
+    _run(emu, 100, 20, 2, [100.0], O.EU, 8)
+
+
+def test_american_projection(emu):
+    _run(emu, 40, 12, 3, [100.0], O.AM, 4)
+
+
+def test_dividends_and_chunked_column_pass(emu):
+    # m2 = 70 -> 71 v-rows -> two chunks coupled by the SPIKE reduced system; dividend lands on step 2
+    _run(emu, 72, 70, 10, [100.0], O.DIV, 3)
+
+
+def test_setup_tables_against_oracle_operators(emu):
+    """The O(m1+m2) tables reproduce the reference's dense operators: apply them to a random field and
+    compare with the oracle's A0U / A1U / A2U of step 1."""
+    m1, m2, N = 70, 30, 10
+    vs, vv, ds, dv, _ = Cm.oracle_grids(m1, m2, [100.0])
+    rng = np.random.default_rng(3)
+    U = rng.standard_normal((m2 + 1) * (m1 + 1))
+    p = Cm.oracle_params(m1, m2, N, "EU")
+    _, _, d = O.solve(p, vs[0], vv[0], ds[0], dv[0], U, U, dump_step=1)
+    plan = (C.c_int * 6)()
+    assert emu.emu_plan(m1, m2, 1, 8, plan) == 0
+    B, rowp, Pn = plan[0], plan[1], plan[2]
+    nrows = m2 + 1
+    scoef, b2row = np.zeros(6 * 64 * B), np.zeros(rowp)
+    rowc, a2i, pb, rinv = np.zeros(nrows * 16), np.zeros(5 * nrows), np.zeros(nrows * 12), np.zeros(16 * Pn * Pn)
+    rc = emu.emu_tables(m1, m2, N, C.c_double(Cm.T / N), C.c_double(Cm.THETA), C.c_double(Cm.R_D), C.c_double(0.0),
+                        C.c_double(Cm.RHO), C.c_double(Cm.SIGMA), C.c_double(Cm.KAPPA), C.c_double(Cm.ETA),
+                        _P(vs[0]), _P(vv[0]), _P(ds[0]), _P(dv[0]), 8, _P(scoef), _P(b2row), _P(rowc), _P(a2i),
+                        _P(pb), _P(rinv))
+    assert rc == 0
+    rowc = rowc.reshape(nrows, 16)
+
+    def pos(i):
+        if i == 0:
+            return 64 * B
+        e = i - 1
+        if B == 1:
+            return e
+        lane, r = divmod(e, B)
+        return (r >> 1) * 128 + 2 * lane + (r & 1)
+
+    sc = scoef.reshape(6, 64 * B)
+    Ug = U.reshape(m2 + 1, m1 + 1)
+    A0 = np.zeros_like(Ug); A1 = np.zeros_like(Ug); A2 = np.zeros_like(Ug)
+    for j in range(m2 + 1):
+        v = rowc[j, 0]
+        for i in range(1, m1 + 1):
+            Bk = [sc[k, pos(i)] for k in range(3)]
+            Dk = [sc[3 + k, pos(i)] for k in range(3)]
+            nb = lambda jj: [Ug[jj, i - 1], Ug[jj, i], Ug[jj, i + 1] if i + 1 <= m1 else 0.0]
+            lo, mn, up = [v * Dk[k] + (Cm.R_D - Cm.R_F) * Bk[k] for k in range(3)]
+            mn -= 0.5 * Cm.R_D
+            u = nb(j)
+            A1[j, i] = lo * u[0] + mn * u[1] + up * u[2]
+            if 1 <= j <= m2 - 1:
+                A0[j, i] = sum(rowc[j, 1 + l] * sum(Bk[k] * nb(j - 1 + l)[k] for k in range(3)) for l in range(3))
+        for i in range(m1 + 1):
+            for k, off in enumerate((-2, -1, 0, 1, 2)):
+                if 0 <= j + off <= m2:
+                    A2[j, i] += rowc[j, 4 + k] * Ug[j + off, i]
+    scale = lambda x: max(1.0, np.abs(x).max())
+    assert np.abs(A0.ravel() - d["A0U"]).max() < 1e-12 * scale(d["A0U"])
+    assert np.abs(A1.ravel() - d["A1U"]).max() < 1e-12 * scale(d["A1U"])
+    assert np.abs(A2.ravel() - d["A2U"]).max() < 1e-12 * scale(d["A2U"])
+    # boundary vectors: b2 on the last v-row, b1 at index m1*(j+1) (quirk)
+    b1 = np.zeros((m2 + 1) * (m1 + 1))
+    for j in range(m2 + 1):
+        if rowc[j, 10] >= 0:
+            b1[j * (m1 + 1) + int(rowc[j, 10])] = rowc[j, 9]
+    assert np.array_equal(b1, d["b1"])
+    b2 = np.zeros_like(b1)
+    b2[m2 * (m1 + 1):] = [b2row[pos(i)] for i in range(m1 + 1)]
+    assert np.array_equal(b2, d["b2"])

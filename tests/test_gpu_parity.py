@@ -1,0 +1,295 @@
+"""GPU parity tests: libhadi (hand-written gfx950 kernels, through the C ABI) against the CPU oracle on
+the same seeded inputs, against the reference outputs recorded in tests/golden, and -- at BASELINE.json's
+full sizes, where the oracle is too slow -- through size-independent properties.
+
+Tolerances (fp64 everywhere; north_star asks price error < 1e-6):
+  full field  max|U - U_oracle| <= 1e-10 * max|U_oracle|   (observed ~1e-14)
+  prices      |p - p_ref| <= 1e-9                           (observed ~1e-13)
+  Jacobian    forward differences with eps = 1e-6 amplify 1e-13 price noise to 1e-7: atol 2e-5
+The only differences from the oracle are operation order (partition / cyclic-reduction line solves,
+FMA contraction, factored coefficients); there is no approximation in the scheme.
+"""
+import numpy as np
+import pytest
+
+import pde_based_heston_solver_gpu_accelerated_amd as H
+from oracle import oracle as O
+
+import common as Cm
+
+pytestmark = pytest.mark.gpu
+
+FIELD_RTOL = 1e-10
+PRICE_ATOL = 1e-9
+
+
+def _batch(m1, m2, strikes):
+    grids = H.GridViewsBatch.for_strikes(m1, m2, Cm.S_0, Cm.V_0, strikes)
+    return grids, grids.call_payoff(strikes)
+
+
+def _hadi_solve(solver, m1, m2, N, strikes, variant, r_f=Cm.R_F, want_lambda=False, T=Cm.T, per_instance=None,
+                model=None):
+    grids, U0 = _batch(m1, m2, strikes)
+    U = U0.copy()
+    lam = np.zeros_like(U) if want_lambda else None
+    div = H.Dividends(*Cm.DIVS) if variant in (H.DIV, H.AM_DIV) else None
+    rho, sigma, kappa, eta = model or (Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA)
+    solver.DO_timestepping(m1, m2, N, T / N, Cm.THETA, Cm.R_D, r_f, rho, sigma, kappa, eta, grids, U,
+                           variant=variant, U_0=U0, lambda_bar=lam, dividends=div, per_instance=per_instance)
+    return grids, U0, U, lam
+
+
+def _assert_field(U, Uo, rtol=FIELD_RTOL):
+    scale = np.abs(Uo).max()
+    err = np.abs(U - Uo).max()
+    assert err <= rtol * scale, "field error %.3e (scale %.3e)" % (err, scale)
+
+
+SHAPES = [
+    # m1, m2, N, n_inst           what it exercises
+    (50, 25, 20, 5),            # reference calibration grid: 1 node/lane, single chunk
+    (100, 50, 200, 1),          # BASELINE config 1
+    (40, 12, 7, 3),             # tiny, idle lanes
+    (33, 20, 5, 2),             # odd sizes
+    (64, 33, 6, 2),             # m1 exactly one wave
+    (65, 40, 6, 2),             # 2 nodes/lane, mostly padding
+    (128, 64, 10, 3),           # 2 nodes/lane full
+    (200, 100, 40, 2),          # 4 nodes/lane, 2 chunks
+    (130, 70, 6, 2),            # 4 nodes/lane, ragged
+    (256, 128, 12, 3),          # BASELINE config 3 grid
+    (512, 256, 8, 2),           # BASELINE config 2 grid (few steps so the oracle finishes in seconds)
+    (300, 140, 5, 1),           # 8 nodes/lane with padding, 3 chunks
+]
+
+
+@pytest.mark.parametrize("m1,m2,N,n", SHAPES)
+def test_european_full_field_vs_oracle(solver, m1, m2, N, n):
+    strikes = Cm.strikes_for(n)
+    grids, U0, U, _ = _hadi_solve(solver, m1, m2, N, strikes, H.EU)
+    p = Cm.oracle_params(m1, m2, N, "EU")
+    Uo, _, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0)
+    _assert_field(U, Uo)
+
+
+@pytest.mark.parametrize("variant,name", [(H.AM, "AM"), (H.DIV, "DIV"), (H.AM_DIV, "AM_DIV")])
+@pytest.mark.parametrize("m1,m2,N,n", [(50, 25, 20, 4), (256, 128, 25, 2), (130, 70, 20, 2)])
+def test_american_dividend_variants_vs_oracle(solver, variant, name, m1, m2, N, n):
+    strikes = Cm.strikes_for(n)
+    grids, U0, U, lam = _hadi_solve(solver, m1, m2, N, strikes, variant, want_lambda=variant in (H.AM, H.AM_DIV))
+    p = Cm.oracle_params(m1, m2, N, name)
+    Uo, lamo, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0, want_lambda=True)
+    _assert_field(U, Uo)
+    if lamo is not None:
+        # lambda_bar = max(0, lambda + (U_0 - U_bar)/dt): a field error e shows up as e/dt
+        assert np.abs(lam - lamo).max() <= 1e-8 * max(1.0, np.abs(lamo).max())
+
+
+def test_foreign_rate_boundary_terms(solver):
+    """r_f != 0 switches on the time-dependent boundary factors exp(r_f dt n) (device_solver.hpp:238-247)
+    that every reference test leaves at 1."""
+    m1, m2, N, strikes = 70, 30, 12, [90.0, 105.0]
+    grids, U0, U, _ = _hadi_solve(solver, m1, m2, N, strikes, H.EU, r_f=0.013)
+    p = Cm.oracle_params(m1, m2, N, "EU", r_f=0.013)
+    Uo, _, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0)
+    _assert_field(U, Uo)
+
+
+def test_upwind_rows_are_exercised(solver):
+    """sigma large enough that the v > 1 upwind block (hes_a2_shuffled_kernels.hpp:129-144) matters,
+    compared on the full field (the price node alone is blind to those rows)."""
+    m1, m2, N, strikes = 60, 40, 10, [100.0]
+    model = (-0.5, 0.9, 3.0, 0.3)
+    grids, U0, U, _ = _hadi_solve(solver, m1, m2, N, strikes, H.EU, model=model)
+    assert (grids.Vec_v > 1.0).sum() >= 5
+    p = Cm.oracle_params(m1, m2, N, "EU", rho=model[0], sigma=model[1], kappa=model[2], eta=model[3])
+    Uo, _, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0)
+    _assert_field(U, Uo)
+
+
+GOLD = Cm.GOLDEN["prices"]
+
+
+@pytest.mark.parametrize("case", GOLD, ids=lambda c: "%s_%dx%dx%d_K%s" % (c["variant"], c["m1"], c["m2"], c["N"], c["K"]))
+def test_reference_recorded_prices(solver, case):
+    """Every reference output recorded for this path, incl. BASELINE config 2
+    (512x256, 1000 steps) and the config-3 sized American+dividend call, through the mirrored
+    launchers compute_base_prices*."""
+    m1, m2, N, K = case["m1"], case["m2"], case["N"], float(case["K"])
+    grids, U0 = _batch(m1, m2, [K])
+    ws = H.DOWorkspace(1, (m1 + 1) * (m2 + 1))
+    ws.U[...] = U0
+    args = (Cm.S_0, Cm.V_0, Cm.T, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, m1, m2, (m1 + 1) * (m2 + 1), N,
+            Cm.THETA, Cm.T / N, 1, grids)
+    div = H.Dividends(*Cm.DIVS)
+    v = case["variant"]
+    if v == "EU":
+        price = solver.compute_base_prices(*args, ws)
+    elif v == "AM":
+        price = solver.compute_base_prices_american(*args, U0, ws)
+    elif v == "DIV":
+        price = solver.compute_base_prices_dividends(*args, ws, div)
+    else:
+        price = solver.compute_base_prices_american_dividends(*args, U0, ws, div)
+    tol = PRICE_ATOL if case["digits"] >= 16 else 0.5 * 10.0 ** (2 - case["digits"])
+    assert abs(price[0] - case["price"]) <= tol, (price[0], case["price"])
+
+
+def test_parallel_DO_solve_matches_compute_base_prices_and_oracle(solver):
+    m1, m2, N, n = 50, 25, 20, 20
+    strikes = [85.0 + i for i in range(n)]  # device_solver.cpp:624-627
+    grids, U0 = _batch(m1, m2, strikes)
+    ws = H.DOWorkspace(n, (m1 + 1) * (m2 + 1))
+    ws.U[...] = U0
+    prices = solver.parallel_DO_solve(n, Cm.S_0, Cm.V_0, m1, m2, N, Cm.T, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F,
+                                      Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, ws)
+    p = Cm.oracle_params(m1, m2, N, "EU")
+    want, _ = O.base_prices(p, Cm.S_0, Cm.V_0, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0)
+    assert np.abs(prices - want).max() <= PRICE_ATOL
+    # the three strikes the reference's own test prints (device_solver.cpp:780)
+    for k, ref in enumerate((19.36766348353193, 18.57361239232885, 17.7901173119001)):
+        assert abs(prices[k] - ref) < 1e-9
+    ws.U[...] = U0
+    again = solver.compute_base_prices(Cm.S_0, Cm.V_0, Cm.T, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA,
+                                       m1, m2, (m1 + 1) * (m2 + 1), N, Cm.THETA, Cm.T / N, n, grids, ws)
+    assert np.abs(again - prices).max() <= 1e-12
+
+
+@pytest.mark.parametrize("variant", ["EU", "AM", "DIV", "AM_DIV"])
+def test_jacobian_vs_oracle(solver, variant):
+    j = Cm.GOLDEN["jacobian"]
+    m1, m2, N = j["m1"], j["m2"], j["N"]
+    strikes = [float(k) for k in j["strikes"]]
+    grids, U0 = _batch(m1, m2, strikes)
+    args = (Cm.S_0, Cm.V_0, Cm.T, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, m1, m2, (m1 + 1) * (m2 + 1), N,
+            Cm.THETA, Cm.T / N, len(strikes), grids, U0)
+    div = H.Dividends(*Cm.DIVS)
+    if variant == "EU":
+        J, base = solver.compute_jacobian(*args, eps=j["eps"])
+    elif variant == "AM":
+        J, base = solver.compute_jacobian_american(*args, eps=j["eps"])
+    elif variant == "DIV":
+        J, base = solver.compute_jacobian_dividends(*args, div, eps=j["eps"])
+    else:
+        J, base = solver.compute_jacobian_american_dividends(*args, div, eps=j["eps"])
+    p = Cm.oracle_params(m1, m2, N, variant)
+    Jo, baseo = O.jacobian(p, Cm.S_0, Cm.V_0, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, eps=j["eps"])
+    assert np.abs(base - baseo).max() <= PRICE_ATOL
+    assert np.abs(J - Jo).max() <= 2e-5, np.abs(J - Jo).max()
+    if variant == "EU":  # the row the reference printed
+        assert abs(base[0] - j["base_price_0"]) <= PRICE_ATOL
+        assert np.abs(J[0] - np.array(j["J_row_0"])).max() <= 2e-5
+
+
+def test_per_instance_parameters_and_maturities(solver):
+    """Per-instance model parameters (the flattened Jacobian needs them) and per-instance (N, delta_t)
+    (multi-maturity calibration, heston_calibration.cpp:2165-2171): each instance must equal an
+    individual oracle solve."""
+    m1, m2 = 60, 30
+    strikes = [90.0, 100.0, 110.0, 95.0]
+    Ts = [0.5, 1.0, 2.0, 0.25]
+    Ns = [10, 20, 40, 5]
+    rhos, sigmas = [-0.9, -0.5, 0.0, 0.3], [0.3, 0.5, 0.2, 0.4]
+    kappas, etas = [1.5, 2.0, 0.5, 3.0], [0.04, 0.09, 0.02, 0.06]
+    per = {"rho_i": rhos, "sigma_i": sigmas, "kappa_i": kappas, "eta_i": etas, "N_i": Ns,
+           "delta_t_i": [t / n for t, n in zip(Ts, Ns)]}
+    grids, U0 = _batch(m1, m2, strikes)
+    U = U0.copy()
+    solver.DO_timestepping(m1, m2, 1, 1.0, Cm.THETA, Cm.R_D, Cm.R_F, 0.0, 0.1, 1.0, 0.04, grids, U, per_instance=per)
+    for k in range(len(strikes)):
+        p = O.make_params(m1, m2, Ns[k], Ts[k] / Ns[k], Cm.THETA, Cm.R_D, Cm.R_F, rhos[k], sigmas[k], kappas[k], etas[k])
+        Uo, _, _ = O.solve(p, grids.Vec_s[k], grids.Vec_v[k], grids.Delta_s[k], grids.Delta_v[k], U0[k])
+        _assert_field(U[k], Uo)
+
+
+def test_device_memory_path_equals_host_path(solver):
+    import torch
+    m1, m2, N, strikes = 100, 50, 15, Cm.strikes_for(6)
+    grids, U0, U_host, _ = _hadi_solve(solver, m1, m2, N, strikes, H.EU)
+    dev = torch.device("cuda:0")
+    gd = grids.to(dev)
+    ws = H.DOWorkspace(len(strikes), (m1 + 1) * (m2 + 1), device=dev)
+    ws.U.copy_(torch.from_numpy(U0))
+    torch.cuda.synchronize()
+    prices = solver.parallel_DO_solve(len(strikes), Cm.S_0, Cm.V_0, m1, m2, N, Cm.T, Cm.T / N, Cm.THETA, Cm.R_D,
+                                      Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, gd, ws)
+    assert prices.is_cuda
+    assert np.array_equal(ws.U.cpu().numpy(), U_host)  # same kernels, same inputs: bit-identical
+    i_s = grids_index = H.Grid(m1, 8 * strikes[0], Cm.S_0, strikes[0], strikes[0] / 5, m2, 5.0, Cm.V_0, 0.01)
+    k = i_s.find_s_index(Cm.S_0) + i_s.find_v0_index(Cm.V_0) * (m1 + 1)
+    assert prices.cpu().numpy()[0] == U_host[0, k]
+
+
+def test_batch_composition_does_not_change_an_instance(solver):
+    """Instances are independent (TeamPolicy league, device_solver.hpp:83-88): results must be
+    bit-identical whatever else is in the batch and wherever the instance sits in it."""
+    m1, m2, N = 128, 64, 10
+    strikes = Cm.strikes_for(7)
+    _, _, U_all, _ = _hadi_solve(solver, m1, m2, N, strikes, H.EU)
+    perm = [3, 0, 6, 2]
+    _, _, U_sub, _ = _hadi_solve(solver, m1, m2, N, [strikes[i] for i in perm], H.EU)
+    for a, i in enumerate(perm):
+        assert np.array_equal(U_sub[a], U_all[i])
+    _, _, U_one, _ = _hadi_solve(solver, m1, m2, N, [strikes[5]], H.EU)
+    assert np.array_equal(U_one[0], U_all[5])
+
+
+def test_full_size_properties_config2(solver):
+    """BASELINE config 2 at full size (512x256, 1000 steps, 4 instances): the oracle would need ~30 s
+    per instance, so check (i) the recorded reference price, (ii) affine superposition of the Douglas
+    map, S(U0 + W) - S(U0) = S(W) - S(0), which holds for ANY correct linear scheme and couples every
+    row/column of the grid, (iii) discrete maximum-principle sanity 0 <= price <= S_0."""
+    m1, m2, N = 512, 256, 1000
+    K = 100.0
+    grids1, U0 = _batch(m1, m2, [K])
+    grids = H.GridViewsBatch([H.Grid(m1, 8 * K, Cm.S_0, K, K / 5, m2, 5.0, Cm.V_0, 5.0 / 500)] * 4)
+    rng = np.random.default_rng(11)
+    W = rng.standard_normal(U0.shape) * 3.0
+    U = np.concatenate([U0, U0 + W, W, np.zeros_like(U0)])
+    solver.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U)
+    node = 181 + 78 * (m1 + 1)
+    assert abs(U[0, node] - 8.8942192888223310) <= PRICE_ATOL
+    lhs, rhs = U[1] - U[0], U[2] - U[3]
+    assert np.abs(lhs - rhs).max() <= 1e-9 * max(1.0, np.abs(rhs).max())
+    assert 0.0 <= U[0, node] <= Cm.S_0
+    t = solver.timing()
+    assert t["point_steps"] == 4 * 513 * 257 * 1000 and t["sweep_ms"] > 0
+
+
+def test_error_conventions(solver):
+    m1, m2, N = 40, 12, 3
+    grids, U0 = _batch(m1, m2, [100.0])
+    ws = H.DOWorkspace(1, (m1 + 1) * (m2 + 1))
+    ws.U[...] = U0
+    with pytest.raises(H.HadiError) as e:  # S_0 off-grid: the reference silently reads index -1
+        solver.parallel_DO_solve(1, 101.2345, Cm.V_0, m1, m2, N, Cm.T, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO,
+                                 Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, ws)
+    assert e.value.status == 4
+    g2, U2 = _batch(20, 30, [100.0])  # m2 > m1
+    with pytest.raises(H.HadiError) as e:
+        solver.DO_timestepping(20, 30, N, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, g2, U2)
+    assert e.value.status == 2
+    with pytest.raises(H.HadiError) as e:
+        solver.DO_timestepping(m1, m2, 0, Cm.T, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U0.copy())
+    assert e.value.status == 1
+    with pytest.raises(ValueError):
+        solver.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids,
+                               U0[:, :-1].copy())
+    # V_0 off-grid picks v-index 0 like the reference (grid_pod.hpp:76-87) -- no error
+    ws.U[...] = U0
+    p = solver.parallel_DO_solve(1, Cm.S_0, 0.0123, m1, m2, N, Cm.T, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO,
+                                 Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, ws)
+    i_s = H.Grid(m1, 800.0, Cm.S_0, 100.0, 20.0, m2, 5.0, Cm.V_0, 0.01).find_s_index(Cm.S_0)
+    assert p[0] == ws.U[0, i_s]
+
+
+def test_profiling_reports_kernel_times(solver):
+    m1, m2, N = 128, 64, 20
+    solver.set_profiling(True)
+    try:
+        _hadi_solve(solver, m1, m2, N, Cm.strikes_for(8), H.EU)
+        t = solver.timing()
+    finally:
+        solver.set_profiling(False)
+    assert t["pass_a_launches"] == N and t["pass_b_launches"] == N
+    assert 0 < t["pass_a_ms"] <= t["sweep_ms"] * 1.05 and 0 < t["pass_b_ms"] <= t["sweep_ms"] * 1.05
