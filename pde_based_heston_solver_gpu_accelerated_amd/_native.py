@@ -73,6 +73,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise HadiError(-1, "libhadi.so not built at %s -- run `python __graft_entry__.py` (hipcc, gfx950); "
                             "this package has no CPU fallback" % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 under the same soname as
+    # /opt/rocm's.  Whichever is loaded first serves both; torch cannot see the GPU through the system
+    # copy, so when torch is installed let it load first (libhadi runs fine on torch's copy).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     L.hadi_last_error.restype = C.c_char_p
     L.hadi_status_string.restype = C.c_char_p

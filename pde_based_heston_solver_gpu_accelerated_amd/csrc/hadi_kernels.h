@@ -144,10 +144,12 @@ __global__ void __launch_bounds__(64) hadi_pass_a(HadiSweepArgs a, int n) {
     hadi_load_row<B>(rowptr(j0 - 1), lane, inrange(j0 - 1), um1);
     hadi_load_row<B>(rowptr(j0), lane, true, u0);
     hadi_load_row<B>(rowptr(j0 + 1), lane, inrange(j0 + 1), up1);
+    hadi_load_row<B>(rowptr(j0 + 2), lane, inrange(j0 + 2), up2);
     cm2 = inrange(j0 - 2) ? rowptr(j0 - 2)[c0slot] : 0.0;
     cm1 = inrange(j0 - 1) ? rowptr(j0 - 1)[c0slot] : 0.0;
     c0 = rowptr(j0)[c0slot];
     cp1 = inrange(j0 + 1) ? rowptr(j0 + 1)[c0slot] : 0.0;
+    cp2 = inrange(j0 + 2) ? rowptr(j0 + 2)[c0slot] : 0.0;
 
     // B-weighted s-derivatives of rows j-1, j, j+1 (A0 needs all three, A1 the middle one's edges)
     double sbm[B], sb0[B], sbp[B];
@@ -157,9 +159,12 @@ __global__ void __launch_bounds__(64) hadi_pass_a(HadiSweepArgs a, int n) {
     hadi_sderiv<B>(up1, cp1, lane, Bm, Bz, Bp, sbp, eLp, eRp);
 
     for (int j = j0; j < j1; j++) {
-        // prefetch row j+2 (consumed by A2 now, becomes the centre row two iterations later)
-        hadi_load_row<B>(rowptr(j + 2), lane, inrange(j + 2), up2);
-        cp2 = inrange(j + 2) ? rowptr(j + 2)[c0slot] : 0.0;
+        // software prefetch: row j+3 is requested now and first consumed (as the j+2 operand of A2)
+        // in the NEXT iteration, so its HBM latency hides behind this row's solve
+        double nxt[B];
+        const bool more = (j + 1 < j1);
+        hadi_load_row<B>(rowptr(j + 3), lane, more && inrange(j + 3), nxt);
+        const double cnxt = (more && inrange(j + 3)) ? rowptr(j + 3)[c0slot] : 0.0;
         double lam[B];
         double lamc0 = 0.0;
         if (a.american) {
@@ -302,10 +307,11 @@ __global__ void __launch_bounds__(64) hadi_pass_a(HadiSweepArgs a, int n) {
             um1[r] = u0[r];
             u0[r] = up1[r];
             up1[r] = up2[r];
+            up2[r] = nxt[r];
             sbm[r] = sb0[r];
             sb0[r] = sbp[r];
         }
-        cm2 = cm1; cm1 = c0; c0 = cp1; cp1 = cp2;
+        cm2 = cm1; cm1 = c0; c0 = cp1; cp1 = cp2; cp2 = cnxt;
         eL0 = eLp; eR0 = eRp;
         if (j + 1 < j1) hadi_sderiv<B>(up1, cp1, lane, Bm, Bz, Bp, sbp, eLp, eRp);
     }
@@ -316,6 +322,7 @@ __global__ void __launch_bounds__(64) hadi_pass_a(HadiSweepArgs a, int n) {
 // owns v-rows [ja, ja+len) and keeps its y/x values in registers.
 __global__ void __launch_bounds__(64 * HADI_MAX_P) hadi_pass_b(HadiSweepArgs a, int n) {
     __shared__ double zsh[HADI_MAX_P * 4 * 64];
+    __shared__ double tsh[HADI_MAX_P * HADI_LC * HADI_PBW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int P = a.L.P;
     const int inst = blockIdx.x / a.ctiles, ctile = blockIdx.x - inst * a.ctiles;
@@ -330,11 +337,17 @@ __global__ void __launch_bounds__(64 * HADI_MAX_P) hadi_pass_b(HadiSweepArgs a, 
 
     const double *__restrict__ Yb = a.Y + (size_t)inst * a.L.inst_stride + colc;
     double *__restrict__ Ub = a.U + (size_t)inst * a.L.inst_stride + colc;
-    const double *__restrict__ pb = a.pb + ((size_t)inst * nrows + ja) * HADI_PBW;
+    // the chunk's table (len x HADI_PBW doubles, identical for all 64 columns) goes through LDS once:
+    // coalesced load, then every use is a conflict-free broadcast read with a compile-time offset
+    const double *__restrict__ pbg = a.pb + ((size_t)inst * nrows + ja) * HADI_PBW;
+    double *__restrict__ tw = tsh + wave * (HADI_LC * HADI_PBW);
+    for (int e = lane; e < len * HADI_PBW; e += 64) tw[e] = pbg[e];
+    const double *__restrict__ pb = tw;
 
     double y[HADI_LC];
 #pragma unroll
     for (int k = 0; k < HADI_LC; k++) y[k] = (k < len) ? Yb[(size_t)(ja + k) * rowp] : 0.0;
+    __syncthreads();
 
     // forward elimination with the chunk-local factorisation
     {

@@ -5,7 +5,11 @@ full sizes, where the oracle is too slow -- through size-independent properties.
 Tolerances (fp64 everywhere; north_star asks price error < 1e-6):
   full field  max|U - U_oracle| <= 1e-10 * max|U_oracle|   (observed ~1e-14)
   prices      |p - p_ref| <= 1e-9                           (observed ~1e-13)
-  Jacobian    forward differences with eps = 1e-6 amplify 1e-13 price noise to 1e-7: atol 2e-5
+  Jacobian    forward differences with eps = 1e-6 amplify price round-off by 1e6.  On the reference's
+              25x20 test grid the K = 94 instance has a 0.038-wide s-interval next to a 5.4-wide one
+              (S_0 lands beside a node), which conditions its operators badly: oracle and libhadi each
+              carry ~1e-11 of round-off there, so J agrees to ~4e-5 on that row (1e-7 on the others):
+              atol 2e-4; the row the reference printed (K = 90) is checked to 2e-5
 The only differences from the oracle are operation order (partition / cyclic-reduction line solves,
 FMA contraction, factored coefficients); there is no approximation in the scheme.
 """
@@ -131,8 +135,7 @@ def test_reference_recorded_prices(solver, case):
         price = solver.compute_base_prices_dividends(*args, ws, div)
     else:
         price = solver.compute_base_prices_american_dividends(*args, U0, ws, div)
-    tol = PRICE_ATOL if case["digits"] >= 16 else 0.5 * 10.0 ** (2 - case["digits"])
-    assert abs(price[0] - case["price"]) <= tol, (price[0], case["price"])
+    assert abs(price[0] - case["price"]) <= PRICE_ATOL, (price[0], case["price"])
 
 
 def test_parallel_DO_solve_matches_compute_base_prices_and_oracle(solver):
@@ -175,7 +178,8 @@ def test_jacobian_vs_oracle(solver, variant):
     p = Cm.oracle_params(m1, m2, N, variant)
     Jo, baseo = O.jacobian(p, Cm.S_0, Cm.V_0, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, eps=j["eps"])
     assert np.abs(base - baseo).max() <= PRICE_ATOL
-    assert np.abs(J - Jo).max() <= 2e-5, np.abs(J - Jo).max()
+    assert np.abs(J - Jo).max() <= 2e-4, np.abs(J - Jo).max()
+    assert np.abs(J[:3] - Jo[:3]).max() <= 2e-5
     if variant == "EU":  # the row the reference printed
         assert abs(base[0] - j["base_price_0"]) <= PRICE_ATOL
         assert np.abs(J[0] - np.array(j["J_row_0"])).max() <= 2e-5
