@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -28,6 +29,7 @@ struct Ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> kev;  // per-launch events (profiling)
     int profiling = 0;
+    int tune_b16 = 0;  // HADI_TUNE_B16=1: tighter register budget for the column pass (tuning knob)
     int cu_count = 256;
     std::string name, arch;
     std::string err;
@@ -185,7 +187,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     a.U0 = american ? ptr<double>(c->U0) : nullptr;
     a.scoef = ptr<double>(c->scoef); a.b2row = ptr<double>(c->b2row); a.rowc = ptr<double>(c->rowc);
     a.pb = ptr<double>(c->pb); a.rinv = ptr<double>(c->rinv); a.ipar = ptr<HadiInstPar>(c->ipar);
-    a.L = L; a.n_inst = d.n; a.R = pl.R; a.ntiles = pl.ntiles; a.ctiles = pl.ctiles;
+    a.L = L; a.n_inst = d.n; a.R = pl.R; a.ntiles = pl.ntiles; a.ctiles = pl.ctiles; a.btpw = pl.btpw; a.bgroups = pl.bgroups;
     a.american = american ? 1 : 0; a.pos_m1 = pl.pos_m1;
 
     const bool prof = c->profiling != 0;
@@ -223,7 +225,8 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
             HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 1], s));
             HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 2], s));
         }
-        hipLaunchKernelGGL(hadi_pass_b, dim3(pl.grid_b), dim3(pl.block_b), 0, s, a, nstep);
+        if (L.P <= 8 && !c->tune_b16) hipLaunchKernelGGL(hadi_pass_b<8>, dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, s, a, nstep);
+        else hipLaunchKernelGGL(hadi_pass_b<16>, dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, s, a, nstep);
         if (prof) HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 3], s));
     }
     HIP_TRY(c, hipGetLastError());
@@ -533,6 +536,7 @@ int hadi_create(hadi_ctx **out, int device_id) {
     c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->name = prop.name;
     c->arch = prop.gcnArchName;
+    if (const char *e = std::getenv("HADI_TUNE_B16")) c->tune_b16 = std::atoi(e);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return HADI_ERR_HIP; }
     for (auto &e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete c; return HADI_ERR_HIP; }

@@ -15,15 +15,17 @@
 
 #define HADI_RC 16   // doubles per v-row in the row table
 #define HADI_PBW 12  // doubles per v-row in the column-pass table
-#define HADI_MAX_P 8 // max chunks (waves) per column in the column pass
-#define HADI_LC 65   // max rows per chunk in the column pass
+#define HADI_MAX_P 16 // max chunks (waves) per column in the column pass
+#define HADI_LC 33   // max rows per chunk in the column pass
 
 struct HadiLayout {
     int m1, m2, nrows;  // nrows = m2 + 1
+    int nrows_pad;      // P * HADI_LC >= nrows: v-rows past nrows are identity rows (always 0) so that
+                        // every column-pass wavefront owns exactly HADI_LC rows -- no tail branches
     int B;              // grid points per lane in the row pass: i = 1 + B*lane + r
     int rowp;           // row pitch in doubles: 64*B + 8 (slot 64*B holds i = 0, 7 zero pads)
     int P;              // chunks per column in the column pass
-    long long inst_stride;  // rowp * nrows
+    long long inst_stride;  // rowp * nrows_pad
 };
 
 // Storage position of s-index i inside a row.  Lane `l` of the row pass owns i = 1+B*l .. B*l+B
@@ -42,11 +44,6 @@ HADI_HD inline int hadi_pick_B(int m1) {
     return B;
 }
 
-HADI_HD inline void hadi_chunk(int nrows, int P, int p, int *ja, int *len) {
-    const int base = nrows / P, rem = nrows % P;
-    *ja = p * base + (p < rem ? p : rem);
-    *len = base + (p < rem ? 1 : 0);
-}
 
 struct HadiInstPar {
     double dt, thdt;   // delta_t, theta*delta_t
@@ -126,8 +123,8 @@ struct HadiTables {
     double *scoef;   // [6][64*B]   B_k = s_i beta_s(i-1,k), D_k = 1/2 s_i^2 delta_s(i-1,k), k=-1,0,1
     double *b2row;   // [rowp]      -1/2 r_d s_i E in state layout (hes_boundary_kernels.hpp:62-66)
     double *rowc;    // [nrows][HADI_RC]
-    double *a2i;     // [5][nrows]  implicit A2 diagonals by row: l2, l1, m, u1, u2
-    double *pb;      // [nrows][HADI_PBW]  column-pass factorisation + spikes
+    double *a2i;     // [5][nrows_pad]  implicit A2 diagonals by row: l2, l1, m, u1, u2 (identity past nrows)
+    double *pb;      // [nrows_pad][HADI_PBW]  column-pass factorisation + spikes
     double *rinv;    // [4P][4P]    inverse of the SPIKE reduced matrix (P > 1)
     double *rwork;   // [4P][8P]    Gauss-Jordan work area
     HadiInstPar *ipar;
@@ -148,7 +145,7 @@ struct HadiNoSync { HADI_HD void operator()() const {} };
 template <class Sync>
 HADI_HD inline void hadi_setup_instance(const HadiLayout &L, const HadiSetupIn &in, const HadiTables &t,
                                         int tid, int nth, Sync sync) {
-    const int m1 = L.m1, m2 = L.m2, nrows = L.nrows, B = L.B, nslot = 64 * B;
+    const int m1 = L.m1, m2 = L.m2, nrows = L.nrows, npad = L.nrows_pad, B = L.B, nslot = 64 * B;
     const double E = exp(-in.r_f * in.dt * (in.N - 1));  // hes_boundary_kernels.hpp:56
     const double thdt = in.theta * in.dt;
 
@@ -189,11 +186,15 @@ HADI_HD inline void hadi_setup_instance(const HadiLayout &L, const HadiSetupIn &
         rc[RC_B1COL] = -1.0;
         rc[RC_LAST] = (r == m2) ? 1.0 : 0.0;
         // implicit diagonals I - theta*dt*A2 (hes_a2_shuffled_kernels.hpp:159-171)
-        t.a2i[0 * nrows + r] = -in.theta * in.dt * a2[0];
-        t.a2i[1 * nrows + r] = -in.theta * in.dt * a2[1];
-        t.a2i[2 * nrows + r] = 1.0 - in.theta * in.dt * a2[2];
-        t.a2i[3 * nrows + r] = -in.theta * in.dt * a2[3];
-        t.a2i[4 * nrows + r] = -in.theta * in.dt * a2[4];
+        t.a2i[0 * npad + r] = -in.theta * in.dt * a2[0];
+        t.a2i[1 * npad + r] = -in.theta * in.dt * a2[1];
+        t.a2i[2 * npad + r] = 1.0 - in.theta * in.dt * a2[2];
+        t.a2i[3 * npad + r] = -in.theta * in.dt * a2[3];
+        t.a2i[4 * npad + r] = -in.theta * in.dt * a2[4];
+    }
+    for (int r = nrows + tid; r < npad; r += nth) {  // padding rows: identity, decoupled
+        t.a2i[0 * npad + r] = 0.0; t.a2i[1 * npad + r] = 0.0; t.a2i[2 * npad + r] = 1.0;
+        t.a2i[3 * npad + r] = 0.0; t.a2i[4 * npad + r] = 0.0;
     }
     sync();
     // b1_(m1*(j+1)) (quirk: not idx(m1,j)), hes_boundary_kernels.hpp:54-58.  The host rejects
@@ -206,12 +207,11 @@ HADI_HD inline void hadi_setup_instance(const HadiLayout &L, const HadiSetupIn &
         rc[RC_B1COL] = (double)col;
     }
     // --- column pass: per-chunk pentadiagonal LU + SPIKE vectors ----------------------------------
-    const double *l2 = t.a2i, *l1 = t.a2i + nrows, *dm = t.a2i + 2 * nrows, *u1 = t.a2i + 3 * nrows,
-                 *u2 = t.a2i + 4 * nrows;
+    const double *l2 = t.a2i, *l1 = t.a2i + npad, *dm = t.a2i + 2 * npad, *u1 = t.a2i + 3 * npad,
+                 *u2 = t.a2i + 4 * npad;
     const int P = L.P;
     for (int p = tid; p < P; p += nth) {
-        int ja, len;
-        hadi_chunk(nrows, P, p, &ja, &len);
+        const int ja = p * HADI_LC, len = HADI_LC;
         double c1 = 0.0, c21 = 0.0;  // c, c2 of row k-1
         double c0 = 0.0, c20 = 0.0;  // c, c2 of row k-2
         for (int k = 0; k < len; k++) {
@@ -236,8 +236,7 @@ HADI_HD inline void hadi_setup_instance(const HadiLayout &L, const HadiSetupIn &
     //   W = M_pp^-1 [coupling to the next chunk's first two unknowns x[jb], x[jb+1]]
     for (int pw = tid; pw < 4 * P; pw += nth) {
         const int p = pw >> 2, w = pw & 3;
-        int ja, len;
-        hadi_chunk(nrows, P, p, &ja, &len);
+        const int ja = p * HADI_LC, len = HADI_LC;
         if ((w < 2 && p == 0) || (w >= 2 && p == P - 1)) continue;
         const int jb = ja + len;
         // forward sweep with rhs given on the fly
@@ -277,8 +276,7 @@ HADI_HD inline void hadi_setup_instance(const HadiLayout &L, const HadiSetupIn &
         sync();
         for (int pq = tid; pq < n4; pq += nth) {
             const int p = pq >> 2, qd = pq & 3;
-            int ja, len;
-            hadi_chunk(nrows, P, p, &ja, &len);
+            const int ja = p * HADI_LC, len = HADI_LC;
             const int lrow = (qd == 0) ? 0 : (qd == 1) ? 1 : (qd == 2) ? len - 2 : len - 1;
             const double *pb = t.pb + (size_t)(ja + lrow) * HADI_PBW;
             if (p > 0) {

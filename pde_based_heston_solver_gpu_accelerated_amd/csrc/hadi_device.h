@@ -8,11 +8,17 @@
 #define HADI_HD
 #define HADI_DEV
 #define HADI_FORCEINLINE inline
+#define HADI_DYN_SMEM(T, name) T *name = reinterpret_cast<T *>(emu::t_block->dyn_smem)
+#define HADI_UNIFORM(x) (x)
 #else
 #include <hip/hip_runtime.h>
 #define HADI_HD __host__ __device__
 #define HADI_DEV __device__
 #define HADI_FORCEINLINE __forceinline__
+#define HADI_DYN_SMEM(T, name) extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw_[]; \
+    T *name = reinterpret_cast<T *>(name##_raw_)
+// value is the same in every lane of the wavefront: tell the compiler (SGPR, scalar branches)
+#define HADI_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #endif
 
 #include <math.h>

@@ -37,6 +37,7 @@ struct HadiSweepArgs {
     int n_inst;
     int R, ntiles;   // pass A: rows per wave, tiles per instance
     int ctiles;      // pass B: 64-column tiles per instance
+    int btpw, bgroups;  // pass B: column tiles per block, blocks per instance
     int american;
     int pos_m1;      // storage position of i = m1 (lambda_bar is forced to 0 there)
 };
@@ -318,121 +319,165 @@ __global__ void __launch_bounds__(64) hadi_pass_a(HadiSweepArgs a, int n) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// pass B.  Block = P wavefronts (P*64 threads) <-> 64 storage columns of one instance; wavefront p
-// owns v-rows [ja, ja+len) and keeps its y/x values in registers.
-__global__ void __launch_bounds__(64 * HADI_MAX_P) hadi_pass_b(HadiSweepArgs a, int n) {
-    __shared__ double zsh[HADI_MAX_P * 4 * 64];
-    __shared__ double tsh[HADI_MAX_P * HADI_LC * HADI_PBW];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int P = a.L.P;
-    const int inst = blockIdx.x / a.ctiles, ctile = blockIdx.x - inst * a.ctiles;
-    const HadiInstPar ip = a.ipar[inst];
-    if (n > ip.N) return;  // whole block: uniform
-    const int nrows = a.L.nrows, rowp = a.L.rowp;
-    const int col = ctile * 64 + lane;
-    const bool valid = col < rowp;
-    const int colc = valid ? col : rowp - 1;  // clamp: inactive lanes compute on a valid address, never store
-    int ja, len;
-    hadi_chunk(nrows, P, wave, &ja, &len);
+// pass B.  Block = P wavefronts (P*64 threads); wavefront p owns v-rows [p*HADI_LC, (p+1)*HADI_LC) of its
+// instance (rows past nrows are identity padding, so there are no tail branches) and
+// keeps one 64-column tile of them in registers.  A block walks over `btpw` consecutive column tiles
+// with two register buffers: the loads of tile t+1 are in flight while tile t is solved and stored, so
+// the memory pipe stays busy through the dependent forward/backward chains.
+struct HadiPassBCtx {
+    const double *Yi;   // instance base of Y
+    double *Ui;         // instance base of U
+    double *Li;         // instance base of lambda_bar (American)
+    const double *P0i;  // instance base of the payoff (American)
+    const double *pb;   // this chunk's table in LDS
+    const double *Ri;   // reduced inverse (global, uniform)
+    double *zsh;        // LDS exchange, 2 buffers of P*4*64
+    int lane, wave, P, ja, rowp, american, pos_m1;
+    double dt;
+};
 
-    const double *__restrict__ Yb = a.Y + (size_t)inst * a.L.inst_stride + colc;
-    double *__restrict__ Ub = a.U + (size_t)inst * a.L.inst_stride + colc;
-    // the chunk's table (len x HADI_PBW doubles, identical for all 64 columns) goes through LDS once:
-    // coalesced load, then every use is a conflict-free broadcast read with a compile-time offset
-    const double *__restrict__ pbg = a.pb + ((size_t)inst * nrows + ja) * HADI_PBW;
-    double *__restrict__ tw = tsh + wave * (HADI_LC * HADI_PBW);
-    for (int e = lane; e < len * HADI_PBW; e += 64) tw[e] = pbg[e];
-    const double *__restrict__ pb = tw;
-
-    double y[HADI_LC];
+HADI_DEV HADI_FORCEINLINE void hadi_pb_load(const HadiPassBCtx &c, int ctile, double (&y)[HADI_LC]) {
+    const int col = ctile * 64 + c.lane;
+    const int colc = col < c.rowp ? col : c.rowp - 1;  // lanes past the pitch read a valid address, never store
+    const double *__restrict__ src = c.Yi + (size_t)c.ja * c.rowp + colc;
 #pragma unroll
-    for (int k = 0; k < HADI_LC; k++) y[k] = (k < len) ? Yb[(size_t)(ja + k) * rowp] : 0.0;
-    __syncthreads();
+    for (int k = 0; k < HADI_LC; k++) y[k] = src[(size_t)k * c.rowp];
+}
 
+HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ctile, int parity, double (&y)[HADI_LC]) {
+    const double *__restrict__ pb = c.pb;
     // forward elimination with the chunk-local factorisation
     {
         double ym1 = 0.0, ym2 = 0.0;
 #pragma unroll
         for (int k = 0; k < HADI_LC; k++) {
-            if (k < len) {
-                const double *__restrict__ t = pb + (size_t)k * HADI_PBW;
-                const double yk = (y[k] - t[PB_L] * ym1 - t[PB_L2] * ym2) * t[PB_Q];
-                y[k] = yk;
-                ym2 = ym1;
-                ym1 = yk;
-            }
+            const double *__restrict__ t = pb + (size_t)k * HADI_PBW;
+            const double yk = (y[k] - t[PB_L] * ym1 - t[PB_L2] * ym2) * t[PB_Q];
+            y[k] = yk;
+            ym2 = ym1;
+            ym1 = yk;
         }
     }
-    // back substitution; remember the chunk's first two / last two unknowns for the reduced system
-    double zl0 = 0.0, zl1 = 0.0;
+    // back substitution
     {
         double xp1 = 0.0, xp2 = 0.0;
 #pragma unroll
         for (int k = HADI_LC - 1; k >= 0; k--) {
-            if (k < len) {
-                const double *__restrict__ t = pb + (size_t)k * HADI_PBW;
-                const double xk = y[k] - t[PB_C] * xp1 - t[PB_C2] * xp2;
-                y[k] = xk;
-                xp2 = xp1;
-                xp1 = xk;
-                if (k == len - 1) zl1 = xk;
-                if (k == len - 2) zl0 = xk;
-            }
+            const double *__restrict__ t = pb + (size_t)k * HADI_PBW;
+            const double xk = y[k] - t[PB_C] * xp1 - t[PB_C2] * xp2;
+            y[k] = xk;
+            xp2 = xp1;
+            xp1 = xk;
         }
     }
+    const int P = c.P;
     if (P > 1) {
-        zsh[(wave * 4 + 0) * 64 + lane] = y[0];
-        zsh[(wave * 4 + 1) * 64 + lane] = y[1];
-        zsh[(wave * 4 + 2) * 64 + lane] = zl0;
-        zsh[(wave * 4 + 3) * 64 + lane] = zl1;
+        // interface exchange.  Two LDS buffers alternate by tile parity, so one barrier per tile is
+        // enough: a wave can only overwrite buffer b two tiles later, after every wave has passed the
+        // barrier of the tile in between, i.e. has finished reading b.
+        double *__restrict__ z = c.zsh + (size_t)parity * P * 4 * 64;
+        z[(c.wave * 4 + 0) * 64 + c.lane] = y[0];
+        z[(c.wave * 4 + 1) * 64 + c.lane] = y[1];
+        z[(c.wave * 4 + 2) * 64 + c.lane] = y[HADI_LC - 2];
+        z[(c.wave * 4 + 3) * 64 + c.lane] = y[HADI_LC - 1];
         __syncthreads();
         // t = Rinv z : this chunk needs the previous chunk's last two and the next chunk's first two
         const int n4 = 4 * P;
-        const double *__restrict__ Ri = a.rinv + (size_t)inst * n4 * n4;
+        const double *__restrict__ Ri = c.Ri;
         double tl0 = 0.0, tl1 = 0.0, tr0 = 0.0, tr1 = 0.0;
-        const int rl0 = (wave > 0) ? 4 * (wave - 1) + 2 : 0, rr0 = (wave < P - 1) ? 4 * (wave + 1) : 0;
+        const int rl0 = (c.wave > 0) ? 4 * (c.wave - 1) + 2 : 0, rr0 = (c.wave < P - 1) ? 4 * (c.wave + 1) : 0;
         for (int m = 0; m < n4; m++) {
-            const double z = zsh[m * 64 + lane];
-            tl0 = fma(Ri[(size_t)rl0 * n4 + m], z, tl0);
-            tl1 = fma(Ri[(size_t)(rl0 + 1) * n4 + m], z, tl1);
-            tr0 = fma(Ri[(size_t)rr0 * n4 + m], z, tr0);
-            tr1 = fma(Ri[(size_t)(rr0 + 1) * n4 + m], z, tr1);
+            const double zz = z[m * 64 + c.lane];
+            tl0 = fma(Ri[(size_t)rl0 * n4 + m], zz, tl0);
+            tl1 = fma(Ri[(size_t)(rl0 + 1) * n4 + m], zz, tl1);
+            tr0 = fma(Ri[(size_t)rr0 * n4 + m], zz, tr0);
+            tr1 = fma(Ri[(size_t)(rr0 + 1) * n4 + m], zz, tr1);
         }
         // spikes are zero where there is no neighbour (first chunk: V = 0, last chunk: W = 0)
 #pragma unroll
         for (int k = 0; k < HADI_LC; k++) {
-            if (k < len) {
-                const double *__restrict__ t = pb + (size_t)k * HADI_PBW;
-                y[k] = y[k] - t[PB_V0] * tl0 - t[PB_V1] * tl1 - t[PB_W0] * tr0 - t[PB_W1] * tr1;
+            const double *__restrict__ t = pb + (size_t)k * HADI_PBW;
+            y[k] = y[k] - t[PB_V0] * tl0 - t[PB_V1] * tl1 - t[PB_W0] * tr0 - t[PB_W1] * tr1;
+        }
+    }
+    const int col = ctile * 64 + c.lane;
+    const bool valid = col < c.rowp;
+    const int colc = valid ? col : c.rowp - 1;
+    const size_t base = (size_t)c.ja * c.rowp + colc;
+    if (!c.american) {
+        double *__restrict__ dst = c.Ui + base;
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < HADI_LC; k++) dst[(size_t)k * c.rowp] = y[k];
+        }
+    } else {
+        // Ikonen-Toivanen projection, device_solver.hpp:358-372
+        double *__restrict__ dst = c.Ui + base;
+        double *__restrict__ Lb = c.Li + base;
+        const double *__restrict__ P0 = c.P0i + base;
+        const double dt = c.dt;
+        const bool is_smax = (col == c.pos_m1);
+#pragma unroll
+        for (int k = 0; k < HADI_LC; k++) {
+            const size_t off = (size_t)k * c.rowp;
+            const double U_bar = y[k];
+            const double lamv = Lb[off];
+            const double pay = P0[off];
+            const double un = fmax(U_bar - dt * lamv, pay);
+            double ln = fmax(0.0, lamv + (pay - U_bar) / dt);
+            if (is_smax) ln = 0.0;
+            if (valid) {
+                dst[off] = un;
+                Lb[off] = ln;
             }
         }
     }
-    if (!a.american) {
-#pragma unroll
-        for (int k = 0; k < HADI_LC; k++)
-            if (k < len && valid) Ub[(size_t)(ja + k) * rowp] = y[k];
-    } else {
-        // Ikonen-Toivanen projection, device_solver.hpp:358-372
-        double *__restrict__ Lb = a.LAM + (size_t)inst * a.L.inst_stride + colc;
-        const double *__restrict__ P0 = a.U0 + (size_t)inst * a.L.inst_stride + colc;
-        const double dt = ip.dt;
-        const bool is_smax = (col == a.pos_m1);
-#pragma unroll
-        for (int k = 0; k < HADI_LC; k++) {
-            if (k < len) {
-                const size_t off = (size_t)(ja + k) * rowp;
-                const double U_bar = y[k];
-                const double lamv = Lb[off];
-                const double pay = P0[off];
-                const double un = fmax(U_bar - dt * lamv, pay);
-                double ln = fmax(0.0, lamv + (pay - U_bar) / dt);
-                if (is_smax) ln = 0.0;
-                if (valid) {
-                    Ub[off] = un;
-                    Lb[off] = ln;
-                }
-            }
-        }
+}
+
+// Dynamic LDS: P * (2*4*64 + HADI_LC*HADI_PBW) doubles (two interface-exchange buffers + the chunk tables).
+// MAXP only sets the launch bound (register budget): 8 -> 512 threads, 16 -> 1024 threads.
+template <int MAXP>
+__global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n) {
+    HADI_DYN_SMEM(double, smem);
+    HadiPassBCtx c;
+    c.lane = threadIdx.x & 63;
+    c.wave = HADI_UNIFORM((int)(threadIdx.x >> 6));
+    c.P = a.L.P;
+    c.zsh = smem;
+    double *__restrict__ tsh = smem + (size_t)c.P * 2 * 4 * 64;
+    const int inst = blockIdx.x / a.bgroups, grp = blockIdx.x - inst * a.bgroups;
+    const HadiInstPar ip = a.ipar[inst];
+    if (n > ip.N) return;  // whole block: uniform
+    const int nrows = a.L.nrows_pad;
+    c.rowp = a.L.rowp;
+    c.ja = c.wave * HADI_LC;
+    c.Yi = a.Y + (size_t)inst * a.L.inst_stride;
+    c.Ui = a.U + (size_t)inst * a.L.inst_stride;
+    c.Li = a.american ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
+    c.P0i = a.american ? a.U0 + (size_t)inst * a.L.inst_stride : nullptr;
+    c.Ri = a.rinv + (size_t)inst * 16 * c.P * c.P;
+    c.american = a.american;
+    c.pos_m1 = a.pos_m1;
+    c.dt = ip.dt;
+    const int t0 = grp * a.btpw;
+    const int t1 = (t0 + a.btpw < a.ctiles) ? t0 + a.btpw : a.ctiles;
+
+    double ya[HADI_LC], yb[HADI_LC];
+    hadi_pb_load(c, t0, ya);
+    // the chunk's table (HADI_LC x HADI_PBW doubles, identical for every column) goes through LDS once per
+    // block: coalesced load, then every use is a conflict-free broadcast read with a compile-time offset
+    {
+        const double *__restrict__ pbg = a.pb + ((size_t)inst * nrows + c.ja) * HADI_PBW;
+        double *__restrict__ tw = tsh + c.wave * (HADI_LC * HADI_PBW);
+        for (int e = c.lane; e < HADI_LC * HADI_PBW; e += 64) tw[e] = pbg[e];
+        c.pb = tw;
+    }
+    __syncthreads();
+    for (int t = t0; t < t1; t += 2) {
+        if (t + 1 < t1) hadi_pb_load(c, t + 1, yb);
+        hadi_pb_solve_store(c, t, 0, ya);
+        if (t + 2 < t1) hadi_pb_load(c, t + 2, ya);
+        if (t + 1 < t1) hadi_pb_solve_store(c, t + 1, 1, yb);
     }
 }
 
@@ -471,8 +516,8 @@ __global__ void __launch_bounds__(256) hadi_setup_kernel(HadiSetupArgs s) {
     t.scoef = s.scoef + (size_t)inst * 6 * 64 * L.B;
     t.b2row = s.b2row + (size_t)inst * L.rowp;
     t.rowc = s.rowc + (size_t)inst * L.nrows * HADI_RC;
-    t.a2i = s.a2i + (size_t)inst * 5 * L.nrows;
-    t.pb = s.pb + (size_t)inst * L.nrows * HADI_PBW;
+    t.a2i = s.a2i + (size_t)inst * 5 * L.nrows_pad;
+    t.pb = s.pb + (size_t)inst * L.nrows_pad * HADI_PBW;
     t.rinv = s.rinv + (size_t)inst * n4 * n4;
     t.rwork = s.rwork + (size_t)inst * n4 * 2 * n4;
     t.ipar = s.ipar + inst;
@@ -484,13 +529,13 @@ __global__ void __launch_bounds__(256) hadi_setup_kernel(HadiSetupArgs s) {
 // Instance k of the internal array reads natural instance k % n_src (a Jacobian batch replicates U_0).
 __global__ void __launch_bounds__(256) hadi_pack_kernel(HadiLayout L, int n_inst, int n_src,
                                                         const double *__restrict__ nat, double *__restrict__ internal) {
-    const size_t total = (size_t)n_inst * L.nrows * L.rowp;
+    const size_t total = (size_t)n_inst * L.nrows_pad * L.rowp;
     const size_t m = (size_t)(L.m1 + 1) * L.nrows;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int slot = (int)(e % L.rowp);
         const size_t rowid = e / L.rowp;
-        const int j = (int)(rowid % L.nrows);
-        const size_t inst = rowid / L.nrows;
+        const int j = (int)(rowid % L.nrows_pad);
+        const size_t inst = rowid / L.nrows_pad;
         // invert pos(): slot -> i
         int i;
         if (slot == 64 * L.B) i = 0;
@@ -501,7 +546,7 @@ __global__ void __launch_bounds__(256) hadi_pack_kernel(HadiLayout L, int n_inst
             i = 1 + L.B * lane + r;
         }
         double v = 0.0;
-        if (i >= 0 && i <= L.m1) v = nat[(inst % (size_t)n_src) * m + (size_t)j * (L.m1 + 1) + i];
+        if (i >= 0 && i <= L.m1 && j < L.nrows) v = nat[(inst % (size_t)n_src) * m + (size_t)j * (L.m1 + 1) + i];
         internal[e] = v;
     }
 }

@@ -7,7 +7,9 @@ struct HadiPlan {
     int R, ntiles;       // pass A: v-rows per wavefront, wavefront tiles per instance
     int grid_a;          // pass A grid (64-thread blocks), padded to a multiple of 8 for the XCD remap
     int ctiles;          // pass B: 64-column tiles per instance
+    int btpw, bgroups;   // pass B: column tiles per block (register double-buffered), blocks per instance
     int grid_b, block_b; // pass B grid / block (P*64 threads)
+    size_t smem_b;       // pass B dynamic LDS bytes
     int pos_m1;
     // table sizes per instance (doubles)
     size_t n_scoef, n_b2row, n_rowc, n_a2i, n_pb, n_rinv, n_rwork;
@@ -25,9 +27,8 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
     L.rowp = 64 * L.B + 8;
     L.P = (L.nrows + HADI_LC - 1) / HADI_LC;
     if (L.P > HADI_MAX_P) return 1;
-    // every chunk needs >= 2 rows for its first2/last2 interface pairs
-    if (L.P > 1 && L.nrows / L.P < 2) return 1;
-    L.inst_stride = (long long)L.rowp * L.nrows;
+    L.nrows_pad = L.P * HADI_LC;
+    L.inst_stride = (long long)L.rowp * L.nrows_pad;
     // Row tiles: as tall as possible (halo re-reads cost 4/R) while the launch still has
     // >= target_waves wavefronts (256 CUs x 4 SIMDs x a few waves).
     int ntiles = (target_waves + n_inst - 1) / n_inst;
@@ -42,14 +43,25 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
     const long long total = (long long)n_inst * ntiles;
     p.grid_a = (int)((total + 7) / 8 * 8);
     p.ctiles = (L.rowp + 63) / 64;
-    p.grid_b = n_inst * p.ctiles;
+    // Each block walks over btpw column tiles (loads of the next tile overlap the solve of the current
+    // one); keep >= ~3 blocks per CU in the launch so that tails stay short.
+    {
+        const int want_blocks = (3 * target_waves) / 8;  // target_waves = 8 per CU
+        int groups = (want_blocks + n_inst - 1) / n_inst;
+        if (groups < 1) groups = 1;
+        if (groups > p.ctiles) groups = p.ctiles;
+        p.btpw = (p.ctiles + groups - 1) / groups;
+        p.bgroups = (p.ctiles + p.btpw - 1) / p.btpw;
+    }
+    p.grid_b = n_inst * p.bgroups;
     p.block_b = 64 * L.P;
+    p.smem_b = (size_t)L.P * (2 * 4 * 64 + HADI_LC * HADI_PBW) * sizeof(double);
     p.pos_m1 = hadi_pos(L.B, m1);
     p.n_scoef = (size_t)6 * 64 * L.B;
     p.n_b2row = (size_t)L.rowp;
     p.n_rowc = (size_t)L.nrows * HADI_RC;
-    p.n_a2i = (size_t)5 * L.nrows;
-    p.n_pb = (size_t)L.nrows * HADI_PBW;
+    p.n_a2i = (size_t)5 * L.nrows_pad;
+    p.n_pb = (size_t)L.nrows_pad * HADI_PBW;
     p.n_rinv = (size_t)16 * L.P * L.P;
     p.n_rwork = (size_t)32 * L.P * L.P;
     *out = p;

@@ -61,7 +61,7 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
     HadiSweepArgs a;
     a.U = dU.data(); a.Y = dY.data(); a.LAM = american ? dLAM.data() : nullptr; a.U0 = american ? dU0.data() : nullptr;
     a.scoef = scoef.data(); a.b2row = b2row.data(); a.rowc = rowc.data(); a.pb = pb.data(); a.rinv = rinv.data();
-    a.ipar = ipar.data(); a.L = L; a.n_inst = n_inst; a.R = pl.R; a.ntiles = pl.ntiles; a.ctiles = pl.ctiles;
+    a.ipar = ipar.data(); a.L = L; a.n_inst = n_inst; a.R = pl.R; a.ntiles = pl.ntiles; a.ctiles = pl.ctiles; a.btpw = pl.btpw; a.bgroups = pl.bgroups;
     a.american = american; a.pos_m1 = pl.pos_m1;
 
     int cur = 0;
@@ -84,7 +84,7 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
             case 16: run_pass_a<16>(pl, a, n); break;
             default: return 2;
         }
-        emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b(a, n); });
+        emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b<16>(a, n); }, pl.smem_b);
     }
     emu::launch(8, 64, [&]() { hadi_unpack_kernel(L, n_inst, dU.data(), U); });
     if (american && lam_out) emu::launch(8, 64, [&]() { hadi_unpack_kernel(L, n_inst, dLAM.data(), lam_out); });

@@ -42,6 +42,7 @@ struct WaveState {
 struct BlockState {
     pthread_barrier_t bar;
     std::vector<WaveState *> waves;
+    unsigned char *dyn_smem = nullptr;
 };
 extern thread_local emu_dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 extern thread_local BlockState *t_block;
@@ -81,9 +82,11 @@ namespace emu {
 // thread that returns early simply drops out (its wave mates must not shuffle afterwards, which
 // holds for the wave- or block-uniform early exits the kernels use).
 template <class F>
-void launch(unsigned grid, unsigned block, F body) {
+void launch(unsigned grid, unsigned block, F body, size_t dyn_smem_bytes = 0) {
+    std::vector<double> smem_store((dyn_smem_bytes + 7) / 8 + 2);
     for (unsigned b = 0; b < grid; b++) {
         BlockState bs;
+        bs.dyn_smem = reinterpret_cast<unsigned char *>(smem_store.data());
         pthread_barrier_init(&bs.bar, nullptr, block);
         const unsigned nw = (block + 63) / 64;
         for (unsigned w = 0; w < nw; w++) {

@@ -84,7 +84,8 @@ def test_setup_tables_against_oracle_operators(emu):
     B, rowp, Pn = plan[0], plan[1], plan[2]
     nrows = m2 + 1
     scoef, b2row = np.zeros(6 * 64 * B), np.zeros(rowp)
-    rowc, a2i, pb, rinv = np.zeros(nrows * 16), np.zeros(5 * nrows), np.zeros(nrows * 12), np.zeros(16 * Pn * Pn)
+    npad = Pn * 33  # HADI_LC rows per column-pass chunk
+    rowc, a2i, pb, rinv = np.zeros(nrows * 16), np.zeros(5 * npad), np.zeros(npad * 12), np.zeros(16 * Pn * Pn)
     rc = emu.emu_tables(m1, m2, N, C.c_double(Cm.T / N), C.c_double(Cm.THETA), C.c_double(Cm.R_D), C.c_double(0.0),
                         C.c_double(Cm.RHO), C.c_double(Cm.SIGMA), C.c_double(Cm.KAPPA), C.c_double(Cm.ETA),
                         _P(vs[0]), _P(vv[0]), _P(ds[0]), _P(dv[0]), 8, _P(scoef), _P(b2row), _P(rowc), _P(a2i),
