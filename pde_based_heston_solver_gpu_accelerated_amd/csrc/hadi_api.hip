@@ -29,7 +29,6 @@ struct Ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> kev;  // per-launch events (profiling)
     int profiling = 0;
-    int tune_b16 = 0;  // HADI_TUNE_B16=1: tighter register budget for the column pass (tuning knob)
     int cu_count = 256;
     std::string name, arch;
     std::string err;
@@ -125,7 +124,23 @@ struct SweepDesc {
 
 template <int B>
 void launch_pass_a(const HadiPlan &pl, const HadiSweepArgs &a, int n, hipStream_t s) {
-    hipLaunchKernelGGL(hadi_pass_a<B>, dim3(pl.grid_a), dim3(64), 0, s, a, n);
+    hipLaunchKernelGGL((hadi_pass_a<B, 4>), dim3(pl.grid_a), dim3(64 * pl.W), pl.smem_a, s, a, n);
+}
+
+// Kernels whose dynamic LDS can exceed the 64 KiB default need the limit raised once.
+template <class K>
+hipError_t raise_lds_limit(K kernel) {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+hipError_t raise_all_lds_limits() {
+    hipError_t e;
+    if ((e = raise_lds_limit(hadi_pass_a<1, 4>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<2, 4>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<4, 4>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<8, 4>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<16, 4>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_b<8>)) != hipSuccess) return e;
+    return raise_lds_limit(hadi_pass_b<16>);
 }
 
 int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
@@ -161,6 +176,8 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     hipStream_t s = c->stream;
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     HIP_TRY(c, hipMemcpyAsync(c->par8.p, d.par8.data(), 8 * 8 * n, hipMemcpyHostToDevice, s));
+    // identity padding rows of Y must read as zeros in the column pass (the row pass never writes them)
+    HIP_TRY(c, hipMemsetAsync(c->Y.p, 0, st, s));
 
     HadiSetupArgs sa;
     sa.L = L; sa.n_inst = d.n;
@@ -225,7 +242,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
             HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 1], s));
             HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 2], s));
         }
-        if (L.P <= 8 && !c->tune_b16) hipLaunchKernelGGL(hadi_pass_b<8>, dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, s, a, nstep);
+        if (L.P <= 8) hipLaunchKernelGGL(hadi_pass_b<8>, dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, s, a, nstep);
         else hipLaunchKernelGGL(hadi_pass_b<16>, dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, s, a, nstep);
         if (prof) HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 3], s));
     }
@@ -536,8 +553,8 @@ int hadi_create(hadi_ctx **out, int device_id) {
     c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->name = prop.name;
     c->arch = prop.gcnArchName;
-    if (const char *e = std::getenv("HADI_TUNE_B16")) c->tune_b16 = std::atoi(e);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return HADI_ERR_HIP; }
+    if (raise_all_lds_limits() != hipSuccess) { delete c; return HADI_ERR_HIP; }
     for (auto &e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete c; return HADI_ERR_HIP; }
     *out = reinterpret_cast<hadi_ctx *>(c);

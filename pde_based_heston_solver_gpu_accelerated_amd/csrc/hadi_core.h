@@ -120,7 +120,8 @@ struct HadiSetupIn {
 
 // Output tables of one instance (all device pointers, already offset to the instance).
 struct HadiTables {
-    double *scoef;   // [6][64*B]   B_k = s_i beta_s(i-1,k), D_k = 1/2 s_i^2 delta_s(i-1,k), k=-1,0,1
+    double *scoef;   // [4][64*B]   Bm, Bp, Dm, Dp with B_k = s_i beta_s(i-1,k), D_k = 1/2 s_i^2 delta_s(i-1,k),
+                     //             k = -1, +1 (the k = 0 weights are -(m + p): the FD weights sum to zero)
     double *b2row;   // [rowp]      -1/2 r_d s_i E in state layout (hes_boundary_kernels.hpp:62-66)
     double *rowc;    // [nrows][HADI_RC]
     double *a2i;     // [5][nrows_pad]  implicit A2 diagonals by row: l2, l1, m, u1, u2 (identity past nrows)
@@ -156,16 +157,16 @@ HADI_HD inline void hadi_setup_instance(const HadiLayout &L, const HadiSetupIn &
         *t.ipar = ip;
     }
     // --- s-direction coefficients (hes_a0_kernels.hpp:37-49, hes_a1_kernels.hpp:69-91) ---------
-    for (int k = tid; k < 6 * nslot; k += nth) t.scoef[k] = 0.0;
+    for (int k = tid; k < 4 * nslot; k += nth) t.scoef[k] = 0.0;
     for (int k = tid; k < L.rowp; k += nth) t.b2row[k] = 0.0;
     sync();
     for (int i = tid + 1; i < m1; i += nth) {
         const double s = in.vec_s[i];
         const int pos = hadi_pos(B, i);
-        for (int k = -1; k <= 1; k++) {
-            t.scoef[(k + 1) * nslot + pos] = s * hadi_fd_beta(in.delta_s, i - 1, k);
-            t.scoef[(k + 4) * nslot + pos] = 0.5 * s * s * hadi_fd_delta(in.delta_s, i - 1, k);
-        }
+        t.scoef[0 * nslot + pos] = s * hadi_fd_beta(in.delta_s, i - 1, -1);
+        t.scoef[1 * nslot + pos] = s * hadi_fd_beta(in.delta_s, i - 1, 1);
+        t.scoef[2 * nslot + pos] = 0.5 * s * s * hadi_fd_delta(in.delta_s, i - 1, -1);
+        t.scoef[3 * nslot + pos] = 0.5 * s * s * hadi_fd_delta(in.delta_s, i - 1, 1);
     }
     for (int i = tid; i <= m1; i += nth) t.b2row[hadi_pos(B, i)] = -0.5 * in.r_d * in.vec_s[i] * E;
     // --- v-rows: A0 weights, explicit A2, boundary b1 ---------------------------------------------

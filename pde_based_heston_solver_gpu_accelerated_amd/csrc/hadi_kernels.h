@@ -83,39 +83,69 @@ HADI_DEV HADI_FORCEINLINE void hadi_store_row(double *__restrict__ row, int lane
     }
 }
 
-// B-weighted s-derivative of one row: sb[r] = Bm[r] u[r-1] + Bz[r] u[r] + Bp[r] u[r+1], with the
-// neighbours of the lane's block fetched from the adjacent lanes (eL/eR are returned for reuse).
-template <int B>
-HADI_DEV HADI_FORCEINLINE void hadi_sderiv(const double (&u)[B], double c0val, int lane, const double (&Bm)[B],
-                                           const double (&Bz)[B], const double (&Bp)[B], double (&sb)[B],
-                                           double &eL, double &eR) {
-    eL = __shfl_up(u[B - 1], 1);
-    if (lane == 0) eL = c0val;
-    eR = __shfl_down(u[0], 1);
-    if (lane == 63) eR = 0.0;
-#pragma unroll
-    for (int r = 0; r < B; r++) {
-        const double uL = (r == 0) ? eL : u[r == 0 ? 0 : r - 1];
-        const double uR = (r == B - 1) ? eR : u[r == B - 1 ? r : r + 1];
-        sb[r] = Bm[r] * uL + Bz[r] * u[r] + Bp[r] * uR;
+// ---- LDS row ring helpers ---------------------------------------------------------------------------
+// Asynchronous copy of one state row (rowp doubles, HBM layout == LDS layout) into the ring: LDS-DMA
+// (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPRs); it completes before the next
+// __syncthreads(), which drains vmcnt.  Rows outside the allocation are written as zeros instead.
+HADI_DEV HADI_FORCEINLINE void hadi_row_to_lds(const double *__restrict__ grow, double *lrow, int rowp, int lane,
+                                               bool exists) {
+    const int nvec = rowp >> 1;  // 16-byte vectors per row
+    if (exists) {
+        for (int v0 = 0; v0 < nvec; v0 += 64) {
+            if (v0 + lane < nvec) {
+#if defined(HADI_EMU)
+                lrow[2 * (v0 + lane)] = grow[2 * (v0 + lane)];
+                lrow[2 * (v0 + lane) + 1] = grow[2 * (v0 + lane) + 1];
+#else
+                __builtin_amdgcn_global_load_lds((const void *)(grow + 2 * (v0 + lane)),
+                                                 (__attribute__((address_space(3))) void *)(lrow + 2 * v0), 16, 0, 0);
+#endif
+            }
+        }
+    } else {
+        for (int v = lane; v < nvec; v += 64) {
+            lrow[2 * v] = 0.0;
+            lrow[2 * v + 1] = 0.0;
+        }
     }
 }
 
 template <int B>
-__global__ void __launch_bounds__(64) hadi_pass_a(HadiSweepArgs a, int n) {
-    const int lane = threadIdx.x;
+HADI_DEV HADI_FORCEINLINE void hadi_lds_row(const double *lrow, int lane, double (&u)[B]) {
+    if constexpr (B == 1) {
+        u[0] = lrow[lane];
+    } else {
+#pragma unroll
+        for (int q = 0; q < B / 2; q++) {
+            const double2 t = *reinterpret_cast<const double2 *>(lrow + q * 128 + 2 * lane);
+            u[2 * q] = t.x;
+            u[2 * q + 1] = t.y;
+        }
+    }
+}
+
+// pass A.  Block = W wavefronts working on W consecutive v-rows of one instance at a time; the rows
+// j-2 .. j+W+1 they need (9-point A0, 5-point A2) sit in an LDS ring of 2W+4 rows that is refilled by
+// LDS-DMA one iteration ahead, so HBM latency hides behind the line solves.  Lane l owns the s-nodes
+// i = 1+B*l .. B*l+B of its wave's row.
+template <int B, int W>
+__global__ void __launch_bounds__(64 * W, (B >= 16 ? 1 : 2)) hadi_pass_a(HadiSweepArgs a, int n) {
+    HADI_DYN_SMEM(double, smem);
+    constexpr int RING = 2 * W + 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = HADI_UNIFORM((int)(threadIdx.x >> 6));
     const int total = a.n_inst * a.ntiles;
     const int logical = hadi_xcd_remap(blockIdx.x, gridDim.x);
     if (logical >= total) return;
     const int inst = logical / a.ntiles, tile = logical - inst * a.ntiles;
     const HadiInstPar ip = a.ipar[inst];
     if (n > ip.N) return;
-    const int nrows = a.L.nrows, rowp = a.L.rowp;
+    const int nrows = a.L.nrows, npad = a.L.nrows_pad, rowp = a.L.rowp;
     const int j0 = tile * a.R;
     const int j1 = (j0 + a.R < nrows) ? j0 + a.R : nrows;
     if (j0 >= j1) return;
 
-    const double dt = ip.dt, thdt = ip.thdt, q = ip.q, half_rd = ip.half_rd;
+    const double dt = ip.dt, thdt = ip.thdt, qd = ip.q, half_rd = ip.half_rd;
     const double e_nm1 = exp(ip.r_f * dt * (n - 1));  // device_solver.hpp:238
     const double e_n = exp(ip.r_f * dt * n);          // device_solver.hpp:246
 
@@ -123,56 +153,41 @@ __global__ void __launch_bounds__(64) hadi_pass_a(HadiSweepArgs a, int n) {
     double *__restrict__ Yb = a.Y + (size_t)inst * a.L.inst_stride;
     const double *__restrict__ Lb = a.american ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
     const double *__restrict__ rowc = a.rowc + (size_t)inst * nrows * HADI_RC;
-    const double *__restrict__ sc = a.scoef + (size_t)inst * 6 * 64 * B;
+    const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B;
     const double *__restrict__ b2r = a.b2row + (size_t)inst * rowp;
     const int c0slot = 64 * B;
+    // positions of the s-neighbours of this lane's block: i-1 of its first node, i+1 of its last node.
+    // Lane 0's left neighbour is the i = 0 slot; lane 63's right neighbour is a pad slot (always 0).
+    int posL, posR;
+    if constexpr (B == 1) {
+        posL = lane == 0 ? c0slot : lane - 1;
+        posR = lane == 63 ? c0slot + 1 : lane + 1;
+    } else {
+        posL = lane == 0 ? c0slot : (B / 2 - 1) * 128 + 2 * lane - 1;
+        posR = lane == 63 ? c0slot + 1 : 2 * lane + 2;
+    }
 
-    // j- and time-invariant s-coefficients of this lane's B nodes
-    double Bm[B], Bz[B], Bp[B], Dm[B], Dz[B], Dp[B];
+    // j- and time-invariant s-coefficients of this lane's B nodes.  The central weights follow from
+    // sum_k beta_s(.,k) = sum_k delta_s(.,k) = 0:  B0 = -(Bm + Bp), D0 = -(Dm + Dp).
+    double Bm[B], Bp[B], Dm[B], Dp[B];
     hadi_load_row<B>(sc + 0 * 64 * B, lane, true, Bm);
-    hadi_load_row<B>(sc + 1 * 64 * B, lane, true, Bz);
-    hadi_load_row<B>(sc + 2 * 64 * B, lane, true, Bp);
-    hadi_load_row<B>(sc + 3 * 64 * B, lane, true, Dm);
-    hadi_load_row<B>(sc + 4 * 64 * B, lane, true, Dz);
-    hadi_load_row<B>(sc + 5 * 64 * B, lane, true, Dp);
+    hadi_load_row<B>(sc + 1 * 64 * B, lane, true, Bp);
+    hadi_load_row<B>(sc + 2 * 64 * B, lane, true, Dm);
+    hadi_load_row<B>(sc + 3 * 64 * B, lane, true, Dp);
 
-    // rolling window of v-rows j-2 .. j+2 (u*) and of column i = 0 (c*); rows outside the grid are 0
-    double um2[B], um1[B], u0[B], up1[B], up2[B];
-    double cm2, cm1, c0, cp1, cp2;
-    auto rowptr = [&](int j) { return Ub + (size_t)j * rowp; };
-    auto inrange = [&](int j) { return j >= 0 && j < nrows; };
-    hadi_load_row<B>(rowptr(j0 - 2), lane, inrange(j0 - 2), um2);
-    hadi_load_row<B>(rowptr(j0 - 1), lane, inrange(j0 - 1), um1);
-    hadi_load_row<B>(rowptr(j0), lane, true, u0);
-    hadi_load_row<B>(rowptr(j0 + 1), lane, inrange(j0 + 1), up1);
-    hadi_load_row<B>(rowptr(j0 + 2), lane, inrange(j0 + 2), up2);
-    cm2 = inrange(j0 - 2) ? rowptr(j0 - 2)[c0slot] : 0.0;
-    cm1 = inrange(j0 - 1) ? rowptr(j0 - 1)[c0slot] : 0.0;
-    c0 = rowptr(j0)[c0slot];
-    cp1 = inrange(j0 + 1) ? rowptr(j0 + 1)[c0slot] : 0.0;
-    cp2 = inrange(j0 + 2) ? rowptr(j0 + 2)[c0slot] : 0.0;
+    auto slot = [&](int jj) { return smem + (size_t)((jj + RING) % RING) * rowp; };
+    auto fetch = [&](int jj) { hadi_row_to_lds(Ub + (size_t)jj * rowp, slot(jj), rowp, lane, jj >= 0 && jj < npad); };
+    for (int rr = wave; rr < W + 4; rr += W) fetch(j0 - 2 + rr);
 
-    // B-weighted s-derivatives of rows j-1, j, j+1 (A0 needs all three, A1 the middle one's edges)
-    double sbm[B], sb0[B], sbp[B];
-    double eL0, eR0, eLp, eRp, eTmpL, eTmpR;
-    hadi_sderiv<B>(um1, cm1, lane, Bm, Bz, Bp, sbm, eTmpL, eTmpR);
-    hadi_sderiv<B>(u0, c0, lane, Bm, Bz, Bp, sb0, eL0, eR0);
-    hadi_sderiv<B>(up1, cp1, lane, Bm, Bz, Bp, sbp, eLp, eRp);
+    const int iters = (j1 - j0 + W - 1) / W;
+    for (int it = 0; it < iters; it++) {
+        const int J = j0 + it * W;
+        __syncthreads();  // this iteration's rows have landed; everyone is done with the rows replaced below
+        if (it + 1 < iters) fetch(J + W + 2 + wave);
+        const int j = J + wave;
+        if (j >= j1) continue;
 
-    for (int j = j0; j < j1; j++) {
-        // software prefetch: row j+3 is requested now and first consumed (as the j+2 operand of A2)
-        // in the NEXT iteration, so its HBM latency hides behind this row's solve
-        double nxt[B];
-        const bool more = (j + 1 < j1);
-        hadi_load_row<B>(rowptr(j + 3), lane, more && inrange(j + 3), nxt);
-        const double cnxt = (more && inrange(j + 3)) ? rowptr(j + 3)[c0slot] : 0.0;
-        double lam[B];
-        double lamc0 = 0.0;
-        if (a.american) {
-            hadi_load_row<B>(Lb + (size_t)j * rowp, lane, true, lam);
-            lamc0 = Lb[(size_t)j * rowp + c0slot];
-        }
-
+        const double *rm2 = slot(j - 2), *rm1 = slot(j - 1), *r0 = slot(j), *rp1 = slot(j + 1), *rp2 = slot(j + 2);
         const double *__restrict__ rc = rowc + (size_t)j * HADI_RC;
         const double v = rc[RC_V];
         const double wm = rc[RC_WM], wz = rc[RC_WZ], wp = rc[RC_WP];
@@ -180,13 +195,22 @@ __global__ void __launch_bounds__(64) hadi_pass_a(HadiSweepArgs a, int n) {
         const double b1val = rc[RC_B1VAL];
         const int b1col = (int)rc[RC_B1COL];
         const bool last = rc[RC_LAST] != 0.0;
-        // b1 sits at s-index b1col of this row: which lane / slot is that?
         const int b1e = b1col - 1;
         const int b1lane = (b1col >= 1) ? b1e / B : -1;
         const int b1r = (b1col >= 1) ? b1e - b1lane * B : -1;
 
+        double lam[B];
+        double lamc0 = 0.0;
+        if (a.american) {
+            hadi_load_row<B>(Lb + (size_t)j * rowp, lane, true, lam);
+            lamc0 = Lb[(size_t)j * rowp + c0slot];
+        }
+        double b2v[B];
+        hadi_load_row<B>(b2r, lane, last, b2v);
+
         // ---- column i = 0 (A0 and A1 rows are zero there; only A2 and the boundary act) --------
-        const double a2c0 = a2l2 * cm2 + a2l1 * cm1 + a2m * c0 + a2u1 * cp1 + a2u2 * cp2;
+        const double c0 = r0[c0slot];
+        const double a2c0 = a2l2 * rm2[c0slot] + a2l1 * rm1[c0slot] + a2m * c0 + a2u1 * rp1[c0slot] + a2u2 * rp2[c0slot];
         const double b1c0 = (b1col == 0) ? b1val : 0.0;
         const double b2c0 = last ? b2r[c0slot] : 0.0;
         double y0c0 = c0 + dt * (a2c0 + (b1c0 + b2c0) * e_nm1 + lamc0);
@@ -194,52 +218,78 @@ __global__ void __launch_bounds__(64) hadi_pass_a(HadiSweepArgs a, int n) {
         const double x0 = y0c0;  // A1 row 0 is the identity (hes_a1_kernels.hpp:56-61)
         const double yout_c0 = x0 + thdt * (b2c0 * e_n - (a2c0 + b2c0 * e_nm1));
 
-        // ---- explicit stage on the lane's B nodes --------------------------------------------------
-        double b2v[B];
-        hadi_load_row<B>(b2r, lane, last, b2v);
-        double A2U[B], d[B], il[B], im[B], iu[B];
+        // ---- explicit operators.  A0 = (s-derivative) o (v-derivative): first the v-combination
+        // t = wm u(j-1) + wz u(j) + wp u(j+1) on the block and its two s-neighbours, then B-weights.
+        double u0[B], tt[B], A2U[B];
+        {
+            double um[B], up[B], u2[B];
+            hadi_lds_row<B>(r0, lane, u0);
+            hadi_lds_row<B>(rm1, lane, um);
+            hadi_lds_row<B>(rp1, lane, up);
+#pragma unroll
+            for (int r = 0; r < B; r++) {
+                tt[r] = wm * um[r] + wz * u0[r] + wp * up[r];
+                A2U[r] = a2l1 * um[r] + a2m * u0[r] + a2u1 * up[r];
+            }
+            hadi_lds_row<B>(rm2, lane, u2);
+#pragma unroll
+            for (int r = 0; r < B; r++) A2U[r] = fma(a2l2, u2[r], A2U[r]);
+            hadi_lds_row<B>(rp2, lane, u2);
+#pragma unroll
+            for (int r = 0; r < B; r++) A2U[r] = fma(a2u2, u2[r], A2U[r]);
+        }
+        const double u0L = r0[posL], u0R = r0[posR];
+        const double tL = wm * rm1[posL] + wz * u0L + wp * rp1[posL];
+        const double tR = wm * rm1[posR] + wz * u0R + wp * rp1[posR];
+
+        // ---- Y0 (device_solver.hpp:236-250) fused with the forward sweep of the in-lane Thomas --------
+        //   x[r] = ys[r] - XL*ps[r] - X*gs[r],  XL = interface unknown of lane-1, X = own x[B-1]
+        constexpr int NB = B - 1;
+        double ys[B], ps[B], iu[B], invt[B];
+        double il_last = 0.0, im_last = 1.0, d_last = 0.0;
 #pragma unroll
         for (int r = 0; r < B; r++) {
-            const double uL = (r == 0) ? eL0 : u0[r == 0 ? 0 : r - 1];
-            const double uR = (r == B - 1) ? eR0 : u0[r == B - 1 ? r : r + 1];
-            const double lo = fma(v, Dm[r], q * Bm[r]);
-            const double mn = fma(v, Dz[r], fma(q, Bz[r], -half_rd));
-            const double up = fma(v, Dp[r], q * Bp[r]);
+            const double uL = (r == 0) ? u0L : u0[r == 0 ? 0 : r - 1];
+            const double uR = (r == B - 1) ? u0R : u0[r == B - 1 ? r : r + 1];
+            const double tl = (r == 0) ? tL : tt[r == 0 ? 0 : r - 1];
+            const double tr = (r == B - 1) ? tR : tt[r == B - 1 ? r : r + 1];
+            const double lo = fma(v, Dm[r], qd * Bm[r]);
+            const double up = fma(v, Dp[r], qd * Bp[r]);
+            const double mn = -(fma(v, Dm[r] + Dp[r], qd * (Bm[r] + Bp[r])) + half_rd);
             const double A1U = lo * uL + mn * u0[r] + up * uR;
-            const double A0U = wm * sbm[r] + wz * sb0[r] + wp * sbp[r];
-            A2U[r] = a2l2 * um2[r] + a2l1 * um1[r] + a2m * u0[r] + a2u1 * up1[r] + a2u2 * up2[r];
+            const double A0U = Bm[r] * tl - (Bm[r] + Bp[r]) * tt[r] + Bp[r] * tr;
             const double b1h = (lane == b1lane && r == b1r) ? b1val : 0.0;
             double S = A0U + A1U + A2U[r] + (b1h + b2v[r]) * e_nm1;
             if (a.american) S += lam[r];
             double y = u0[r] + dt * S;
             y = y + thdt * (b1h * e_n - (A1U + b1h * e_nm1));
-            d[r] = y;
-            il[r] = -thdt * lo;
-            im[r] = 1.0 - thdt * mn;
+            double il = -thdt * lo;
+            const double im = 1.0 - thdt * mn;
             iu[r] = -thdt * up;
+            if (r == 0 && lane == 0) {  // x_0 is known: move it to the right-hand side
+                y -= il * x0;
+                il = 0.0;
+            }
+            if (r < NB) {
+                if (r == 0) {
+                    invt[0] = hadi_rcp(im);
+                    ys[0] = y;
+                    ps[0] = il;
+                } else {
+                    const double w = il * invt[r - 1];
+                    invt[r] = hadi_rcp(fma(-w, iu[r - 1], im));
+                    ys[r] = fma(-w, ys[r - 1], y);
+                    ps[r] = -w * ps[r - 1];
+                }
+            } else {
+                il_last = il;
+                im_last = im;
+                d_last = y;
+            }
         }
-        // x_0 is known: move it to the right-hand side of the first unknown
-        if (lane == 0) {
-            d[0] -= il[0] * x0;
-            il[0] = 0.0;
-        }
-
-        // ---- A1 solve: in-lane Thomas on r = 0..B-2 against both interfaces ------------------------
-        //   x[r] = y[r] - XL*p[r] - X*g[r],  XL = interface unknown of lane-1, X = own x[B-1]
-        constexpr int NB = B - 1;
-        double ys[B], ps[B], gs[B], invt[B];  // sized B so B == 1 compiles; entries [0..NB) used
+        double gs[B];
         double ra, rb, rcc, rf;
         if constexpr (NB > 0) {
-            invt[0] = hadi_rcp(im[0]);
-            ys[0] = d[0];
-            ps[0] = il[0];
-#pragma unroll
-            for (int r = 1; r < NB; r++) {
-                const double w = il[r] * invt[r - 1];
-                invt[r] = hadi_rcp(fma(-w, iu[r - 1], im[r]));
-                ys[r] = fma(-w, ys[r - 1], d[r]);
-                ps[r] = -w * ps[r - 1];
-            }
             gs[NB - 1] = iu[NB - 1] * invt[NB - 1];
             ys[NB - 1] *= invt[NB - 1];
             ps[NB - 1] *= invt[NB - 1];
@@ -253,15 +303,15 @@ __global__ void __launch_bounds__(64) hadi_pass_a(HadiSweepArgs a, int n) {
             const double p0n = __shfl_down(ps[0], 1);
             const double g0n = __shfl_down(gs[0], 1);
             const double y0n = __shfl_down(ys[0], 1);
-            ra = -il[B - 1] * ps[NB - 1];
-            rb = im[B - 1] - il[B - 1] * gs[NB - 1] - iu[B - 1] * p0n;
+            ra = -il_last * ps[NB - 1];
+            rb = im_last - il_last * gs[NB - 1] - iu[B - 1] * p0n;
             rcc = -iu[B - 1] * g0n;
-            rf = d[B - 1] - il[B - 1] * ys[NB - 1] - iu[B - 1] * y0n;
+            rf = d_last - il_last * ys[NB - 1] - iu[B - 1] * y0n;
         } else {
-            ra = il[0];
-            rb = im[0];
+            ra = il_last;
+            rb = im_last;
             rcc = iu[0];
-            rf = d[0];
+            rf = d_last;
         }
         // ---- parallel cyclic reduction over the 64 interface unknowns (normalised rows) -----------
         {
@@ -300,21 +350,6 @@ __global__ void __launch_bounds__(64) hadi_pass_a(HadiSweepArgs a, int n) {
         }
         hadi_store_row<B>(Yb + (size_t)j * rowp, lane, yo);
         if (lane == 0) Yb[(size_t)j * rowp + c0slot] = yout_c0;
-
-        // ---- roll the window ---------------------------------------------------------------------
-#pragma unroll
-        for (int r = 0; r < B; r++) {
-            um2[r] = um1[r];
-            um1[r] = u0[r];
-            u0[r] = up1[r];
-            up1[r] = up2[r];
-            up2[r] = nxt[r];
-            sbm[r] = sb0[r];
-            sb0[r] = sbp[r];
-        }
-        cm2 = cm1; cm1 = c0; c0 = cp1; cp1 = cp2; cp2 = cnxt;
-        eL0 = eLp; eR0 = eRp;
-        if (j + 1 < j1) hadi_sderiv<B>(up1, cp1, lane, Bm, Bz, Bp, sbp, eLp, eRp);
     }
 }
 
@@ -513,7 +548,7 @@ __global__ void __launch_bounds__(256) hadi_setup_kernel(HadiSetupArgs s) {
     in.r_d = s.r_d; in.r_f = s.r_f; in.theta = s.theta;
     HadiTables t;
     const int n4 = 4 * L.P;
-    t.scoef = s.scoef + (size_t)inst * 6 * 64 * L.B;
+    t.scoef = s.scoef + (size_t)inst * 4 * 64 * L.B;
     t.b2row = s.b2row + (size_t)inst * L.rowp;
     t.rowc = s.rowc + (size_t)inst * L.nrows * HADI_RC;
     t.a2i = s.a2i + (size_t)inst * 5 * L.nrows_pad;

@@ -4,8 +4,10 @@
 
 struct HadiPlan {
     HadiLayout L;
-    int R, ntiles;       // pass A: v-rows per wavefront, wavefront tiles per instance
-    int grid_a;          // pass A grid (64-thread blocks), padded to a multiple of 8 for the XCD remap
+    int W;               // pass A: wavefronts per block = v-rows solved concurrently by one block
+    int R, ntiles;       // pass A: v-rows per block tile, tiles per instance
+    int grid_a;          // pass A grid (64*W-thread blocks), padded to a multiple of 8 for the XCD remap
+    size_t smem_a;       // pass A dynamic LDS bytes: ring of 2W+4 rows
     int ctiles;          // pass B: 64-column tiles per instance
     int btpw, bgroups;   // pass B: column tiles per block (register double-buffered), blocks per instance
     int grid_b, block_b; // pass B grid / block (P*64 threads)
@@ -29,17 +31,22 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
     if (L.P > HADI_MAX_P) return 1;
     L.nrows_pad = L.P * HADI_LC;
     L.inst_stride = (long long)L.rowp * L.nrows_pad;
-    // Row tiles: as tall as possible (halo re-reads cost 4/R) while the launch still has
-    // >= target_waves wavefronts (256 CUs x 4 SIMDs x a few waves).
-    int ntiles = (target_waves + n_inst - 1) / n_inst;
+    // Row tiles: as tall as possible (halo re-reads cost 4/R) while the launch still has about three
+    // blocks per CU (target_waves = 8 per CU), a multiple of W rows each.
+    p.W = 4;
+    const int W = p.W;
+    int ntiles = ((3 * target_waves) / 8 + n_inst - 1) / n_inst;
     if (ntiles < 1) ntiles = 1;
     int R = (L.nrows + ntiles - 1) / ntiles;
-    if (R < 2) R = 2;
-    if (R > 40) R = 40;
+    R = (R + W - 1) / W * W;
+    if (R < W) R = W;
+    if (R > 64) R = 64;
     ntiles = (L.nrows + R - 1) / R;
-    R = (L.nrows + ntiles - 1) / ntiles;  // balance
+    R = ((L.nrows + ntiles - 1) / ntiles + W - 1) / W * W;  // balance
+    ntiles = (L.nrows + R - 1) / R;
     p.R = R;
     p.ntiles = ntiles;
+    p.smem_a = (size_t)(2 * W + 4) * L.rowp * sizeof(double);
     const long long total = (long long)n_inst * ntiles;
     p.grid_a = (int)((total + 7) / 8 * 8);
     p.ctiles = (L.rowp + 63) / 64;
@@ -57,7 +64,7 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
     p.block_b = 64 * L.P;
     p.smem_b = (size_t)L.P * (2 * 4 * 64 + HADI_LC * HADI_PBW) * sizeof(double);
     p.pos_m1 = hadi_pos(L.B, m1);
-    p.n_scoef = (size_t)6 * 64 * L.B;
+    p.n_scoef = (size_t)4 * 64 * L.B;
     p.n_b2row = (size_t)L.rowp;
     p.n_rowc = (size_t)L.nrows * HADI_RC;
     p.n_a2i = (size_t)5 * L.nrows_pad;

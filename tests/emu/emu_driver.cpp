@@ -14,7 +14,7 @@ thread_local int t_lane;
 
 template <int B>
 static void run_pass_a(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
-    emu::launch(pl.grid_a, 64, [&]() { hadi_pass_a<B>(a, n); });
+    emu::launch(pl.grid_a, 64 * pl.W, [&]() { hadi_pass_a<B, 4>(a, n); }, pl.smem_a);
 }
 
 extern "C" int emu_plan(int m1, int m2, int n_inst, int target_waves, int *out /*B,rowp,P,R,ntiles,ctiles*/) {
@@ -35,7 +35,7 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
     const HadiLayout &L = pl.L;
     const int american = variant & 1, dividend = (variant >> 1) & 1;
     const size_t st = (size_t)L.inst_stride * n_inst;
-    std::vector<double> dU(st), dY(st), dLAM(american ? st : 0), dU0(american ? st : 0), dUT(dividend ? st : 0);
+    std::vector<double> dU(st), dY(st, 0.0), dLAM(american ? st : 0), dU0(american ? st : 0), dUT(dividend ? st : 0);
     std::vector<double> scoef(pl.n_scoef * n_inst), b2row(pl.n_b2row * n_inst), rowc(pl.n_rowc * n_inst),
         a2i(pl.n_a2i * n_inst), pb(pl.n_pb * n_inst), rinv(pl.n_rinv * n_inst), rwork(pl.n_rwork * n_inst);
     std::vector<HadiInstPar> ipar(n_inst);

@@ -83,7 +83,7 @@ def test_setup_tables_against_oracle_operators(emu):
     assert emu.emu_plan(m1, m2, 1, 8, plan) == 0
     B, rowp, Pn = plan[0], plan[1], plan[2]
     nrows = m2 + 1
-    scoef, b2row = np.zeros(6 * 64 * B), np.zeros(rowp)
+    scoef, b2row = np.zeros(4 * 64 * B), np.zeros(rowp)
     npad = Pn * 33  # HADI_LC rows per column-pass chunk
     rowc, a2i, pb, rinv = np.zeros(nrows * 16), np.zeros(5 * npad), np.zeros(npad * 12), np.zeros(16 * Pn * Pn)
     rc = emu.emu_tables(m1, m2, N, C.c_double(Cm.T / N), C.c_double(Cm.THETA), C.c_double(Cm.R_D), C.c_double(0.0),
@@ -102,14 +102,14 @@ def test_setup_tables_against_oracle_operators(emu):
         lane, r = divmod(e, B)
         return (r >> 1) * 128 + 2 * lane + (r & 1)
 
-    sc = scoef.reshape(6, 64 * B)
+    sc = scoef.reshape(4, 64 * B)  # Bm, Bp, Dm, Dp; centre weights are -(m + p)
     Ug = U.reshape(m2 + 1, m1 + 1)
     A0 = np.zeros_like(Ug); A1 = np.zeros_like(Ug); A2 = np.zeros_like(Ug)
     for j in range(m2 + 1):
         v = rowc[j, 0]
         for i in range(1, m1 + 1):
-            Bk = [sc[k, pos(i)] for k in range(3)]
-            Dk = [sc[3 + k, pos(i)] for k in range(3)]
+            Bk = [sc[0, pos(i)], -(sc[0, pos(i)] + sc[1, pos(i)]), sc[1, pos(i)]]
+            Dk = [sc[2, pos(i)], -(sc[2, pos(i)] + sc[3, pos(i)]), sc[3, pos(i)]]
             nb = lambda jj: [Ug[jj, i - 1], Ug[jj, i], Ug[jj, i + 1] if i + 1 <= m1 else 0.0]
             lo, mn, up = [v * Dk[k] + (Cm.R_D - Cm.R_F) * Bk[k] for k in range(3)]
             mn -= 0.5 * Cm.R_D
