@@ -124,7 +124,8 @@ struct SweepDesc {
 
 template <int B>
 void launch_pass_a(const HadiPlan &pl, const HadiSweepArgs &a, int n, hipStream_t s) {
-    hipLaunchKernelGGL((hadi_pass_a<B, 4>), dim3(pl.grid_a), dim3(64 * pl.W), pl.smem_a, s, a, n);
+    if (a.american) hipLaunchKernelGGL((hadi_pass_a<B, 4, true>), dim3(pl.grid_a), dim3(64 * pl.W), pl.smem_a, s, a, n);
+    else hipLaunchKernelGGL((hadi_pass_a<B, 4, false>), dim3(pl.grid_a), dim3(64 * pl.W), pl.smem_a, s, a, n);
 }
 
 // Kernels whose dynamic LDS can exceed the 64 KiB default need the limit raised once.
@@ -134,11 +135,16 @@ hipError_t raise_lds_limit(K kernel) {
 }
 hipError_t raise_all_lds_limits() {
     hipError_t e;
-    if ((e = raise_lds_limit(hadi_pass_a<1, 4>)) != hipSuccess) return e;
-    if ((e = raise_lds_limit(hadi_pass_a<2, 4>)) != hipSuccess) return e;
-    if ((e = raise_lds_limit(hadi_pass_a<4, 4>)) != hipSuccess) return e;
-    if ((e = raise_lds_limit(hadi_pass_a<8, 4>)) != hipSuccess) return e;
-    if ((e = raise_lds_limit(hadi_pass_a<16, 4>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<1, 4, false>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<1, 4, true>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<2, 4, false>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<2, 4, true>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<4, 4, false>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<4, 4, true>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<8, 4, false>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<8, 4, true>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<16, 4, false>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<16, 4, true>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b<8>)) != hipSuccess) return e;
     return raise_lds_limit(hadi_pass_b<16>);
 }

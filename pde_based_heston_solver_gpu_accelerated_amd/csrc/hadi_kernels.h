@@ -127,8 +127,195 @@ HADI_DEV HADI_FORCEINLINE void hadi_lds_row(const double *lrow, int lane, double
 // pass A.  Block = W wavefronts working on W consecutive v-rows of one instance at a time; the rows
 // j-2 .. j+W+1 they need (9-point A0, 5-point A2) sit in an LDS ring of 2W+4 rows that is refilled by
 // LDS-DMA one iteration ahead, so HBM latency hides behind the line solves.  Lane l owns the s-nodes
-// i = 1+B*l .. B*l+B of its wave's row.
-template <int B, int W>
+// i = 1+B*l .. B*l+B of its wave's row.  The s-direction coefficient arrays live in LDS too (shared
+// by the block's waves), which keeps the kernel at two wavefronts per SIMD without spills.
+struct HadiRowCtx {
+    const double *coef;  // LDS: Bm, Bp, Dm, Dp, each 64*B doubles in row layout
+    double *Yi;          // instance base of Y
+    const double *Li;    // instance base of lambda_bar (American)
+    const double *rowc;  // instance base of the row table
+    const double *b2r;   // instance b2 row (global)
+    int lane, posL, posR, rowp;
+    double dt, thdt, qd, half_rd, e_nm1, e_n;
+};
+
+// One v-row: explicit stage, Y0, A1 line solve, A2 right-hand side.  LAST = this is the v-row that
+// carries b2 (hes_boundary_kernels.hpp:62-66); AMER adds lambda_bar (device_solver.hpp:325-331).
+template <int B, bool AMER, bool LAST>
+HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtx &c, int j, const double *rm2, const double *rm1,
+                                             const double *r0, const double *rp1, const double *rp2) {
+    const int lane = c.lane, rowp = c.rowp;
+    constexpr int c0slot = 64 * B;
+    const double dt = c.dt, thdt = c.thdt, qd = c.qd, half_rd = c.half_rd, e_nm1 = c.e_nm1, e_n = c.e_n;
+    const double *__restrict__ rc = c.rowc + (size_t)j * HADI_RC;
+    const double v = rc[RC_V];
+    const double wm = rc[RC_WM], wz = rc[RC_WZ], wp = rc[RC_WP];
+    const double a2l2 = rc[RC_L2], a2l1 = rc[RC_L1], a2m = rc[RC_M], a2u1 = rc[RC_U1], a2u2 = rc[RC_U2];
+    const double b1val = rc[RC_B1VAL];
+    const int b1col = (int)rc[RC_B1COL];
+    const int b1e = b1col - 1;
+    const int b1lane = (b1col >= 1) ? b1e / B : -1;
+    const int b1r = (b1col >= 1) ? b1e - b1lane * B : -1;
+
+    // ---- column i = 0 (A0 and A1 rows are zero there; only A2 and the boundary act) ------------
+    const double c0 = r0[c0slot];
+    const double a2c0 = a2l2 * rm2[c0slot] + a2l1 * rm1[c0slot] + a2m * c0 + a2u1 * rp1[c0slot] + a2u2 * rp2[c0slot];
+    const double b1c0 = (b1col == 0) ? b1val : 0.0;
+    const double b2c0 = LAST ? c.b2r[c0slot] : 0.0;
+    const double lamc0 = AMER ? c.Li[(size_t)j * rowp + c0slot] : 0.0;
+    double y0c0 = c0 + dt * (a2c0 + (b1c0 + b2c0) * e_nm1 + lamc0);
+    y0c0 = y0c0 + thdt * (b1c0 * e_n - (0.0 + b1c0 * e_nm1));
+    const double x0 = y0c0;  // A1 row 0 is the identity (hes_a1_kernels.hpp:56-61)
+    const double yout_c0 = x0 + thdt * (b2c0 * e_n - (a2c0 + b2c0 * e_nm1));
+
+    // ---- explicit operators.  A0 = (s-derivative) o (v-derivative): first the v-combination
+    // t = wm u(j-1) + wz u(j) + wp u(j+1) on the block and its two s-neighbours, then the B-weights.
+    double u0[B], tt[B], A2U[B];
+    {
+        double um[B], up[B], u2[B];
+        hadi_lds_row<B>(r0, lane, u0);
+        hadi_lds_row<B>(rm1, lane, um);
+        hadi_lds_row<B>(rp1, lane, up);
+#pragma unroll
+        for (int r = 0; r < B; r++) {
+            tt[r] = wm * um[r] + wz * u0[r] + wp * up[r];
+            A2U[r] = a2l1 * um[r] + a2m * u0[r] + a2u1 * up[r];
+        }
+        hadi_lds_row<B>(rm2, lane, u2);
+#pragma unroll
+        for (int r = 0; r < B; r++) A2U[r] = fma(a2l2, u2[r], A2U[r]);
+        hadi_lds_row<B>(rp2, lane, u2);
+#pragma unroll
+        for (int r = 0; r < B; r++) A2U[r] = fma(a2u2, u2[r], A2U[r]);
+    }
+    const double u0L = r0[c.posL], u0R = r0[c.posR];
+    const double tL = wm * rm1[c.posL] + wz * u0L + wp * rp1[c.posL];
+    const double tR = wm * rm1[c.posR] + wz * u0R + wp * rp1[c.posR];
+
+    double lam[B], b2v[B];
+    if constexpr (AMER) hadi_load_row<B>(c.Li + (size_t)j * rowp, lane, true, lam);
+    if constexpr (LAST) hadi_load_row<B>(c.b2r, lane, true, b2v);
+
+    // ---- Y0 (device_solver.hpp:236-250) fused with the forward sweep of the in-lane Thomas ----------
+    //   x[r] = ys[r] - XL*ps[r] - X*gs[r],  XL = interface unknown of lane-1, X = own x[B-1]
+    // The central FD weights follow from sum_k beta_s = sum_k delta_s = 0: B0 = -(Bm+Bp), D0 = -(Dm+Dp).
+    constexpr int NB = B - 1;
+    double Bm[B], Bp[B], Dm[B], Dp[B];
+    hadi_lds_row<B>(c.coef + 0 * 64 * B, lane, Bm);
+    hadi_lds_row<B>(c.coef + 1 * 64 * B, lane, Bp);
+    hadi_lds_row<B>(c.coef + 2 * 64 * B, lane, Dm);
+    hadi_lds_row<B>(c.coef + 3 * 64 * B, lane, Dp);
+    double ys[B], ps[B], iu[B], invt[B];
+    double il_last = 0.0, im_last = 1.0, d_last = 0.0;
+#pragma unroll
+    for (int r = 0; r < B; r++) {
+        const double uL = (r == 0) ? u0L : u0[r == 0 ? 0 : r - 1];
+        const double uR = (r == B - 1) ? u0R : u0[r == B - 1 ? r : r + 1];
+        const double tl = (r == 0) ? tL : tt[r == 0 ? 0 : r - 1];
+        const double tr = (r == B - 1) ? tR : tt[r == B - 1 ? r : r + 1];
+        const double lo = fma(v, Dm[r], qd * Bm[r]);
+        const double up = fma(v, Dp[r], qd * Bp[r]);
+        const double mn = -(fma(v, Dm[r] + Dp[r], qd * (Bm[r] + Bp[r])) + half_rd);
+        const double A1U = lo * uL + mn * u0[r] + up * uR;
+        const double A0U = Bm[r] * tl - (Bm[r] + Bp[r]) * tt[r] + Bp[r] * tr;
+        const double b1h = (lane == b1lane && r == b1r) ? b1val : 0.0;
+        double S = A0U + A1U + A2U[r];
+        if constexpr (LAST) S += (b1h + b2v[r]) * e_nm1;
+        else S += b1h * e_nm1;
+        if constexpr (AMER) S += lam[r];
+        double y = u0[r] + dt * S;
+        y = y + thdt * (b1h * e_n - (A1U + b1h * e_nm1));
+        double il = -thdt * lo;
+        const double im = 1.0 - thdt * mn;
+        iu[r] = -thdt * up;
+        if (r == 0 && lane == 0) {  // x_0 is known: move it to the right-hand side
+            y -= il * x0;
+            il = 0.0;
+        }
+        if (r < NB) {
+            if (r == 0) {
+                invt[0] = hadi_rcp(im);
+                ys[0] = y;
+                ps[0] = il;
+            } else {
+                const double w = il * invt[r - 1];
+                invt[r] = hadi_rcp(fma(-w, iu[r - 1], im));
+                ys[r] = fma(-w, ys[r - 1], y);
+                ps[r] = -w * ps[r - 1];
+            }
+        } else {
+            il_last = il;
+            im_last = im;
+            d_last = y;
+        }
+    }
+    double gs[B];
+    double ra, rb, rcc, rf;
+    if constexpr (NB > 0) {
+        gs[NB - 1] = iu[NB - 1] * invt[NB - 1];
+        ys[NB - 1] *= invt[NB - 1];
+        ps[NB - 1] *= invt[NB - 1];
+#pragma unroll
+        for (int r = NB - 2; r >= 0; r--) {
+            ys[r] = fma(-iu[r], ys[r + 1], ys[r]) * invt[r];
+            ps[r] = fma(-iu[r], ps[r + 1], ps[r]) * invt[r];
+            gs[r] = -iu[r] * gs[r + 1] * invt[r];
+        }
+        // interface row of this lane couples to XL, X and the next lane's X
+        const double p0n = __shfl_down(ps[0], 1);
+        const double g0n = __shfl_down(gs[0], 1);
+        const double y0n = __shfl_down(ys[0], 1);
+        ra = -il_last * ps[NB - 1];
+        rb = im_last - il_last * gs[NB - 1] - iu[B - 1] * p0n;
+        rcc = -iu[B - 1] * g0n;
+        rf = d_last - il_last * ys[NB - 1] - iu[B - 1] * y0n;
+    } else {
+        ra = il_last;
+        rb = im_last;
+        rcc = iu[0];
+        rf = d_last;
+    }
+    // ---- parallel cyclic reduction over the 64 interface unknowns (normalised rows) -------------
+    {
+        const double rinv0 = hadi_rcp(rb);
+        ra *= rinv0;
+        rcc *= rinv0;
+        rf *= rinv0;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const double aL = __shfl_up(ra, s), cL = __shfl_up(rcc, s), fL = __shfl_up(rf, s);
+            const double aR = __shfl_down(ra, s), cR = __shfl_down(rcc, s), fR = __shfl_down(rf, s);
+            // lanes without a partner at distance s have ra == 0 (left) / rcc == 0 (right), so
+            // the wrapped values they fetch are multiplied by zero
+            const double bn = 1.0 - ra * cL - rcc * aR;
+            const double rn = hadi_rcp(bn);
+            const double fn = (rf - ra * fL - rcc * fR) * rn;
+            const double an = (lane >= s) ? (-ra * aL) * rn : 0.0;
+            const double cn = (lane + s < 64) ? (-rcc * cR) * rn : 0.0;
+            ra = an;
+            rcc = cn;
+            rf = fn;
+        }
+    }
+    const double X = rf;
+    double XL = __shfl_up(X, 1);
+    if (lane == 0) XL = 0.0;
+
+    // ---- Y1 -> right-hand side of the A2 solve (device_solver.hpp:254-260) and store ----------
+    double yo[B];
+#pragma unroll
+    for (int r = 0; r < B; r++) {
+        double x;
+        if (r < NB) x = ys[r] - XL * ps[r] - X * gs[r];
+        else x = X;
+        if constexpr (LAST) yo[r] = x + thdt * (b2v[r] * e_n - (A2U[r] + b2v[r] * e_nm1));
+        else yo[r] = x - thdt * A2U[r];
+    }
+    hadi_store_row<B>(c.Yi + (size_t)j * rowp, lane, yo);
+    if (lane == 0) c.Yi[(size_t)j * rowp + c0slot] = yout_c0;
+}
+
+template <int B, int W, bool AMER>
 __global__ void __launch_bounds__(64 * W, (B >= 16 ? 1 : 2)) hadi_pass_a(HadiSweepArgs a, int n) {
     HADI_DYN_SMEM(double, smem);
     constexpr int RING = 2 * W + 4;
@@ -145,35 +332,35 @@ __global__ void __launch_bounds__(64 * W, (B >= 16 ? 1 : 2)) hadi_pass_a(HadiSwe
     const int j1 = (j0 + a.R < nrows) ? j0 + a.R : nrows;
     if (j0 >= j1) return;
 
-    const double dt = ip.dt, thdt = ip.thdt, qd = ip.q, half_rd = ip.half_rd;
-    const double e_nm1 = exp(ip.r_f * dt * (n - 1));  // device_solver.hpp:238
-    const double e_n = exp(ip.r_f * dt * n);          // device_solver.hpp:246
-
+    HadiRowCtx c;
+    c.lane = lane;
+    c.rowp = rowp;
+    c.dt = ip.dt; c.thdt = ip.thdt; c.qd = ip.q; c.half_rd = ip.half_rd;
+    c.e_nm1 = exp(ip.r_f * ip.dt * (n - 1));  // device_solver.hpp:238
+    c.e_n = exp(ip.r_f * ip.dt * n);          // device_solver.hpp:246
     const double *__restrict__ Ub = a.U + (size_t)inst * a.L.inst_stride;
-    double *__restrict__ Yb = a.Y + (size_t)inst * a.L.inst_stride;
-    const double *__restrict__ Lb = a.american ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
-    const double *__restrict__ rowc = a.rowc + (size_t)inst * nrows * HADI_RC;
-    const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B;
-    const double *__restrict__ b2r = a.b2row + (size_t)inst * rowp;
-    const int c0slot = 64 * B;
+    c.Yi = a.Y + (size_t)inst * a.L.inst_stride;
+    c.Li = AMER ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
+    c.rowc = a.rowc + (size_t)inst * nrows * HADI_RC;
+    c.b2r = a.b2row + (size_t)inst * rowp;
+    constexpr int c0slot = 64 * B;
     // positions of the s-neighbours of this lane's block: i-1 of its first node, i+1 of its last node.
     // Lane 0's left neighbour is the i = 0 slot; lane 63's right neighbour is a pad slot (always 0).
-    int posL, posR;
     if constexpr (B == 1) {
-        posL = lane == 0 ? c0slot : lane - 1;
-        posR = lane == 63 ? c0slot + 1 : lane + 1;
+        c.posL = lane == 0 ? c0slot : lane - 1;
+        c.posR = lane == 63 ? c0slot + 1 : lane + 1;
     } else {
-        posL = lane == 0 ? c0slot : (B / 2 - 1) * 128 + 2 * lane - 1;
-        posR = lane == 63 ? c0slot + 1 : 2 * lane + 2;
+        c.posL = lane == 0 ? c0slot : (B / 2 - 1) * 128 + 2 * lane - 1;
+        c.posR = lane == 63 ? c0slot + 1 : 2 * lane + 2;
     }
 
-    // j- and time-invariant s-coefficients of this lane's B nodes.  The central weights follow from
-    // sum_k beta_s(.,k) = sum_k delta_s(.,k) = 0:  B0 = -(Bm + Bp), D0 = -(Dm + Dp).
-    double Bm[B], Bp[B], Dm[B], Dp[B];
-    hadi_load_row<B>(sc + 0 * 64 * B, lane, true, Bm);
-    hadi_load_row<B>(sc + 1 * 64 * B, lane, true, Bp);
-    hadi_load_row<B>(sc + 2 * 64 * B, lane, true, Dm);
-    hadi_load_row<B>(sc + 3 * 64 * B, lane, true, Dp);
+    // LDS: [RING rows of rowp] [4 coefficient arrays of 64*B]
+    double *coef = smem + (size_t)RING * rowp;
+    {
+        const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B;
+        for (int e = threadIdx.x; e < 4 * 64 * B; e += 64 * W) coef[e] = sc[e];
+    }
+    c.coef = coef;
 
     auto slot = [&](int jj) { return smem + (size_t)((jj + RING) % RING) * rowp; };
     auto fetch = [&](int jj) { hadi_row_to_lds(Ub + (size_t)jj * rowp, slot(jj), rowp, lane, jj >= 0 && jj < npad); };
@@ -186,170 +373,10 @@ __global__ void __launch_bounds__(64 * W, (B >= 16 ? 1 : 2)) hadi_pass_a(HadiSwe
         if (it + 1 < iters) fetch(J + W + 2 + wave);
         const int j = J + wave;
         if (j >= j1) continue;
-
-        const double *rm2 = slot(j - 2), *rm1 = slot(j - 1), *r0 = slot(j), *rp1 = slot(j + 1), *rp2 = slot(j + 2);
-        const double *__restrict__ rc = rowc + (size_t)j * HADI_RC;
-        const double v = rc[RC_V];
-        const double wm = rc[RC_WM], wz = rc[RC_WZ], wp = rc[RC_WP];
-        const double a2l2 = rc[RC_L2], a2l1 = rc[RC_L1], a2m = rc[RC_M], a2u1 = rc[RC_U1], a2u2 = rc[RC_U2];
-        const double b1val = rc[RC_B1VAL];
-        const int b1col = (int)rc[RC_B1COL];
-        const bool last = rc[RC_LAST] != 0.0;
-        const int b1e = b1col - 1;
-        const int b1lane = (b1col >= 1) ? b1e / B : -1;
-        const int b1r = (b1col >= 1) ? b1e - b1lane * B : -1;
-
-        double lam[B];
-        double lamc0 = 0.0;
-        if (a.american) {
-            hadi_load_row<B>(Lb + (size_t)j * rowp, lane, true, lam);
-            lamc0 = Lb[(size_t)j * rowp + c0slot];
-        }
-        double b2v[B];
-        hadi_load_row<B>(b2r, lane, last, b2v);
-
-        // ---- column i = 0 (A0 and A1 rows are zero there; only A2 and the boundary act) --------
-        const double c0 = r0[c0slot];
-        const double a2c0 = a2l2 * rm2[c0slot] + a2l1 * rm1[c0slot] + a2m * c0 + a2u1 * rp1[c0slot] + a2u2 * rp2[c0slot];
-        const double b1c0 = (b1col == 0) ? b1val : 0.0;
-        const double b2c0 = last ? b2r[c0slot] : 0.0;
-        double y0c0 = c0 + dt * (a2c0 + (b1c0 + b2c0) * e_nm1 + lamc0);
-        y0c0 = y0c0 + thdt * (b1c0 * e_n - (0.0 + b1c0 * e_nm1));
-        const double x0 = y0c0;  // A1 row 0 is the identity (hes_a1_kernels.hpp:56-61)
-        const double yout_c0 = x0 + thdt * (b2c0 * e_n - (a2c0 + b2c0 * e_nm1));
-
-        // ---- explicit operators.  A0 = (s-derivative) o (v-derivative): first the v-combination
-        // t = wm u(j-1) + wz u(j) + wp u(j+1) on the block and its two s-neighbours, then B-weights.
-        double u0[B], tt[B], A2U[B];
-        {
-            double um[B], up[B], u2[B];
-            hadi_lds_row<B>(r0, lane, u0);
-            hadi_lds_row<B>(rm1, lane, um);
-            hadi_lds_row<B>(rp1, lane, up);
-#pragma unroll
-            for (int r = 0; r < B; r++) {
-                tt[r] = wm * um[r] + wz * u0[r] + wp * up[r];
-                A2U[r] = a2l1 * um[r] + a2m * u0[r] + a2u1 * up[r];
-            }
-            hadi_lds_row<B>(rm2, lane, u2);
-#pragma unroll
-            for (int r = 0; r < B; r++) A2U[r] = fma(a2l2, u2[r], A2U[r]);
-            hadi_lds_row<B>(rp2, lane, u2);
-#pragma unroll
-            for (int r = 0; r < B; r++) A2U[r] = fma(a2u2, u2[r], A2U[r]);
-        }
-        const double u0L = r0[posL], u0R = r0[posR];
-        const double tL = wm * rm1[posL] + wz * u0L + wp * rp1[posL];
-        const double tR = wm * rm1[posR] + wz * u0R + wp * rp1[posR];
-
-        // ---- Y0 (device_solver.hpp:236-250) fused with the forward sweep of the in-lane Thomas --------
-        //   x[r] = ys[r] - XL*ps[r] - X*gs[r],  XL = interface unknown of lane-1, X = own x[B-1]
-        constexpr int NB = B - 1;
-        double ys[B], ps[B], iu[B], invt[B];
-        double il_last = 0.0, im_last = 1.0, d_last = 0.0;
-#pragma unroll
-        for (int r = 0; r < B; r++) {
-            const double uL = (r == 0) ? u0L : u0[r == 0 ? 0 : r - 1];
-            const double uR = (r == B - 1) ? u0R : u0[r == B - 1 ? r : r + 1];
-            const double tl = (r == 0) ? tL : tt[r == 0 ? 0 : r - 1];
-            const double tr = (r == B - 1) ? tR : tt[r == B - 1 ? r : r + 1];
-            const double lo = fma(v, Dm[r], qd * Bm[r]);
-            const double up = fma(v, Dp[r], qd * Bp[r]);
-            const double mn = -(fma(v, Dm[r] + Dp[r], qd * (Bm[r] + Bp[r])) + half_rd);
-            const double A1U = lo * uL + mn * u0[r] + up * uR;
-            const double A0U = Bm[r] * tl - (Bm[r] + Bp[r]) * tt[r] + Bp[r] * tr;
-            const double b1h = (lane == b1lane && r == b1r) ? b1val : 0.0;
-            double S = A0U + A1U + A2U[r] + (b1h + b2v[r]) * e_nm1;
-            if (a.american) S += lam[r];
-            double y = u0[r] + dt * S;
-            y = y + thdt * (b1h * e_n - (A1U + b1h * e_nm1));
-            double il = -thdt * lo;
-            const double im = 1.0 - thdt * mn;
-            iu[r] = -thdt * up;
-            if (r == 0 && lane == 0) {  // x_0 is known: move it to the right-hand side
-                y -= il * x0;
-                il = 0.0;
-            }
-            if (r < NB) {
-                if (r == 0) {
-                    invt[0] = hadi_rcp(im);
-                    ys[0] = y;
-                    ps[0] = il;
-                } else {
-                    const double w = il * invt[r - 1];
-                    invt[r] = hadi_rcp(fma(-w, iu[r - 1], im));
-                    ys[r] = fma(-w, ys[r - 1], y);
-                    ps[r] = -w * ps[r - 1];
-                }
-            } else {
-                il_last = il;
-                im_last = im;
-                d_last = y;
-            }
-        }
-        double gs[B];
-        double ra, rb, rcc, rf;
-        if constexpr (NB > 0) {
-            gs[NB - 1] = iu[NB - 1] * invt[NB - 1];
-            ys[NB - 1] *= invt[NB - 1];
-            ps[NB - 1] *= invt[NB - 1];
-#pragma unroll
-            for (int r = NB - 2; r >= 0; r--) {
-                ys[r] = fma(-iu[r], ys[r + 1], ys[r]) * invt[r];
-                ps[r] = fma(-iu[r], ps[r + 1], ps[r]) * invt[r];
-                gs[r] = -iu[r] * gs[r + 1] * invt[r];
-            }
-            // interface row of this lane couples to XL, X and the next lane's X
-            const double p0n = __shfl_down(ps[0], 1);
-            const double g0n = __shfl_down(gs[0], 1);
-            const double y0n = __shfl_down(ys[0], 1);
-            ra = -il_last * ps[NB - 1];
-            rb = im_last - il_last * gs[NB - 1] - iu[B - 1] * p0n;
-            rcc = -iu[B - 1] * g0n;
-            rf = d_last - il_last * ys[NB - 1] - iu[B - 1] * y0n;
-        } else {
-            ra = il_last;
-            rb = im_last;
-            rcc = iu[0];
-            rf = d_last;
-        }
-        // ---- parallel cyclic reduction over the 64 interface unknowns (normalised rows) -----------
-        {
-            const double rinv0 = hadi_rcp(rb);
-            ra *= rinv0;
-            rcc *= rinv0;
-            rf *= rinv0;
-#pragma unroll
-            for (int s = 1; s < 64; s <<= 1) {
-                const double aL = __shfl_up(ra, s), cL = __shfl_up(rcc, s), fL = __shfl_up(rf, s);
-                const double aR = __shfl_down(ra, s), cR = __shfl_down(rcc, s), fR = __shfl_down(rf, s);
-                // lanes without a partner at distance s have ra == 0 (left) / rcc == 0 (right), so
-                // the wrapped values they fetch are multiplied by zero
-                const double bn = 1.0 - ra * cL - rcc * aR;
-                const double rn = hadi_rcp(bn);
-                const double fn = (rf - ra * fL - rcc * fR) * rn;
-                const double an = (lane >= s) ? (-ra * aL) * rn : 0.0;
-                const double cn = (lane + s < 64) ? (-rcc * cR) * rn : 0.0;
-                ra = an;
-                rcc = cn;
-                rf = fn;
-            }
-        }
-        const double X = rf;
-        double XL = __shfl_up(X, 1);
-        if (lane == 0) XL = 0.0;
-
-        // ---- Y1 -> right-hand side of the A2 solve (device_solver.hpp:254-260) and store --------
-        double yo[B];
-#pragma unroll
-        for (int r = 0; r < B; r++) {
-            double x;
-            if (r < NB) x = ys[r] - XL * ps[r] - X * gs[r];
-            else x = X;
-            yo[r] = x + thdt * (b2v[r] * e_n - (A2U[r] + b2v[r] * e_nm1));
-        }
-        hadi_store_row<B>(Yb + (size_t)j * rowp, lane, yo);
-        if (lane == 0) Yb[(size_t)j * rowp + c0slot] = yout_c0;
+        if (j == nrows - 1)
+            hadi_row_step<B, AMER, true>(c, j, slot(j - 2), slot(j - 1), slot(j), slot(j + 1), slot(j + 2));
+        else
+            hadi_row_step<B, AMER, false>(c, j, slot(j - 2), slot(j - 1), slot(j), slot(j + 1), slot(j + 2));
     }
 }
 

@@ -7,7 +7,7 @@ struct HadiPlan {
     int W;               // pass A: wavefronts per block = v-rows solved concurrently by one block
     int R, ntiles;       // pass A: v-rows per block tile, tiles per instance
     int grid_a;          // pass A grid (64*W-thread blocks), padded to a multiple of 8 for the XCD remap
-    size_t smem_a;       // pass A dynamic LDS bytes: ring of 2W+4 rows
+    size_t smem_a;       // pass A dynamic LDS bytes: ring of 2W+4 rows + the 4 s-coefficient arrays
     int ctiles;          // pass B: 64-column tiles per instance
     int btpw, bgroups;   // pass B: column tiles per block (register double-buffered), blocks per instance
     int grid_b, block_b; // pass B grid / block (P*64 threads)
@@ -46,7 +46,7 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
     ntiles = (L.nrows + R - 1) / R;
     p.R = R;
     p.ntiles = ntiles;
-    p.smem_a = (size_t)(2 * W + 4) * L.rowp * sizeof(double);
+    p.smem_a = ((size_t)(2 * W + 4) * L.rowp + (size_t)4 * 64 * L.B) * sizeof(double);
     const long long total = (long long)n_inst * ntiles;
     p.grid_a = (int)((total + 7) / 8 * 8);
     p.ctiles = (L.rowp + 63) / 64;

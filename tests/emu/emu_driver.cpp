@@ -14,7 +14,8 @@ thread_local int t_lane;
 
 template <int B>
 static void run_pass_a(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
-    emu::launch(pl.grid_a, 64 * pl.W, [&]() { hadi_pass_a<B, 4>(a, n); }, pl.smem_a);
+    if (a.american) emu::launch(pl.grid_a, 64 * pl.W, [&]() { hadi_pass_a<B, 4, true>(a, n); }, pl.smem_a);
+    else emu::launch(pl.grid_a, 64 * pl.W, [&]() { hadi_pass_a<B, 4, false>(a, n); }, pl.smem_a);
 }
 
 extern "C" int emu_plan(int m1, int m2, int n_inst, int target_waves, int *out /*B,rowp,P,R,ntiles,ctiles*/) {
