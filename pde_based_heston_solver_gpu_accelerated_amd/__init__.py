@@ -9,6 +9,9 @@ from ._native import EU, AM, DIV, AM_DIV, HadiError, LIB_PATH  # noqa: F401
 from .grid import Grid, GridViewsBatch  # noqa: F401
 from .solver import (HestonADI, DOWorkspace, Dividends, compute_parameter_update,  # noqa: F401
                      lm_partials, lm_solve)
+from .distributed import Communicator, shard_range  # noqa: F401
+from .calibration import calibrate_european, clamp_parameters  # noqa: F401
 
 __all__ = ["EU", "AM", "DIV", "AM_DIV", "HadiError", "Grid", "GridViewsBatch", "HestonADI", "DOWorkspace",
-           "Dividends", "compute_parameter_update", "lm_partials", "lm_solve", "LIB_PATH"]
+           "Dividends", "compute_parameter_update", "lm_partials", "lm_solve", "LIB_PATH", "Communicator",
+           "shard_range", "calibrate_european", "clamp_parameters"]

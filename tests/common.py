@@ -32,3 +32,19 @@ def oracle_params(m1, m2, N, variant, r_f=R_F, rho=RHO, sigma=SIGMA, kappa=KAPPA
 
 def strikes_for(n):
     return [100.0] if n == 1 else [85.0 + 30.0 * k / (n - 1) for k in range(n)]
+
+
+class OracleSolver:
+    """Oracle-backed stand-in with the call signatures of HestonADI.compute_jacobian /
+    compute_base_prices -- TESTS ONLY (drives the host-side LM loop where no GPU is available and
+    serves as the reference trajectory on the GPU box)."""
+
+    def compute_jacobian(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
+                         delta_t, num_strikes, grids, U_0, eps=1e-6):
+        p = O.make_params(m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta)
+        return O.jacobian(p, S_0, V_0, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U_0, eps=eps)
+
+    def compute_base_prices(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
+                            delta_t, num_strikes, grids, ws):
+        p = O.make_params(m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta)
+        return O.base_prices(p, S_0, V_0, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, ws.U)[0]
