@@ -122,10 +122,12 @@ struct SweepDesc {
     const double *div_dates = nullptr, *div_amounts = nullptr, *div_pcts = nullptr;
 };
 
-template <int B>
+template <int B, int G>
 void launch_pass_a(const HadiPlan &pl, const HadiSweepArgs &a, int n, hipStream_t s) {
-    if (a.american) hipLaunchKernelGGL((hadi_pass_a<B, 4, true>), dim3(pl.grid_a), dim3(64 * pl.W), pl.smem_a, s, a, n);
-    else hipLaunchKernelGGL((hadi_pass_a<B, 4, false>), dim3(pl.grid_a), dim3(64 * pl.W), pl.smem_a, s, a, n);
+    if (a.american)
+        hipLaunchKernelGGL((hadi_pass_a<B, G, 4, true>), dim3(pl.grid_a), dim3(64 * pl.W * G), pl.smem_a, s, a, n);
+    else
+        hipLaunchKernelGGL((hadi_pass_a<B, G, 4, false>), dim3(pl.grid_a), dim3(64 * pl.W * G), pl.smem_a, s, a, n);
 }
 
 // Kernels whose dynamic LDS can exceed the 64 KiB default need the limit raised once.
@@ -133,18 +135,18 @@ template <class K>
 hipError_t raise_lds_limit(K kernel) {
     return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
+template <int B, int G>
+hipError_t raise_pass_a() {
+    hipError_t e = raise_lds_limit(hadi_pass_a<B, G, 4, false>);
+    return e != hipSuccess ? e : raise_lds_limit(hadi_pass_a<B, G, 4, true>);
+}
 hipError_t raise_all_lds_limits() {
     hipError_t e;
-    if ((e = raise_lds_limit(hadi_pass_a<1, 4, false>)) != hipSuccess) return e;
-    if ((e = raise_lds_limit(hadi_pass_a<1, 4, true>)) != hipSuccess) return e;
-    if ((e = raise_lds_limit(hadi_pass_a<2, 4, false>)) != hipSuccess) return e;
-    if ((e = raise_lds_limit(hadi_pass_a<2, 4, true>)) != hipSuccess) return e;
-    if ((e = raise_lds_limit(hadi_pass_a<4, 4, false>)) != hipSuccess) return e;
-    if ((e = raise_lds_limit(hadi_pass_a<4, 4, true>)) != hipSuccess) return e;
-    if ((e = raise_lds_limit(hadi_pass_a<8, 4, false>)) != hipSuccess) return e;
-    if ((e = raise_lds_limit(hadi_pass_a<8, 4, true>)) != hipSuccess) return e;
-    if ((e = raise_lds_limit(hadi_pass_a<16, 4, false>)) != hipSuccess) return e;
-    if ((e = raise_lds_limit(hadi_pass_a<16, 4, true>)) != hipSuccess) return e;
+    if ((e = raise_pass_a<1, 1>()) != hipSuccess) return e;
+    if ((e = raise_pass_a<2, 1>()) != hipSuccess) return e;
+    if ((e = raise_pass_a<4, 1>()) != hipSuccess) return e;
+    if ((e = raise_pass_a<8, 1>()) != hipSuccess) return e;
+    if ((e = raise_pass_a<8, 2>()) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b<8>)) != hipSuccess) return e;
     return raise_lds_limit(hadi_pass_b<16>);
 }
@@ -237,12 +239,12 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
             if (cur < d.num_div && t > d.div_dates[cur]) cur++;
         }
         if (prof) HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 0], s));
-        switch (L.B) {
-            case 1: launch_pass_a<1>(pl, a, nstep, s); break;
-            case 2: launch_pass_a<2>(pl, a, nstep, s); break;
-            case 4: launch_pass_a<4>(pl, a, nstep, s); break;
-            case 8: launch_pass_a<8>(pl, a, nstep, s); break;
-            default: launch_pass_a<16>(pl, a, nstep, s); break;
+        switch (L.B * 10 + L.G) {
+            case 11: launch_pass_a<1, 1>(pl, a, nstep, s); break;
+            case 21: launch_pass_a<2, 1>(pl, a, nstep, s); break;
+            case 41: launch_pass_a<4, 1>(pl, a, nstep, s); break;
+            case 81: launch_pass_a<8, 1>(pl, a, nstep, s); break;
+            default: launch_pass_a<8, 2>(pl, a, nstep, s); break;
         }
         if (prof) {
             HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 1], s));

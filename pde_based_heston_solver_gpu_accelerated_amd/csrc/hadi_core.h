@@ -22,28 +22,47 @@ struct HadiLayout {
     int m1, m2, nrows;  // nrows = m2 + 1
     int nrows_pad;      // P * HADI_LC >= nrows: v-rows past nrows are identity rows (always 0) so that
                         // every column-pass wavefront owns exactly HADI_LC rows -- no tail branches
-    int B;              // grid points per lane in the row pass: i = 1 + B*lane + r
-    int rowp;           // row pitch in doubles: 64*B + 8 (slot 64*B holds i = 0, 7 zero pads)
+    int B;              // grid points per lane in the row pass
+    int G;              // wavefronts per v-row in the row pass: wave g owns i = 1 + 64*B*g + B*lane + r
+    int rowp;           // row pitch in doubles: 64*B*G + 8 (slot 64*B*G holds i = 0, 7 zero pads)
     int P;              // chunks per column in the column pass
     long long inst_stride;  // rowp * nrows_pad
 };
 
-// Storage position of s-index i inside a row.  Lane `l` of the row pass owns i = 1+B*l .. B*l+B
-// and fetches them as B/2 coalesced 16-byte loads: pair q of lane l sits at q*128 + 2*l.
-HADI_HD inline int hadi_pos(int B, int i) {
-    if (i == 0) return 64 * B;
+// Storage position of s-index i inside a row.  Lane l of wave g of the row pass owns the B nodes
+// i = 1 + 64*B*g + B*l .. and fetches them as B/2 coalesced 16-byte accesses: pair q of (g, l) sits at
+// q*128*G + 128*g + 2*l (one wave-instruction = 1 KiB contiguous).
+HADI_HD inline int hadi_pos(int B, int G, int i) {
+    if (i == 0) return 64 * B * G;
     const int e = i - 1;
-    if (B == 1) return e;
-    const int lane = e / B, r = e % B;
-    return (r >> 1) * 128 + 2 * lane + (r & 1);
+    const int g = e / (64 * B), el = e - g * 64 * B;
+    if (B == 1) return 64 * g + el;
+    const int lane = el / B, r = el % B;
+    return (r >> 1) * 128 * G + 128 * g + 2 * lane + (r & 1);
+}
+HADI_HD inline int hadi_pos(const HadiLayout &L, int i) { return hadi_pos(L.B, L.G, i); }
+
+// Inverse: s-index stored in `slot` (-1 for a pad slot).
+HADI_HD inline int hadi_slot_to_i(const HadiLayout &L, int slot) {
+    const int B = L.B, G = L.G, n = 64 * B * G;
+    if (slot == n) return 0;
+    if (slot > n) return -1;
+    if (B == 1) return slot + 1;  // slot = 64 g + lane = e
+    const int q = slot / (128 * G), rem = slot - q * 128 * G;
+    const int g = rem >> 7, rem2 = rem & 127, lane = rem2 >> 1, r = 2 * q + (rem2 & 1);
+    return 1 + 64 * B * g + B * lane + r;
 }
 
-HADI_HD inline int hadi_pick_B(int m1) {
-    int B = 1;
-    while (64 * B < m1) B *= 2;
-    return B;
+// Row-pass shape for m1 s-intervals.  One wavefront per row up to 512 nodes (8 per lane); measured on
+// MI355X at m1 = 512: (B, G) = (8, 1) at 2 waves/SIMD runs 0.183 ms/launch, (4, 2) at 4 waves/SIMD 0.249 ms
+// (the split solve costs 1.75x the instructions).  Two wavefronts per row above 512 nodes.
+HADI_HD inline void hadi_pick_shape(int m1, int *B, int *G) {
+    if (m1 <= 64) { *B = 1; *G = 1; }
+    else if (m1 <= 128) { *B = 2; *G = 1; }
+    else if (m1 <= 256) { *B = 4; *G = 1; }
+    else if (m1 <= 512) { *B = 8; *G = 1; }
+    else { *B = 8; *G = 2; }
 }
-
 
 struct HadiInstPar {
     double dt, thdt;   // delta_t, theta*delta_t
@@ -120,7 +139,7 @@ struct HadiSetupIn {
 
 // Output tables of one instance (all device pointers, already offset to the instance).
 struct HadiTables {
-    double *scoef;   // [4][64*B]   Bm, Bp, Dm, Dp with B_k = s_i beta_s(i-1,k), D_k = 1/2 s_i^2 delta_s(i-1,k),
+    double *scoef;   // [4][64*B*G] Bm, Bp, Dm, Dp with B_k = s_i beta_s(i-1,k), D_k = 1/2 s_i^2 delta_s(i-1,k),
                      //             k = -1, +1 (the k = 0 weights are -(m + p): the FD weights sum to zero)
     double *b2row;   // [rowp]      -1/2 r_d s_i E in state layout (hes_boundary_kernels.hpp:62-66)
     double *rowc;    // [nrows][HADI_RC]
@@ -146,7 +165,7 @@ struct HadiNoSync { HADI_HD void operator()() const {} };
 template <class Sync>
 HADI_HD inline void hadi_setup_instance(const HadiLayout &L, const HadiSetupIn &in, const HadiTables &t,
                                         int tid, int nth, Sync sync) {
-    const int m1 = L.m1, m2 = L.m2, nrows = L.nrows, npad = L.nrows_pad, B = L.B, nslot = 64 * B;
+    const int m1 = L.m1, m2 = L.m2, nrows = L.nrows, npad = L.nrows_pad, nslot = 64 * L.B * L.G;
     const double E = exp(-in.r_f * in.dt * (in.N - 1));  // hes_boundary_kernels.hpp:56
     const double thdt = in.theta * in.dt;
 
@@ -162,13 +181,13 @@ HADI_HD inline void hadi_setup_instance(const HadiLayout &L, const HadiSetupIn &
     sync();
     for (int i = tid + 1; i < m1; i += nth) {
         const double s = in.vec_s[i];
-        const int pos = hadi_pos(B, i);
+        const int pos = hadi_pos(L, i);
         t.scoef[0 * nslot + pos] = s * hadi_fd_beta(in.delta_s, i - 1, -1);
         t.scoef[1 * nslot + pos] = s * hadi_fd_beta(in.delta_s, i - 1, 1);
         t.scoef[2 * nslot + pos] = 0.5 * s * s * hadi_fd_delta(in.delta_s, i - 1, -1);
         t.scoef[3 * nslot + pos] = 0.5 * s * s * hadi_fd_delta(in.delta_s, i - 1, 1);
     }
-    for (int i = tid; i <= m1; i += nth) t.b2row[hadi_pos(B, i)] = -0.5 * in.r_d * in.vec_s[i] * E;
+    for (int i = tid; i <= m1; i += nth) t.b2row[hadi_pos(L, i)] = -0.5 * in.r_d * in.vec_s[i] * E;
     // --- v-rows: A0 weights, explicit A2, boundary b1 ---------------------------------------------
     for (int r = tid; r < nrows; r += nth) {
         double *rc = t.rowc + (size_t)r * HADI_RC;

@@ -83,6 +83,17 @@ HADI_DEV HADI_FORCEINLINE void hadi_store_row(double *__restrict__ row, int lane
     }
 }
 
+// Value of `v` held by lane `src` (0..63) of this wavefront.
+HADI_DEV HADI_FORCEINLINE double hadi_lane_get(double v, int src) {
+#if defined(HADI_EMU)
+    return __shfl(v, src);
+#else
+    const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+#endif
+}
+
 // ---- LDS row ring helpers ---------------------------------------------------------------------------
 // Asynchronous copy of one state row (rowp doubles, HBM layout == LDS layout) into the ring: LDS-DMA
 // (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPRs); it completes before the next
@@ -124,203 +135,296 @@ HADI_DEV HADI_FORCEINLINE void hadi_lds_row(const double *lrow, int lane, double
     }
 }
 
-// pass A.  Block = W wavefronts working on W consecutive v-rows of one instance at a time; the rows
-// j-2 .. j+W+1 they need (9-point A0, 5-point A2) sit in an LDS ring of 2W+4 rows that is refilled by
-// LDS-DMA one iteration ahead, so HBM latency hides behind the line solves.  Lane l owns the s-nodes
-// i = 1+B*l .. B*l+B of its wave's row.  The s-direction coefficient arrays live in LDS too (shared
-// by the block's waves), which keeps the kernel at two wavefronts per SIMD without spills.
+// pass A.  Block = W*G wavefronts working on W consecutive v-rows of one instance at a time, G wavefronts
+// per row.  The rows j-2 .. j+W+1 they need (9-point A0, 5-point A2) sit in an LDS ring of 2W+4 rows that is
+// refilled by LDS-DMA one iteration ahead, so HBM latency hides behind the line solves.  Lane l of wave g owns
+// the s-nodes i = 1 + 64*B*g + B*l .. of its row.  The s-direction coefficient arrays live in LDS too.
+// With G = 2 the row's tridiagonal system is split at the wave boundary: each half is solved against one
+// unknown boundary value (a second right-hand side carried through the cyclic reduction) and the two
+// boundary values follow from a 2x2 system exchanged through LDS -- small per-lane state (B = 4 at
+// m1 = 512) is what lets four wavefronts share a SIMD.
 struct HadiRowCtx {
-    const double *coef;  // LDS: Bm, Bp, Dm, Dp, each 64*B doubles in row layout
+    const double *coef;  // LDS: Bm, Bp, Dm, Dp, each 64*B*G doubles in row layout
+    double *xch;         // LDS: [W][4] boundary exchange between the two waves of a row (G = 2)
     double *Yi;          // instance base of Y
     const double *Li;    // instance base of lambda_bar (American)
     const double *rowc;  // instance base of the row table
     const double *b2r;   // instance b2 row (global)
-    int lane, posL, posR, rowp;
+    int lane, half, wrow, posL, posR, rowp;
     double dt, thdt, qd, half_rd, e_nm1, e_n;
 };
 
-// One v-row: explicit stage, Y0, A1 line solve, A2 right-hand side.  LAST = this is the v-row that
-// carries b2 (hes_boundary_kernels.hpp:62-66); AMER adds lambda_bar (device_solver.hpp:325-331).
-template <int B, bool AMER, bool LAST>
-HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtx &c, int j, const double *rm2, const double *rm1,
-                                             const double *r0, const double *rp1, const double *rp2) {
-    const int lane = c.lane, rowp = c.rowp;
-    constexpr int c0slot = 64 * B;
-    const double dt = c.dt, thdt = c.thdt, qd = c.qd, half_rd = c.half_rd, e_nm1 = c.e_nm1, e_n = c.e_n;
-    const double *__restrict__ rc = c.rowc + (size_t)j * HADI_RC;
-    const double v = rc[RC_V];
-    const double wm = rc[RC_WM], wz = rc[RC_WZ], wp = rc[RC_WP];
-    const double a2l2 = rc[RC_L2], a2l1 = rc[RC_L1], a2m = rc[RC_M], a2u1 = rc[RC_U1], a2u2 = rc[RC_U2];
-    const double b1val = rc[RC_B1VAL];
-    const int b1col = (int)rc[RC_B1COL];
-    const int b1e = b1col - 1;
-    const int b1lane = (b1col >= 1) ? b1e / B : -1;
-    const int b1r = (b1col >= 1) ? b1e - b1lane * B : -1;
-
-    // ---- column i = 0 (A0 and A1 rows are zero there; only A2 and the boundary act) ------------
-    const double c0 = r0[c0slot];
-    const double a2c0 = a2l2 * rm2[c0slot] + a2l1 * rm1[c0slot] + a2m * c0 + a2u1 * rp1[c0slot] + a2u2 * rp2[c0slot];
-    const double b1c0 = (b1col == 0) ? b1val : 0.0;
-    const double b2c0 = LAST ? c.b2r[c0slot] : 0.0;
-    const double lamc0 = AMER ? c.Li[(size_t)j * rowp + c0slot] : 0.0;
-    double y0c0 = c0 + dt * (a2c0 + (b1c0 + b2c0) * e_nm1 + lamc0);
-    y0c0 = y0c0 + thdt * (b1c0 * e_n - (0.0 + b1c0 * e_nm1));
-    const double x0 = y0c0;  // A1 row 0 is the identity (hes_a1_kernels.hpp:56-61)
-    const double yout_c0 = x0 + thdt * (b2c0 * e_n - (a2c0 + b2c0 * e_nm1));
-
-    // ---- explicit operators.  A0 = (s-derivative) o (v-derivative): first the v-combination
-    // t = wm u(j-1) + wz u(j) + wp u(j+1) on the block and its two s-neighbours, then the B-weights.
-    double u0[B], tt[B], A2U[B];
-    {
-        double um[B], up[B], u2[B];
-        hadi_lds_row<B>(r0, lane, u0);
-        hadi_lds_row<B>(rm1, lane, um);
-        hadi_lds_row<B>(rp1, lane, up);
-#pragma unroll
-        for (int r = 0; r < B; r++) {
-            tt[r] = wm * um[r] + wz * u0[r] + wp * up[r];
-            A2U[r] = a2l1 * um[r] + a2m * u0[r] + a2u1 * up[r];
-        }
-        hadi_lds_row<B>(rm2, lane, u2);
-#pragma unroll
-        for (int r = 0; r < B; r++) A2U[r] = fma(a2l2, u2[r], A2U[r]);
-        hadi_lds_row<B>(rp2, lane, u2);
-#pragma unroll
-        for (int r = 0; r < B; r++) A2U[r] = fma(a2u2, u2[r], A2U[r]);
-    }
-    const double u0L = r0[c.posL], u0R = r0[c.posR];
-    const double tL = wm * rm1[c.posL] + wz * u0L + wp * rp1[c.posL];
-    const double tR = wm * rm1[c.posR] + wz * u0R + wp * rp1[c.posR];
-
-    double lam[B], b2v[B];
-    if constexpr (AMER) hadi_load_row<B>(c.Li + (size_t)j * rowp, lane, true, lam);
-    if constexpr (LAST) hadi_load_row<B>(c.b2r, lane, true, b2v);
-
-    // ---- Y0 (device_solver.hpp:236-250) fused with the forward sweep of the in-lane Thomas ----------
-    //   x[r] = ys[r] - XL*ps[r] - X*gs[r],  XL = interface unknown of lane-1, X = own x[B-1]
-    // The central FD weights follow from sum_k beta_s = sum_k delta_s = 0: B0 = -(Bm+Bp), D0 = -(Dm+Dp).
-    constexpr int NB = B - 1;
-    double Bm[B], Bp[B], Dm[B], Dp[B];
-    hadi_lds_row<B>(c.coef + 0 * 64 * B, lane, Bm);
-    hadi_lds_row<B>(c.coef + 1 * 64 * B, lane, Bp);
-    hadi_lds_row<B>(c.coef + 2 * 64 * B, lane, Dm);
-    hadi_lds_row<B>(c.coef + 3 * 64 * B, lane, Dp);
-    double ys[B], ps[B], iu[B], invt[B];
-    double il_last = 0.0, im_last = 1.0, d_last = 0.0;
-#pragma unroll
-    for (int r = 0; r < B; r++) {
-        const double uL = (r == 0) ? u0L : u0[r == 0 ? 0 : r - 1];
-        const double uR = (r == B - 1) ? u0R : u0[r == B - 1 ? r : r + 1];
-        const double tl = (r == 0) ? tL : tt[r == 0 ? 0 : r - 1];
-        const double tr = (r == B - 1) ? tR : tt[r == B - 1 ? r : r + 1];
-        const double lo = fma(v, Dm[r], qd * Bm[r]);
-        const double up = fma(v, Dp[r], qd * Bp[r]);
-        const double mn = -(fma(v, Dm[r] + Dp[r], qd * (Bm[r] + Bp[r])) + half_rd);
-        const double A1U = lo * uL + mn * u0[r] + up * uR;
-        const double A0U = Bm[r] * tl - (Bm[r] + Bp[r]) * tt[r] + Bp[r] * tr;
-        const double b1h = (lane == b1lane && r == b1r) ? b1val : 0.0;
-        double S = A0U + A1U + A2U[r];
-        if constexpr (LAST) S += (b1h + b2v[r]) * e_nm1;
-        else S += b1h * e_nm1;
-        if constexpr (AMER) S += lam[r];
-        double y = u0[r] + dt * S;
-        y = y + thdt * (b1h * e_n - (A1U + b1h * e_nm1));
-        double il = -thdt * lo;
-        const double im = 1.0 - thdt * mn;
-        iu[r] = -thdt * up;
-        if (r == 0 && lane == 0) {  // x_0 is known: move it to the right-hand side
-            y -= il * x0;
-            il = 0.0;
-        }
-        if (r < NB) {
-            if (r == 0) {
-                invt[0] = hadi_rcp(im);
-                ys[0] = y;
-                ps[0] = il;
-            } else {
-                const double w = il * invt[r - 1];
-                invt[r] = hadi_rcp(fma(-w, iu[r - 1], im));
-                ys[r] = fma(-w, ys[r - 1], y);
-                ps[r] = -w * ps[r - 1];
-            }
-        } else {
-            il_last = il;
-            im_last = im;
-            d_last = y;
-        }
-    }
-    double gs[B];
-    double ra, rb, rcc, rf;
-    if constexpr (NB > 0) {
-        gs[NB - 1] = iu[NB - 1] * invt[NB - 1];
-        ys[NB - 1] *= invt[NB - 1];
-        ps[NB - 1] *= invt[NB - 1];
-#pragma unroll
-        for (int r = NB - 2; r >= 0; r--) {
-            ys[r] = fma(-iu[r], ys[r + 1], ys[r]) * invt[r];
-            ps[r] = fma(-iu[r], ps[r + 1], ps[r]) * invt[r];
-            gs[r] = -iu[r] * gs[r + 1] * invt[r];
-        }
-        // interface row of this lane couples to XL, X and the next lane's X
-        const double p0n = __shfl_down(ps[0], 1);
-        const double g0n = __shfl_down(gs[0], 1);
-        const double y0n = __shfl_down(ys[0], 1);
-        ra = -il_last * ps[NB - 1];
-        rb = im_last - il_last * gs[NB - 1] - iu[B - 1] * p0n;
-        rcc = -iu[B - 1] * g0n;
-        rf = d_last - il_last * ys[NB - 1] - iu[B - 1] * y0n;
+// Loads this lane's B values of a row-layout array (LDS or global): pair q at q*128*G + 128*half + 2*lane.
+template <int B, int G>
+HADI_DEV HADI_FORCEINLINE void hadi_get_block(const double *row, int half, int lane, double (&u)[B]) {
+    if constexpr (B == 1) {
+        u[0] = row[64 * half + lane];
     } else {
-        ra = il_last;
-        rb = im_last;
-        rcc = iu[0];
-        rf = d_last;
-    }
-    // ---- parallel cyclic reduction over the 64 interface unknowns (normalised rows) -------------
-    {
-        const double rinv0 = hadi_rcp(rb);
-        ra *= rinv0;
-        rcc *= rinv0;
-        rf *= rinv0;
 #pragma unroll
-        for (int s = 1; s < 64; s <<= 1) {
-            const double aL = __shfl_up(ra, s), cL = __shfl_up(rcc, s), fL = __shfl_up(rf, s);
-            const double aR = __shfl_down(ra, s), cR = __shfl_down(rcc, s), fR = __shfl_down(rf, s);
-            // lanes without a partner at distance s have ra == 0 (left) / rcc == 0 (right), so
-            // the wrapped values they fetch are multiplied by zero
-            const double bn = 1.0 - ra * cL - rcc * aR;
-            const double rn = hadi_rcp(bn);
-            const double fn = (rf - ra * fL - rcc * fR) * rn;
-            const double an = (lane >= s) ? (-ra * aL) * rn : 0.0;
-            const double cn = (lane + s < 64) ? (-rcc * cR) * rn : 0.0;
-            ra = an;
-            rcc = cn;
-            rf = fn;
+        for (int q = 0; q < B / 2; q++) {
+            const double2 t = *reinterpret_cast<const double2 *>(row + q * 128 * G + 128 * half + 2 * lane);
+            u[2 * q] = t.x;
+            u[2 * q + 1] = t.y;
         }
     }
-    const double X = rf;
-    double XL = __shfl_up(X, 1);
-    if (lane == 0) XL = 0.0;
-
-    // ---- Y1 -> right-hand side of the A2 solve (device_solver.hpp:254-260) and store ----------
-    double yo[B];
+}
+template <int B, int G>
+HADI_DEV HADI_FORCEINLINE void hadi_put_block(double *row, int half, int lane, const double (&u)[B]) {
+    if constexpr (B == 1) {
+        row[64 * half + lane] = u[0];
+    } else {
 #pragma unroll
-    for (int r = 0; r < B; r++) {
-        double x;
-        if (r < NB) x = ys[r] - XL * ps[r] - X * gs[r];
-        else x = X;
-        if constexpr (LAST) yo[r] = x + thdt * (b2v[r] * e_n - (A2U[r] + b2v[r] * e_nm1));
-        else yo[r] = x - thdt * A2U[r];
+        for (int q = 0; q < B / 2; q++) {
+            double2 t;
+            t.x = u[2 * q];
+            t.y = u[2 * q + 1];
+            *reinterpret_cast<double2 *>(row + q * 128 * G + 128 * half + 2 * lane) = t;
+        }
     }
-    hadi_store_row<B>(c.Yi + (size_t)j * rowp, lane, yo);
-    if (lane == 0) c.Yi[(size_t)j * rowp + c0slot] = yout_c0;
 }
 
-template <int B, int W, bool AMER>
-__global__ void __launch_bounds__(64 * W, (B >= 16 ? 1 : 2)) hadi_pass_a(HadiSweepArgs a, int n) {
+// One v-row: explicit stage, Y0, A1 line solve, A2 right-hand side.  LAST = this is the v-row that
+// carries b2 (hes_boundary_kernels.hpp:62-66); AMER adds lambda_bar (device_solver.hpp:325-331).
+// `active` is wave-uniform; with G = 2 every wave of the block must call this (it contains a barrier).
+template <int B, int G, bool AMER, bool LAST>
+HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtx &c, bool active, int j, const double *rm2,
+                                             const double *rm1, const double *r0, const double *rp1,
+                                             const double *rp2) {
+    const int lane = c.lane, rowp = c.rowp, half = c.half;
+    constexpr int c0slot = 64 * B * G;
+    constexpr int NB = B - 1;
+    const double dt = c.dt, thdt = c.thdt, qd = c.qd, half_rd = c.half_rd, e_nm1 = c.e_nm1, e_n = c.e_n;
+    const bool first_half = (half == 0), last_half = (half == G - 1);
+    // state that survives the exchange barrier
+    double ys[B], ps[B], gs[B], A2U[B], b2v[B];
+    double Ysol = 0.0, Ssol = 0.0, yout_c0 = 0.0;
+
+    if (active) {
+        const double *__restrict__ rc = c.rowc + (size_t)j * HADI_RC;
+        const double v = rc[RC_V];
+        const double wm = rc[RC_WM], wz = rc[RC_WZ], wp = rc[RC_WP];
+        const double a2l2 = rc[RC_L2], a2l1 = rc[RC_L1], a2m = rc[RC_M], a2u1 = rc[RC_U1], a2u2 = rc[RC_U2];
+        const double b1val = rc[RC_B1VAL];
+        const int b1col = (int)rc[RC_B1COL];
+        // which (wave, lane, slot) holds the b1 node of this v-row
+        const int b1e = b1col - 1;
+        const int b1half = (b1col >= 1) ? b1e / (64 * B) : -1;
+        const int b1el = b1e - b1half * 64 * B;
+        const int b1lane = (b1col >= 1 && b1half == half) ? b1el / B : -1;
+        const int b1r = b1el - (b1el / B) * B;
+
+        // ---- column i = 0 (A0 and A1 rows are zero there; only A2 and the boundary act) ------------
+        const double c0 = r0[c0slot];
+        const double a2c0 = a2l2 * rm2[c0slot] + a2l1 * rm1[c0slot] + a2m * c0 + a2u1 * rp1[c0slot] + a2u2 * rp2[c0slot];
+        const double b1c0 = (b1col == 0) ? b1val : 0.0;
+        const double b2c0 = LAST ? c.b2r[c0slot] : 0.0;
+        const double lamc0 = AMER ? c.Li[(size_t)j * rowp + c0slot] : 0.0;
+        double y0c0 = c0 + dt * (a2c0 + (b1c0 + b2c0) * e_nm1 + lamc0);
+        y0c0 = y0c0 + thdt * (b1c0 * e_n - (0.0 + b1c0 * e_nm1));
+        const double x0 = y0c0;  // A1 row 0 is the identity (hes_a1_kernels.hpp:56-61)
+        yout_c0 = x0 + thdt * (b2c0 * e_n - (a2c0 + b2c0 * e_nm1));
+
+        // ---- explicit operators.  A0 = (s-derivative) o (v-derivative): first the v-combination
+        // t = wm u(j-1) + wz u(j) + wp u(j+1) on the block and its two s-neighbours, then the B-weights.
+        double u0[B], tt[B];
+        {
+            double um[B], up[B], u2[B];
+            hadi_get_block<B, G>(r0, half, lane, u0);
+            hadi_get_block<B, G>(rm1, half, lane, um);
+            hadi_get_block<B, G>(rp1, half, lane, up);
+#pragma unroll
+            for (int r = 0; r < B; r++) {
+                tt[r] = wm * um[r] + wz * u0[r] + wp * up[r];
+                A2U[r] = a2l1 * um[r] + a2m * u0[r] + a2u1 * up[r];
+            }
+            hadi_get_block<B, G>(rm2, half, lane, u2);
+#pragma unroll
+            for (int r = 0; r < B; r++) A2U[r] = fma(a2l2, u2[r], A2U[r]);
+            hadi_get_block<B, G>(rp2, half, lane, u2);
+#pragma unroll
+            for (int r = 0; r < B; r++) A2U[r] = fma(a2u2, u2[r], A2U[r]);
+        }
+        const double cb1 = dt * e_nm1 + thdt * (e_n - e_nm1);
+        const double u0L = r0[c.posL], u0R = r0[c.posR];
+        const double tL = wm * rm1[c.posL] + wz * u0L + wp * rp1[c.posL];
+        const double tR = wm * rm1[c.posR] + wz * u0R + wp * rp1[c.posR];
+
+        double lam[B];
+        if constexpr (AMER) hadi_get_block<B, G>(c.Li + (size_t)j * rowp, half, lane, lam);
+        if constexpr (LAST) hadi_get_block<B, G>(c.b2r, half, lane, b2v);
+
+        // ---- Y0 (device_solver.hpp:236-250) fused with the forward sweep of the in-lane Thomas ----------
+        //   x[r] = ys[r] - XL*ps[r] - X*gs[r],  XL = interface unknown of lane-1, X = own x[B-1]
+        // The central FD weights follow from sum_k beta_s = sum_k delta_s = 0: B0 = -(Bm+Bp), D0 = -(Dm+Dp).
+        double Bm[B], Bp[B], Dm[B], Dp[B];
+        hadi_get_block<B, G>(c.coef + 0 * 64 * B * G, half, lane, Bm);
+        hadi_get_block<B, G>(c.coef + 1 * 64 * B * G, half, lane, Bp);
+        hadi_get_block<B, G>(c.coef + 2 * 64 * B * G, half, lane, Dm);
+        hadi_get_block<B, G>(c.coef + 3 * 64 * B * G, half, lane, Dp);
+        double iu[B], invt[B];
+        double il_last = 0.0, im_last = 1.0, d_last = 0.0;
+#pragma unroll
+        for (int r = 0; r < B; r++) {
+            const double uL = (r == 0) ? u0L : u0[r == 0 ? 0 : r - 1];
+            const double uR = (r == B - 1) ? u0R : u0[r == B - 1 ? r : r + 1];
+            const double tl = (r == 0) ? tL : tt[r == 0 ? 0 : r - 1];
+            const double tr = (r == B - 1) ? tR : tt[r == B - 1 ? r : r + 1];
+            const double lo = fma(v, Dm[r], qd * Bm[r]);
+            const double up = fma(v, Dp[r], qd * Bp[r]);
+            const double mn = -(fma(v, Dm[r] + Dp[r], qd * (Bm[r] + Bp[r])) + half_rd);
+            const double A1U = lo * uL + mn * u0[r] + up * uR;
+            const double A0U = Bm[r] * tl - (Bm[r] + Bp[r]) * tt[r] + Bp[r] * tr;
+            const double b1h = (lane == b1lane && r == b1r) ? b1val : 0.0;
+            // Y0 = U + dt (A0U + A1U + A2U + b e_{n-1} [+ lambda]) + theta dt (b1 e_n - (A1U + b1 e_{n-1})); the b1
+            // entry of this v-row (a single node) contributes b1 * cb1, cb1 = dt e_{n-1} + theta dt (e_n - e_{n-1})
+            double S = A0U + A1U + A2U[r];
+            if constexpr (LAST) S += b2v[r] * e_nm1;
+            if constexpr (AMER) S += lam[r];
+            double y = fma(dt, S, u0[r]);
+            y = fma(-thdt, A1U, y);
+            y = fma(b1h, cb1, y);
+            double il = -thdt * lo;
+            const double im = 1.0 - thdt * mn;
+            iu[r] = -thdt * up;
+            if (r == 0 && lane == 0 && first_half) {  // x_0 is known: move it to the right-hand side
+                y -= il * x0;
+                il = 0.0;
+            }
+            if (r < NB) {
+                if (r == 0) {
+                    invt[0] = hadi_rcp(im);
+                    ys[0] = y;
+                    ps[0] = il;
+                } else {
+                    const double w = il * invt[r - 1];
+                    invt[r] = hadi_rcp(fma(-w, iu[r - 1], im));
+                    ys[r] = fma(-w, ys[r - 1], y);
+                    ps[r] = -w * ps[r - 1];
+                }
+            } else {
+                il_last = il;
+                im_last = im;
+                d_last = y;
+            }
+        }
+        // reduced (interface) row of this lane:  ra*X(l-1) + rb*X(l) + rcc*X(l+1) = rf [- rs * boundary value]
+        double ra, rb, rcc, rf, rs = 0.0;
+        const bool edge_hi = (G > 1) && !last_half && lane == 63;  // next node belongs to the other wave
+        const bool edge_lo = (G > 1) && !first_half && lane == 0;  // previous node belongs to the other wave
+        if constexpr (NB > 0) {
+            gs[NB - 1] = iu[NB - 1] * invt[NB - 1];
+            ys[NB - 1] *= invt[NB - 1];
+            ps[NB - 1] *= invt[NB - 1];
+#pragma unroll
+            for (int r = NB - 2; r >= 0; r--) {
+                ys[r] = fma(-iu[r], ys[r + 1], ys[r]) * invt[r];
+                ps[r] = fma(-iu[r], ps[r + 1], ps[r]) * invt[r];
+                gs[r] = -iu[r] * gs[r + 1] * invt[r];
+            }
+            const int nl = (lane + 1) & 63;
+            double p0n = hadi_lane_get(ps[0], nl), g0n = hadi_lane_get(gs[0], nl), y0n = hadi_lane_get(ys[0], nl);
+            if (edge_hi) { p0n = 0.0; g0n = 0.0; y0n = 0.0; }
+            ra = -il_last * ps[NB - 1];
+            rb = im_last - il_last * gs[NB - 1] - iu[B - 1] * p0n;
+            rcc = -iu[B - 1] * g0n;
+            rf = d_last - il_last * ys[NB - 1] - iu[B - 1] * y0n;
+        } else {
+            ra = il_last;
+            rb = im_last;
+            rcc = iu[0];
+            rf = d_last;
+        }
+        if constexpr (G > 1) {
+            if (edge_hi) { rs = iu[B - 1]; rcc = 0.0; }  // couples to t = first node of the other half
+            if (edge_lo) { rs = ra; ra = 0.0; }          // couples to the last node of the other half
+        }
+        // ---- parallel cyclic reduction over the 64 interface unknowns (normalised rows) -------------
+        // Lanes without a partner at distance s have ra == 0 (left) / rcc == 0 (right) by induction, so the
+        // (wrapped) values they fetch are multiplied by zero: no lane masks are needed.
+        {
+            const double rinv0 = hadi_rcp(rb);
+            ra *= rinv0;
+            rcc *= rinv0;
+            rf *= rinv0;
+            if constexpr (G > 1) rs *= rinv0;
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) {
+                const int up_lane = (lane - s) & 63, dn_lane = (lane + s) & 63;
+                const double aL = hadi_lane_get(ra, up_lane), cL = hadi_lane_get(rcc, up_lane), fL = hadi_lane_get(rf, up_lane);
+                const double aR = hadi_lane_get(ra, dn_lane), cR = hadi_lane_get(rcc, dn_lane), fR = hadi_lane_get(rf, dn_lane);
+                const double bn = fma(-rcc, aR, fma(-ra, cL, 1.0));
+                const double rn = hadi_rcp(bn);
+                rf = fma(-rcc, fR, fma(-ra, fL, rf)) * rn;
+                if constexpr (G > 1) {
+                    const double sL = hadi_lane_get(rs, up_lane), sR = hadi_lane_get(rs, dn_lane);
+                    rs = fma(-rcc, sR, fma(-ra, sL, rs)) * rn;
+                }
+                if (s < 32) {  // the last level only needs the right-hand sides
+                    const double an = -(ra * aL) * rn;
+                    const double cn = -(rcc * cR) * rn;
+                    ra = an;
+                    rcc = cn;
+                }
+            }
+        }
+        Ysol = rf;
+        Ssol = rs;
+        if constexpr (G > 1) {
+            // X(l) = Ysol - bv * Ssol with bv the other half's adjacent node.  Publish what the 2x2 needs:
+            //   low half, lane 63:  x_hi = A - t*Bc              (A = Ysol, Bc = Ssol; x_hi = its own X)
+            //   high half, lane 0:  t = C - x_hi*D   (t = its first node = ys0 - XL ps0 - X gs0, XL = x_hi)
+            if (edge_hi) {
+                c.xch[4 * c.wrow + 0] = Ysol;
+                c.xch[4 * c.wrow + 1] = Ssol;
+            }
+            if (edge_lo) {
+                if constexpr (NB > 0) {
+                    c.xch[4 * c.wrow + 2] = ys[0] - Ysol * gs[0];
+                    c.xch[4 * c.wrow + 3] = ps[0] - Ssol * gs[0];
+                } else {
+                    c.xch[4 * c.wrow + 2] = Ysol;
+                    c.xch[4 * c.wrow + 3] = Ssol;
+                }
+            }
+        }
+    }
+    if constexpr (G > 1) __syncthreads();
+    if (active) {
+        double X = Ysol, XL;
+        if constexpr (G > 1) {
+            const double A = c.xch[4 * c.wrow + 0], Bc = c.xch[4 * c.wrow + 1];
+            const double Cc = c.xch[4 * c.wrow + 2], Dd = c.xch[4 * c.wrow + 3];
+            const double xhi = (A - Bc * Cc) / (1.0 - Bc * Dd);  // last node of the low half
+            const double tlo = Cc - Dd * xhi;                    // first node of the high half
+            X = Ysol - (first_half ? tlo : xhi) * Ssol;
+            XL = hadi_lane_get(X, (lane - 1) & 63);
+            if (lane == 0) XL = first_half ? 0.0 : xhi;
+        } else {
+            XL = hadi_lane_get(X, (lane - 1) & 63);
+            if (lane == 0) XL = 0.0;
+        }
+        // ---- Y1 -> right-hand side of the A2 solve (device_solver.hpp:254-260) and store ----------
+        double yo[B];
+#pragma unroll
+        for (int r = 0; r < B; r++) {
+            double x;
+            if (r < NB) x = ys[r] - XL * ps[r] - X * gs[r];
+            else x = X;
+            if constexpr (LAST) yo[r] = x + thdt * (b2v[r] * e_n - (A2U[r] + b2v[r] * e_nm1));
+            else yo[r] = x - thdt * A2U[r];
+        }
+        hadi_put_block<B, G>(c.Yi + (size_t)j * rowp, half, lane, yo);
+        if (lane == 0 && first_half) c.Yi[(size_t)j * rowp + c0slot] = yout_c0;
+    }
+}
+
+template <int B, int G, int W, bool AMER>
+__global__ void __launch_bounds__(64 * W * G, (B >= 8 ? 2 : 4)) hadi_pass_a(HadiSweepArgs a, int n) {
     HADI_DYN_SMEM(double, smem);
     constexpr int RING = 2 * W + 4;
     const int lane = threadIdx.x & 63;
     const int wave = HADI_UNIFORM((int)(threadIdx.x >> 6));
+    const int wrow = wave / G, half = wave - wrow * G;
     const int total = a.n_inst * a.ntiles;
     const int logical = hadi_xcd_remap(blockIdx.x, gridDim.x);
     if (logical >= total) return;
@@ -334,6 +438,8 @@ __global__ void __launch_bounds__(64 * W, (B >= 16 ? 1 : 2)) hadi_pass_a(HadiSwe
 
     HadiRowCtx c;
     c.lane = lane;
+    c.half = half;
+    c.wrow = wrow;
     c.rowp = rowp;
     c.dt = ip.dt; c.thdt = ip.thdt; c.qd = ip.q; c.half_rd = ip.half_rd;
     c.e_nm1 = exp(ip.r_f * ip.dt * (n - 1));  // device_solver.hpp:238
@@ -343,40 +449,42 @@ __global__ void __launch_bounds__(64 * W, (B >= 16 ? 1 : 2)) hadi_pass_a(HadiSwe
     c.Li = AMER ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
     c.rowc = a.rowc + (size_t)inst * nrows * HADI_RC;
     c.b2r = a.b2row + (size_t)inst * rowp;
-    constexpr int c0slot = 64 * B;
-    // positions of the s-neighbours of this lane's block: i-1 of its first node, i+1 of its last node.
-    // Lane 0's left neighbour is the i = 0 slot; lane 63's right neighbour is a pad slot (always 0).
-    if constexpr (B == 1) {
-        c.posL = lane == 0 ? c0slot : lane - 1;
-        c.posR = lane == 63 ? c0slot + 1 : lane + 1;
-    } else {
-        c.posL = lane == 0 ? c0slot : (B / 2 - 1) * 128 + 2 * lane - 1;
-        c.posR = lane == 63 ? c0slot + 1 : 2 * lane + 2;
+    constexpr int c0slot = 64 * B * G;
+    // storage positions of the s-neighbours of this lane's block (node before its first, node after its
+    // last).  Before i = 1 comes the i = 0 slot; after the row's last node comes a pad slot (always 0).
+    {
+        const int ifirst = 1 + 64 * B * half + B * lane;
+        c.posL = hadi_pos(B, G, ifirst - 1);
+        c.posR = (ifirst + B <= 64 * B * G) ? hadi_pos(B, G, ifirst + B) : c0slot + 1;
     }
 
-    // LDS: [RING rows of rowp] [4 coefficient arrays of 64*B]
+    // LDS: [RING rows of rowp] [4 coefficient arrays of 64*B*G] [W*4 exchange]
     double *coef = smem + (size_t)RING * rowp;
     {
-        const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B;
-        for (int e = threadIdx.x; e < 4 * 64 * B; e += 64 * W) coef[e] = sc[e];
+        const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B * G;
+        for (int e = threadIdx.x; e < 4 * 64 * B * G; e += 64 * W * G) coef[e] = sc[e];
     }
     c.coef = coef;
+    c.xch = coef + 4 * 64 * B * G;
 
     auto slot = [&](int jj) { return smem + (size_t)((jj + RING) % RING) * rowp; };
     auto fetch = [&](int jj) { hadi_row_to_lds(Ub + (size_t)jj * rowp, slot(jj), rowp, lane, jj >= 0 && jj < npad); };
-    for (int rr = wave; rr < W + 4; rr += W) fetch(j0 - 2 + rr);
+    for (int rr = wave; rr < W + 4; rr += W * G) fetch(j0 - 2 + rr);
 
     const int iters = (j1 - j0 + W - 1) / W;
     for (int it = 0; it < iters; it++) {
         const int J = j0 + it * W;
         __syncthreads();  // this iteration's rows have landed; everyone is done with the rows replaced below
-        if (it + 1 < iters) fetch(J + W + 2 + wave);
-        const int j = J + wave;
-        if (j >= j1) continue;
+        if (it + 1 < iters && wave < W) fetch(J + W + 2 + wave);
+        const int j = J + wrow;
+        const bool active = j < j1;
+        if constexpr (G == 1) {
+            if (!active) continue;
+        }
         if (j == nrows - 1)
-            hadi_row_step<B, AMER, true>(c, j, slot(j - 2), slot(j - 1), slot(j), slot(j + 1), slot(j + 2));
+            hadi_row_step<B, G, AMER, true>(c, active, j, slot(j - 2), slot(j - 1), slot(j), slot(j + 1), slot(j + 2));
         else
-            hadi_row_step<B, AMER, false>(c, j, slot(j - 2), slot(j - 1), slot(j), slot(j + 1), slot(j + 2));
+            hadi_row_step<B, G, AMER, false>(c, active, j, slot(j - 2), slot(j - 1), slot(j), slot(j + 1), slot(j + 2));
     }
 }
 
@@ -575,7 +683,7 @@ __global__ void __launch_bounds__(256) hadi_setup_kernel(HadiSetupArgs s) {
     in.r_d = s.r_d; in.r_f = s.r_f; in.theta = s.theta;
     HadiTables t;
     const int n4 = 4 * L.P;
-    t.scoef = s.scoef + (size_t)inst * 4 * 64 * L.B;
+    t.scoef = s.scoef + (size_t)inst * 4 * 64 * L.B * L.G;
     t.b2row = s.b2row + (size_t)inst * L.rowp;
     t.rowc = s.rowc + (size_t)inst * L.nrows * HADI_RC;
     t.a2i = s.a2i + (size_t)inst * 5 * L.nrows_pad;
@@ -598,15 +706,7 @@ __global__ void __launch_bounds__(256) hadi_pack_kernel(HadiLayout L, int n_inst
         const size_t rowid = e / L.rowp;
         const int j = (int)(rowid % L.nrows_pad);
         const size_t inst = rowid / L.nrows_pad;
-        // invert pos(): slot -> i
-        int i;
-        if (slot == 64 * L.B) i = 0;
-        else if (slot > 64 * L.B) i = -1;
-        else if (L.B == 1) i = slot + 1;
-        else {
-            const int qq = slot >> 7, rem = slot & 127, lane = rem >> 1, r = 2 * qq + (rem & 1);
-            i = 1 + L.B * lane + r;
-        }
+        const int i = hadi_slot_to_i(L, slot);
         double v = 0.0;
         if (i >= 0 && i <= L.m1 && j < L.nrows) v = nat[(inst % (size_t)n_src) * m + (size_t)j * (L.m1 + 1) + i];
         internal[e] = v;
@@ -622,7 +722,7 @@ __global__ void __launch_bounds__(256) hadi_unpack_kernel(HadiLayout L, int n_in
         const size_t rowid = e / (L.m1 + 1);
         const int j = (int)(rowid % L.nrows);
         const size_t inst = rowid / L.nrows;
-        nat[e] = internal[inst * L.inst_stride + (size_t)j * L.rowp + hadi_pos(L.B, i)];
+        nat[e] = internal[inst * L.inst_stride + (size_t)j * L.rowp + hadi_pos(L, i)];
     }
 }
 
@@ -662,13 +762,13 @@ __global__ void __launch_bounds__(256) hadi_dividend_kernel(HadiLayout L, int n_
             if (idx > 0) {
                 const double s_low = s[idx - 1], s_high = s[idx];
                 const double weight = (new_s - s_low) / (s_high - s_low);
-                const double val_low = src[hadi_pos(L.B, idx - 1)], val_high = src[hadi_pos(L.B, idx)];
+                const double val_low = src[hadi_pos(L, idx - 1)], val_high = src[hadi_pos(L, idx)];
                 out = (1.0 - weight) * val_low + weight * val_high;
             } else {
-                out = src[hadi_pos(L.B, 0)];
+                out = src[hadi_pos(L, 0)];
             }
         }
-        U[inst * L.inst_stride + (size_t)j * L.rowp + hadi_pos(L.B, i)] = out;
+        U[inst * L.inst_stride + (size_t)j * L.rowp + hadi_pos(L, i)] = out;
     }
 }
 
@@ -696,7 +796,7 @@ __global__ void __launch_bounds__(64) hadi_pick_kernel(HadiLayout L, int n_inst,
         return;
     }
     status[inst] = 0;
-    prices[(size_t)inst * price_stride] = U[(size_t)inst * L.inst_stride + (size_t)iv * L.rowp + hadi_pos(L.B, is)];
+    prices[(size_t)inst * price_stride] = U[(size_t)inst * L.inst_stride + (size_t)iv * L.rowp + hadi_pos(L, is)];
 }
 
 // Replicate one of `nsrc` source rows (length len) into every instance's row: dst[inst] = src[sel[inst]]

@@ -21,12 +21,12 @@ struct HadiPlan {
 inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan *out) {
     if (m1 < 2 || m2 < 3 || n_inst < 1) return 1;
     if (m2 > m1) return 1;           // b1 would put two entries on one v-row (hadi_core.h)
-    if (m1 > 64 * 16) return 1;      // row pass keeps at most 16 nodes per lane
+    if (m1 > 1024) return 1;         // row pass: 2 waves x 64 lanes x 8 nodes
     HadiPlan p;
     HadiLayout &L = p.L;
     L.m1 = m1; L.m2 = m2; L.nrows = m2 + 1;
-    L.B = hadi_pick_B(m1);
-    L.rowp = 64 * L.B + 8;
+    hadi_pick_shape(m1, &L.B, &L.G);
+    L.rowp = 64 * L.B * L.G + 8;
     L.P = (L.nrows + HADI_LC - 1) / HADI_LC;
     if (L.P > HADI_MAX_P) return 1;
     L.nrows_pad = L.P * HADI_LC;
@@ -46,7 +46,7 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
     ntiles = (L.nrows + R - 1) / R;
     p.R = R;
     p.ntiles = ntiles;
-    p.smem_a = ((size_t)(2 * W + 4) * L.rowp + (size_t)4 * 64 * L.B) * sizeof(double);
+    p.smem_a = ((size_t)(2 * W + 4) * L.rowp + (size_t)4 * 64 * L.B * L.G + 4 * W) * sizeof(double);
     const long long total = (long long)n_inst * ntiles;
     p.grid_a = (int)((total + 7) / 8 * 8);
     p.ctiles = (L.rowp + 63) / 64;
@@ -63,8 +63,8 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
     p.grid_b = n_inst * p.bgroups;
     p.block_b = 64 * L.P;
     p.smem_b = (size_t)L.P * (2 * 4 * 64 + HADI_LC * HADI_PBW) * sizeof(double);
-    p.pos_m1 = hadi_pos(L.B, m1);
-    p.n_scoef = (size_t)4 * 64 * L.B;
+    p.pos_m1 = hadi_pos(L, m1);
+    p.n_scoef = (size_t)4 * 64 * L.B * L.G;
     p.n_b2row = (size_t)L.rowp;
     p.n_rowc = (size_t)L.nrows * HADI_RC;
     p.n_a2i = (size_t)5 * L.nrows_pad;

@@ -12,16 +12,16 @@ thread_local WaveState *t_wave;
 thread_local int t_lane;
 }  // namespace emu
 
-template <int B>
+template <int B, int G>
 static void run_pass_a(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
-    if (a.american) emu::launch(pl.grid_a, 64 * pl.W, [&]() { hadi_pass_a<B, 4, true>(a, n); }, pl.smem_a);
-    else emu::launch(pl.grid_a, 64 * pl.W, [&]() { hadi_pass_a<B, 4, false>(a, n); }, pl.smem_a);
+    if (a.american) emu::launch(pl.grid_a, 64 * pl.W * G, [&]() { hadi_pass_a<B, G, 4, true>(a, n); }, pl.smem_a);
+    else emu::launch(pl.grid_a, 64 * pl.W * G, [&]() { hadi_pass_a<B, G, 4, false>(a, n); }, pl.smem_a);
 }
 
 extern "C" int emu_plan(int m1, int m2, int n_inst, int target_waves, int *out /*B,rowp,P,R,ntiles,ctiles*/) {
     HadiPlan pl;
     if (hadi_make_plan(m1, m2, n_inst, target_waves, &pl)) return 1;
-    out[0] = pl.L.B; out[1] = pl.L.rowp; out[2] = pl.L.P; out[3] = pl.R; out[4] = pl.ntiles; out[5] = pl.ctiles;
+    out[0] = pl.L.B; out[1] = pl.L.rowp; out[2] = pl.L.P; out[3] = pl.R; out[4] = pl.ntiles; out[5] = pl.L.G;
     return 0;
 }
 
@@ -77,12 +77,12 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
             }
             if (cur < ndiv && t > ddates[cur]) cur++;
         }
-        switch (L.B) {
-            case 1: run_pass_a<1>(pl, a, n); break;
-            case 2: run_pass_a<2>(pl, a, n); break;
-            case 4: run_pass_a<4>(pl, a, n); break;
-            case 8: run_pass_a<8>(pl, a, n); break;
-            case 16: run_pass_a<16>(pl, a, n); break;
+        switch (L.B * 10 + L.G) {
+            case 11: run_pass_a<1, 1>(pl, a, n); break;
+            case 21: run_pass_a<2, 1>(pl, a, n); break;
+            case 41: run_pass_a<4, 1>(pl, a, n); break;
+            case 81: run_pass_a<8, 1>(pl, a, n); break;
+            case 82: run_pass_a<8, 2>(pl, a, n); break;
             default: return 2;
         }
         emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b<16>(a, n); }, pl.smem_b);

@@ -70,6 +70,12 @@ def test_dividends_and_chunked_column_pass(emu):
     _run(emu, 72, 70, 10, [100.0], O.DIV, 3)
 
 
+def test_two_waves_per_row_split_solve(emu):
+    # m1 > 512: the row's tridiagonal system is split over two wavefronts and re-coupled by a 2x2 system
+    _run(emu, 600, 12, 2, [100.0, 93.0], O.EU, 8)
+    _run(emu, 530, 10, 2, [100.0], O.AM, 8, r_f=0.01)
+
+
 def test_setup_tables_against_oracle_operators(emu):
     """The O(m1+m2) tables reproduce the reference's dense operators: apply them to a random field and
     compare with the oracle's A0U / A1U / A2U of step 1."""
@@ -81,9 +87,9 @@ def test_setup_tables_against_oracle_operators(emu):
     _, _, d = O.solve(p, vs[0], vv[0], ds[0], dv[0], U, U, dump_step=1)
     plan = (C.c_int * 6)()
     assert emu.emu_plan(m1, m2, 1, 8, plan) == 0
-    B, rowp, Pn = plan[0], plan[1], plan[2]
+    B, rowp, Pn, G = plan[0], plan[1], plan[2], plan[5]
     nrows = m2 + 1
-    scoef, b2row = np.zeros(4 * 64 * B), np.zeros(rowp)
+    scoef, b2row = np.zeros(4 * 64 * B * G), np.zeros(rowp)
     npad = Pn * 33  # HADI_LC rows per column-pass chunk
     rowc, a2i, pb, rinv = np.zeros(nrows * 16), np.zeros(5 * npad), np.zeros(npad * 12), np.zeros(16 * Pn * Pn)
     rc = emu.emu_tables(m1, m2, N, C.c_double(Cm.T / N), C.c_double(Cm.THETA), C.c_double(Cm.R_D), C.c_double(0.0),
@@ -95,14 +101,15 @@ def test_setup_tables_against_oracle_operators(emu):
 
     def pos(i):
         if i == 0:
-            return 64 * B
+            return 64 * B * G
         e = i - 1
+        g, el = divmod(e, 64 * B)
         if B == 1:
-            return e
-        lane, r = divmod(e, B)
-        return (r >> 1) * 128 + 2 * lane + (r & 1)
+            return 64 * g + el
+        lane, r = divmod(el, B)
+        return (r >> 1) * 128 * G + 128 * g + 2 * lane + (r & 1)
 
-    sc = scoef.reshape(4, 64 * B)  # Bm, Bp, Dm, Dp; centre weights are -(m + p)
+    sc = scoef.reshape(4, 64 * B * G)  # Bm, Bp, Dm, Dp; centre weights are -(m + p)
     Ug = U.reshape(m2 + 1, m1 + 1)
     A0 = np.zeros_like(Ug); A1 = np.zeros_like(Ug); A2 = np.zeros_like(Ug)
     for j in range(m2 + 1):

@@ -63,7 +63,9 @@ SHAPES = [
     (130, 70, 6, 2),            # 4 nodes/lane, ragged
     (256, 128, 12, 3),          # BASELINE config 3 grid
     (512, 256, 8, 2),           # BASELINE config 2 grid (few steps so the oracle finishes in seconds)
-    (300, 140, 5, 1),           # 8 nodes/lane with padding, 3 chunks
+    (300, 140, 5, 1),           # 8 nodes/lane with padding, 5 chunks
+    (1024, 512, 4, 1),          # BASELINE config 5 grid: two wavefronts per row (split solve), 16 chunks
+    (700, 300, 4, 2),           # two wavefronts per row, ragged
 ]
 
 
