@@ -533,6 +533,18 @@ extern "C" {
 
 int hadi_version(void) { return HADI_VERSION_MAJOR * 100 + HADI_VERSION_MINOR; }
 
+#if defined(HADI_STAMPS)
+// diagnostic build only (tools/stamps.py)
+int hadi_debug_stamps(unsigned long long *out32, int reset) {
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_hadi_stamps), 32 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_hadi_stamps), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
+
 const char *hadi_status_string(int s) {
     switch (s) {
         case HADI_OK: return "ok";

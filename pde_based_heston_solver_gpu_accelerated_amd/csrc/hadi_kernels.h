@@ -94,10 +94,29 @@ HADI_DEV HADI_FORCEINLINE double hadi_lane_get(double v, int src) {
 #endif
 }
 
+#if defined(HADI_STAMPS) && !defined(HADI_EMU)
+// Diagnostic build only (tools/stamps.py): per-phase cycle sums of the row pass, never in the product.
+// Each wavefront accumulates its own sums and adds them to the global array once, at kernel end.
+__device__ unsigned long long g_hadi_stamps[32];
+#define HADI_STAMP_ACC unsigned long long *stamp_acc_;
+#define HADI_STAMP_DECL(accptr) unsigned long long *sacc_ = (accptr); unsigned long long stamp_prev_; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev_) :: "memory");
+#define HADI_STAMP(k) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    sacc_[k] += t_ - stamp_prev_; stamp_prev_ = t_; } while (0)
+#else
+#define HADI_STAMP_ACC
+#define HADI_STAMP_DECL(accptr)
+#define HADI_STAMP(k)
+#endif
+
 // ---- LDS row ring helpers ---------------------------------------------------------------------------
-// Asynchronous copy of one state row (rowp doubles, HBM layout == LDS layout) into the ring: LDS-DMA
-// (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPRs); it completes before the next
-// __syncthreads(), which drains vmcnt.  Rows outside the allocation are written as zeros instead.
+// Asynchronous copy of one state row (rowp doubles, HBM layout == LDS layout) into the ring by LDS-DMA
+// (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPRs).  Issued through inline asm on purpose:
+// with the builtin hipcc sees an LDS write and puts s_waitcnt vmcnt(0) in front of the very next ds_read
+// (it cannot know the ring slots differ), which serialises the prefetch with the row it should overlap.
+// The asm form is invisible to that bookkeeping, so completion is OUR job: hadi_dma_wait() + barrier
+// before anyone reads the rows (cdna_hip_programming.md 5.7).  Rows outside the allocation are zeros.
 HADI_DEV HADI_FORCEINLINE void hadi_row_to_lds(const double *__restrict__ grow, double *lrow, int rowp, int lane,
                                                bool exists) {
     const int nvec = rowp >> 1;  // 16-byte vectors per row
@@ -108,8 +127,15 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_to_lds(const double *__restrict__ grow, 
                 lrow[2 * (v0 + lane)] = grow[2 * (v0 + lane)];
                 lrow[2 * (v0 + lane) + 1] = grow[2 * (v0 + lane) + 1];
 #else
-                __builtin_amdgcn_global_load_lds((const void *)(grow + 2 * (v0 + lane)),
-                                                 (__attribute__((address_space(3))) void *)(lrow + 2 * v0), 16, 0, 0);
+                const double *gsrc = grow + 2 * (v0 + lane);
+                // wave-uniform LDS byte address of this 1 KiB piece; the hardware adds lane*16
+                const unsigned lds_dst = __builtin_amdgcn_readfirstlane(
+                    (unsigned)(size_t)(__attribute__((address_space(3))) char *)(lrow + 2 * v0));
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(gsrc), "s"(lds_dst)
+                             : "memory");
 #endif
             }
         }
@@ -119,6 +145,23 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_to_lds(const double *__restrict__ grow, 
             lrow[2 * v + 1] = 0.0;
         }
     }
+}
+
+// Wait until this wavefront's LDS-DMA transfers have completed; pair with a barrier.  vmcnt retires in
+// issue order, and a wave that solved a row issued KEEP result stores AFTER its DMA: those may stay in
+// flight (waiting for their write acknowledgements costs microseconds under load).
+template <int KEEP>
+HADI_DEV HADI_FORCEINLINE void hadi_dma_wait(bool stores_behind) {
+#if !defined(HADI_EMU)
+    if (stores_behind) {
+        if constexpr (KEEP == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if constexpr (KEEP == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if constexpr (KEEP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#endif
 }
 
 template <int B>
@@ -148,10 +191,12 @@ struct HadiRowCtx {
     double *xch;         // LDS: [W][4] boundary exchange between the two waves of a row (G = 2)
     double *Yi;          // instance base of Y
     const double *Li;    // instance base of lambda_bar (American)
-    const double *rowc;  // instance base of the row table
+    const double *rowc;  // LDS copy of the row table of this block's tile: entry (j - j0)
+    int j0;              // first v-row of the tile
     const double *b2r;   // instance b2 row (global)
     int lane, half, wrow, posL, posR, rowp;
     double dt, thdt, qd, half_rd, e_nm1, e_n;
+    HADI_STAMP_ACC
 };
 
 // Loads this lane's B values of a row-layout array (LDS or global): pair q at q*128*G + 128*half + 2*lane.
@@ -199,8 +244,11 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtx &c, bool active, i
     double ys[B], ps[B], gs[B], A2U[B], b2v[B];
     double Ysol = 0.0, Ssol = 0.0, yout_c0 = 0.0;
 
+    HADI_STAMP_DECL(c.stamp_acc_)
     if (active) {
-        const double *__restrict__ rc = c.rowc + (size_t)j * HADI_RC;
+        // (LDS, not global: an ordinary global load here would make hipcc drain the in-flight LDS-DMA
+        // prefetch with vmcnt(0) at the start of every row)
+        const double *rc = c.rowc + (size_t)(j - c.j0) * HADI_RC;
         const double v = rc[RC_V];
         const double wm = rc[RC_WM], wz = rc[RC_WZ], wp = rc[RC_WP];
         const double a2l2 = rc[RC_L2], a2l1 = rc[RC_L1], a2m = rc[RC_M], a2u1 = rc[RC_U1], a2u2 = rc[RC_U2];
@@ -224,6 +272,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtx &c, bool active, i
         const double x0 = y0c0;  // A1 row 0 is the identity (hes_a1_kernels.hpp:56-61)
         yout_c0 = x0 + thdt * (b2c0 * e_n - (a2c0 + b2c0 * e_nm1));
 
+        HADI_STAMP(0);  // row scalars + column 0
         // ---- explicit operators.  A0 = (s-derivative) o (v-derivative): first the v-combination
         // t = wm u(j-1) + wz u(j) + wp u(j+1) on the block and its two s-neighbours, then the B-weights.
         double u0[B], tt[B];
@@ -249,6 +298,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtx &c, bool active, i
         const double tL = wm * rm1[c.posL] + wz * u0L + wp * rp1[c.posL];
         const double tR = wm * rm1[c.posR] + wz * u0R + wp * rp1[c.posR];
 
+        HADI_STAMP(1);  // LDS rows -> tt, A2U
         double lam[B];
         if constexpr (AMER) hadi_get_block<B, G>(c.Li + (size_t)j * rowp, half, lane, lam);
         if constexpr (LAST) hadi_get_block<B, G>(c.b2r, half, lane, b2v);
@@ -307,6 +357,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtx &c, bool active, i
                 d_last = y;
             }
         }
+        HADI_STAMP(2);  // coefficients + Y0 + forward Thomas
         // reduced (interface) row of this lane:  ra*X(l-1) + rb*X(l) + rcc*X(l+1) = rf [- rs * boundary value]
         double ra, rb, rcc, rf, rs = 0.0;
         const bool edge_hi = (G > 1) && !last_half && lane == 63;  // next node belongs to the other wave
@@ -338,6 +389,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtx &c, bool active, i
             if (edge_hi) { rs = iu[B - 1]; rcc = 0.0; }  // couples to t = first node of the other half
             if (edge_lo) { rs = ra; ra = 0.0; }          // couples to the last node of the other half
         }
+        HADI_STAMP(3);  // backward Thomas + reduced row
         // ---- parallel cyclic reduction over the 64 interface unknowns (normalised rows) -------------
         // Lanes without a partner at distance s have ra == 0 (left) / rcc == 0 (right) by induction, so the
         // (wrapped) values they fetch are multiplied by zero: no lane masks are needed.
@@ -367,6 +419,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtx &c, bool active, i
                 }
             }
         }
+        HADI_STAMP(4);  // PCR
         Ysol = rf;
         Ssol = rs;
         if constexpr (G > 1) {
@@ -415,6 +468,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtx &c, bool active, i
         }
         hadi_put_block<B, G>(c.Yi + (size_t)j * rowp, half, lane, yo);
         if (lane == 0 && first_half) c.Yi[(size_t)j * rowp + c0slot] = yout_c0;
+        HADI_STAMP(5);  // final correction + store
     }
 }
 
@@ -447,8 +501,8 @@ __global__ void __launch_bounds__(64 * W * G, (B >= 8 ? 2 : 4)) hadi_pass_a(Hadi
     const double *__restrict__ Ub = a.U + (size_t)inst * a.L.inst_stride;
     c.Yi = a.Y + (size_t)inst * a.L.inst_stride;
     c.Li = AMER ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
-    c.rowc = a.rowc + (size_t)inst * nrows * HADI_RC;
     c.b2r = a.b2row + (size_t)inst * rowp;
+    c.j0 = j0;
     constexpr int c0slot = 64 * B * G;
     // storage positions of the s-neighbours of this lane's block (node before its first, node after its
     // last).  Before i = 1 comes the i = 0 slot; after the row's last node comes a pad slot (always 0).
@@ -458,7 +512,7 @@ __global__ void __launch_bounds__(64 * W * G, (B >= 8 ? 2 : 4)) hadi_pass_a(Hadi
         c.posR = (ifirst + B <= 64 * B * G) ? hadi_pos(B, G, ifirst + B) : c0slot + 1;
     }
 
-    // LDS: [RING rows of rowp] [4 coefficient arrays of 64*B*G] [W*4 exchange]
+    // LDS: [RING rows of rowp] [4 coefficient arrays of 64*B*G] [W*4 exchange] [row table of the tile]
     double *coef = smem + (size_t)RING * rowp;
     {
         const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B * G;
@@ -466,18 +520,35 @@ __global__ void __launch_bounds__(64 * W * G, (B >= 8 ? 2 : 4)) hadi_pass_a(Hadi
     }
     c.coef = coef;
     c.xch = coef + 4 * 64 * B * G;
+    {
+        double *rtab = c.xch + 4 * W;
+        const double *__restrict__ rg = a.rowc + ((size_t)inst * nrows + j0) * HADI_RC;
+        for (int e = threadIdx.x; e < (j1 - j0) * HADI_RC; e += 64 * W * G) rtab[e] = rg[e];
+        c.rowc = rtab;
+    }
 
     auto slot = [&](int jj) { return smem + (size_t)((jj + RING) % RING) * rowp; };
     auto fetch = [&](int jj) { hadi_row_to_lds(Ub + (size_t)jj * rowp, slot(jj), rowp, lane, jj >= 0 && jj < npad); };
     for (int rr = wave; rr < W + 4; rr += W * G) fetch(j0 - 2 + rr);
 
     const int iters = (j1 - j0 + W - 1) / W;
+    bool stored = false;  // did this wave issue result stores after its last DMA?
+#if defined(HADI_STAMPS) && !defined(HADI_EMU)
+    unsigned long long stamp_store_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    c.stamp_acc_ = stamp_store_;
+#endif
+    HADI_STAMP_DECL(stamp_store_)
+    HADI_STAMP(8);  // prologue
     for (int it = 0; it < iters; it++) {
         const int J = j0 + it * W;
+        // a row step issues B/2 (one for B = 1) vector stores of its block (+ possibly the i = 0 node)
+        hadi_dma_wait<(B == 1 ? 1 : B / 2)>(stored);
         __syncthreads();  // this iteration's rows have landed; everyone is done with the rows replaced below
+        HADI_STAMP(9);  // barrier wait (incl. DMA drain)
         if (it + 1 < iters && wave < W) fetch(J + W + 2 + wave);
         const int j = J + wrow;
         const bool active = j < j1;
+        stored = active;
         if constexpr (G == 1) {
             if (!active) continue;
         }
@@ -485,7 +556,12 @@ __global__ void __launch_bounds__(64 * W * G, (B >= 8 ? 2 : 4)) hadi_pass_a(Hadi
             hadi_row_step<B, G, AMER, true>(c, active, j, slot(j - 2), slot(j - 1), slot(j), slot(j + 1), slot(j + 2));
         else
             hadi_row_step<B, G, AMER, false>(c, active, j, slot(j - 2), slot(j - 1), slot(j), slot(j + 1), slot(j + 2));
+        HADI_STAMP(10);  // whole row step (+ fetch issue)
     }
+#if defined(HADI_STAMPS) && !defined(HADI_EMU)
+    if (lane == 0)
+        for (int k = 0; k < 12; k++) atomicAdd(&g_hadi_stamps[k], stamp_store_[k]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

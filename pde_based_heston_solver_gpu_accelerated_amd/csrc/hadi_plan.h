@@ -46,7 +46,7 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
     ntiles = (L.nrows + R - 1) / R;
     p.R = R;
     p.ntiles = ntiles;
-    p.smem_a = ((size_t)(2 * W + 4) * L.rowp + (size_t)4 * 64 * L.B * L.G + 4 * W) * sizeof(double);
+    p.smem_a = ((size_t)(2 * W + 4) * L.rowp + (size_t)4 * 64 * L.B * L.G + 4 * W + (size_t)R * HADI_RC) * sizeof(double);
     const long long total = (long long)n_inst * ntiles;
     p.grid_a = (int)((total + 7) / 8 * 8);
     p.ctiles = (L.rowp + 63) / 64;

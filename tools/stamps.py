@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Diagnostic (not product): builds libhadi with -DHADI_STAMPS into tools/_stamps/ and prints where a
+row-pass wavefront spends its cycles (shares, not absolute speed -- the stamps serialise the phases)."""
+import ctypes as C, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+out = os.path.join(ROOT, "tools", "_stamps"); os.makedirs(out, exist_ok=True)
+lib = os.path.join(out, "libhadi.so")
+subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DHADI_STAMPS",
+                       "-o", lib, os.path.join(ROOT, "pde_based_heston_solver_gpu_accelerated_amd", "csrc", "hadi_api.hip")])
+import pde_based_heston_solver_gpu_accelerated_amd._native as nat
+nat.LIB_PATH = lib
+import pde_based_heston_solver_gpu_accelerated_amd as H
+import numpy as np, torch
+n, m1, m2, N = int(sys.argv[1]) if len(sys.argv) > 1 else 256, 512, 256, 20
+strikes = [85 + 30 * k / (n - 1) for k in range(n)]
+g = H.GridViewsBatch.for_strikes(m1, m2, 100.0, 0.04, strikes); U0 = g.call_payoff(strikes)
+dev = torch.device("cuda:0"); gd = g.to(dev); U = torch.from_numpy(U0).to(dev)
+s = H.HestonADI(0)
+L = nat.lib(); L.hadi_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+buf = (C.c_ulonglong * 32)()
+s.DO_timestepping(m1, m2, N, 1.0 / 1000, 0.8, 0.025, 0.0, -0.9, 0.3, 1.5, 0.04, gd, U)
+L.hadi_debug_stamps(buf, 1)
+s.DO_timestepping(m1, m2, N, 1.0 / 1000, 0.8, 0.025, 0.0, -0.9, 0.3, 1.5, 0.04, gd, U)
+L.hadi_debug_stamps(buf, 1)
+names = {0: "row scalars + col0", 1: "LDS rows -> tt,A2U", 2: "coef + Y0 + fwd Thomas", 3: "bwd Thomas + reduced row",
+         4: "PCR", 5: "final + store", 8: "prologue", 9: "barrier wait", 10: "row step total (+fetch issue)"}
+rows = n * 257 * N
+tot = sum(buf[k] for k in (8, 9, 10))
+print("sweep_ms", s.timing()["sweep_ms"])
+for k, nm in names.items():
+    print("%-32s %8.0f cycles/row  %5.1f %%" % (nm, buf[k] / rows, 100.0 * buf[k] / tot))
