@@ -147,8 +147,10 @@ hipError_t raise_all_lds_limits() {
     if ((e = raise_pass_a<4, 1>()) != hipSuccess) return e;
     if ((e = raise_pass_a<8, 1>()) != hipSuccess) return e;
     if ((e = raise_pass_a<8, 2>()) != hipSuccess) return e;
-    if ((e = raise_lds_limit(hadi_pass_b<8>)) != hipSuccess) return e;
-    return raise_lds_limit(hadi_pass_b<16>);
+    if ((e = raise_lds_limit(hadi_pass_b<8, false>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_b<8, true>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_b<16, false>)) != hipSuccess) return e;
+    return raise_lds_limit(hadi_pass_b<16, true>);
 }
 
 int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
@@ -250,8 +252,13 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
             HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 1], s));
             HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 2], s));
         }
-        if (L.P <= 8) hipLaunchKernelGGL(hadi_pass_b<8>, dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, s, a, nstep);
-        else hipLaunchKernelGGL(hadi_pass_b<16>, dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, s, a, nstep);
+        if (L.P <= 8) {
+            if (american) hipLaunchKernelGGL((hadi_pass_b<8, true>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, s, a, nstep);
+            else hipLaunchKernelGGL((hadi_pass_b<8, false>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, s, a, nstep);
+        } else {
+            if (american) hipLaunchKernelGGL((hadi_pass_b<16, true>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, s, a, nstep);
+            else hipLaunchKernelGGL((hadi_pass_b<16, false>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, s, a, nstep);
+        }
         if (prof) HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 3], s));
     }
     HIP_TRY(c, hipGetLastError());

@@ -101,13 +101,44 @@ __device__ unsigned long long g_hadi_stamps[32];
 #define HADI_STAMP_ACC unsigned long long *stamp_acc_;
 #define HADI_STAMP_DECL(accptr) unsigned long long *sacc_ = (accptr); unsigned long long stamp_prev_; \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev_) :: "memory");
-#define HADI_STAMP(k) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+// HADI_STAMPS=1: only the per-iteration stamps (8, 9, 10; small perturbation); 2: also the row phases
+#define HADI_STAMP(k) do { if ((k) >= 8 || HADI_STAMPS >= 2) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
-    sacc_[k] += t_ - stamp_prev_; stamp_prev_ = t_; } while (0)
+    sacc_[k] += t_ - stamp_prev_; stamp_prev_ = t_; } } while (0)
 #else
 #define HADI_STAMP_ACC
 #define HADI_STAMP_DECL(accptr)
 #define HADI_STAMP(k)
+#endif
+
+// ---- buffer addressing: wave-uniform base + scalar row offset + one per-lane 32-bit offset ----------
+// (raw buffer loads/stores take the row offset in an SGPR, so walking down a column costs no VALU
+// address arithmetic and no address VGPR pairs: cdna_hip_programming.md T8)
+#if defined(HADI_EMU)
+struct HadiBuf { const double *p; };
+HADI_DEV HADI_FORCEINLINE HadiBuf hadi_make_buf(const double *base, size_t) { return HadiBuf{base}; }
+HADI_DEV HADI_FORCEINLINE double hadi_buf_load(HadiBuf b, unsigned voff_bytes, unsigned soff_bytes) {
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(b.p) + voff_bytes + soff_bytes);
+}
+HADI_DEV HADI_FORCEINLINE void hadi_buf_store(HadiBuf b, unsigned voff_bytes, unsigned soff_bytes, double v) {
+    *reinterpret_cast<double *>(const_cast<char *>(reinterpret_cast<const char *>(b.p)) + voff_bytes + soff_bytes) = v;
+}
+#else
+typedef unsigned hadi_u32x2 __attribute__((ext_vector_type(2)));
+struct HadiBuf { __amdgpu_buffer_rsrc_t r; };
+HADI_DEV HADI_FORCEINLINE HadiBuf hadi_make_buf(const double *base, size_t bytes) {
+    return HadiBuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base), 0, (int)bytes, 0x00020000)};
+}
+HADI_DEV HADI_FORCEINLINE double hadi_buf_load(HadiBuf b, unsigned voff_bytes, unsigned soff_bytes) {
+    const hadi_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(b.r, voff_bytes, soff_bytes, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+HADI_DEV HADI_FORCEINLINE void hadi_buf_store(HadiBuf b, unsigned voff_bytes, unsigned soff_bytes, double v) {
+    hadi_u32x2 d;
+    d.x = (unsigned)__double2loint(v);
+    d.y = (unsigned)__double2hiint(v);
+    __builtin_amdgcn_raw_buffer_store_b64(d, b.r, voff_bytes, soff_bytes, 0);
+}
 #endif
 
 // ---- LDS row ring helpers ---------------------------------------------------------------------------
@@ -573,6 +604,7 @@ __global__ void __launch_bounds__(64 * W * G, (B >= 8 ? 2 : 4)) hadi_pass_a(Hadi
 struct HadiPassBCtx {
     const double *Yi;   // instance base of Y
     double *Ui;         // instance base of U
+    HadiBuf Yb, Ub;     // the same two as buffer resources (uniform)
     double *Li;         // instance base of lambda_bar (American)
     const double *P0i;  // instance base of the payoff (American)
     const double *pb;   // this chunk's table in LDS
@@ -585,11 +617,13 @@ struct HadiPassBCtx {
 HADI_DEV HADI_FORCEINLINE void hadi_pb_load(const HadiPassBCtx &c, int ctile, double (&y)[HADI_LC]) {
     const int col = ctile * 64 + c.lane;
     const int colc = col < c.rowp ? col : c.rowp - 1;  // lanes past the pitch read a valid address, never store
-    const double *__restrict__ src = c.Yi + (size_t)c.ja * c.rowp + colc;
+    const unsigned voff = (unsigned)colc * 8u;
+    const unsigned row0 = (unsigned)c.ja * (unsigned)c.rowp * 8u, rstride = (unsigned)c.rowp * 8u;
 #pragma unroll
-    for (int k = 0; k < HADI_LC; k++) y[k] = src[(size_t)k * c.rowp];
+    for (int k = 0; k < HADI_LC; k++) y[k] = hadi_buf_load(c.Yb, voff, row0 + (unsigned)k * rstride);
 }
 
+template <bool AMER>
 HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ctile, int parity, double (&y)[HADI_LC]) {
     const double *__restrict__ pb = c.pb;
     // forward elimination with the chunk-local factorisation
@@ -650,11 +684,12 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ct
     const bool valid = col < c.rowp;
     const int colc = valid ? col : c.rowp - 1;
     const size_t base = (size_t)c.ja * c.rowp + colc;
-    if (!c.american) {
-        double *__restrict__ dst = c.Ui + base;
+    if constexpr (!AMER) {
+        const unsigned voff = (unsigned)colc * 8u;
+        const unsigned row0 = (unsigned)c.ja * (unsigned)c.rowp * 8u, rstride = (unsigned)c.rowp * 8u;
         if (valid) {
 #pragma unroll
-            for (int k = 0; k < HADI_LC; k++) dst[(size_t)k * c.rowp] = y[k];
+            for (int k = 0; k < HADI_LC; k++) hadi_buf_store(c.Ub, voff, row0 + (unsigned)k * rstride, y[k]);
         }
     } else {
         // Ikonen-Toivanen projection, device_solver.hpp:358-372
@@ -682,7 +717,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ct
 
 // Dynamic LDS: P * (2*4*64 + HADI_LC*HADI_PBW) doubles (two interface-exchange buffers + the chunk tables).
 // MAXP only sets the launch bound (register budget): 8 -> 512 threads, 16 -> 1024 threads.
-template <int MAXP>
+template <int MAXP, bool AMER>
 __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n) {
     HADI_DYN_SMEM(double, smem);
     HadiPassBCtx c;
@@ -699,8 +734,10 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
     c.ja = c.wave * HADI_LC;
     c.Yi = a.Y + (size_t)inst * a.L.inst_stride;
     c.Ui = a.U + (size_t)inst * a.L.inst_stride;
-    c.Li = a.american ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
-    c.P0i = a.american ? a.U0 + (size_t)inst * a.L.inst_stride : nullptr;
+    c.Yb = hadi_make_buf(c.Yi, (size_t)a.L.inst_stride * sizeof(double));
+    c.Ub = hadi_make_buf(c.Ui, (size_t)a.L.inst_stride * sizeof(double));
+    c.Li = AMER ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
+    c.P0i = AMER ? a.U0 + (size_t)inst * a.L.inst_stride : nullptr;
     c.Ri = a.rinv + (size_t)inst * 16 * c.P * c.P;
     c.american = a.american;
     c.pos_m1 = a.pos_m1;
@@ -721,9 +758,9 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
     __syncthreads();
     for (int t = t0; t < t1; t += 2) {
         if (t + 1 < t1) hadi_pb_load(c, t + 1, yb);
-        hadi_pb_solve_store(c, t, 0, ya);
+        hadi_pb_solve_store<AMER>(c, t, 0, ya);
         if (t + 2 < t1) hadi_pb_load(c, t + 2, ya);
-        if (t + 1 < t1) hadi_pb_solve_store(c, t + 1, 1, yb);
+        if (t + 1 < t1) hadi_pb_solve_store<AMER>(c, t + 1, 1, yb);
     }
 }
 

@@ -85,7 +85,8 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
             case 82: run_pass_a<8, 2>(pl, a, n); break;
             default: return 2;
         }
-        emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b<16>(a, n); }, pl.smem_b);
+        if (a.american) emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b<16, true>(a, n); }, pl.smem_b);
+        else emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b<16, false>(a, n); }, pl.smem_b);
     }
     emu::launch(8, 64, [&]() { hadi_unpack_kernel(L, n_inst, dU.data(), U); });
     if (american && lam_out) emu::launch(8, 64, [&]() { hadi_unpack_kernel(L, n_inst, dLAM.data(), lam_out); });

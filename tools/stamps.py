@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 out = os.path.join(ROOT, "tools", "_stamps"); os.makedirs(out, exist_ok=True)
 lib = os.path.join(out, "libhadi.so")
-subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DHADI_STAMPS",
+subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DHADI_STAMPS=%s" % os.environ.get("STAMP_LEVEL", "2"),
                        "-o", lib, os.path.join(ROOT, "pde_based_heston_solver_gpu_accelerated_amd", "csrc", "hadi_api.hip")])
 import pde_based_heston_solver_gpu_accelerated_amd._native as nat
 nat.LIB_PATH = lib
