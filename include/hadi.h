@@ -125,6 +125,9 @@ const char *hadi_status_string(int status);
 int hadi_version(void);
 int hadi_set_profiling(hadi_ctx *ctx, int enabled);
 int hadi_get_timing(const hadi_ctx *ctx, hadi_timing *out);
+/* Execution-path switches (results are unaffected): "small_grid" = LDS-resident one-launch path for grids that
+ * fit in LDS (default 1), "graph" = hipGraph replay of the time loop for small batches (default 1). */
+int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value);
 /* Device the handle runs on: name, CU count, gcn arch string (for bench reports). */
 int hadi_device_info(const hadi_ctx *ctx, char *name, int name_len, int *compute_units, char *arch, int arch_len);
 /* Opaque hipStream_t of the handle (void*), so callers can order their own work after it. */

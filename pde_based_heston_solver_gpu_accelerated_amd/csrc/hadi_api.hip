@@ -39,6 +39,13 @@ struct Ctx {
     DevBuf g_s, g_v, g_ds, g_dv;      // grids owned by the library (staged / broadcast)
     DevBuf src_v, src_dv, sel_a, sel_b, v0_i;
     DevBuf natU, natU0, natOut, prices, status;
+    // hipGraph cache for the time loop (2 launches per step: launch-bound for small batches)
+    struct GraphEntry { std::string key; hipGraph_t graph; hipGraphExec_t exec; unsigned long long stamp; };
+    std::vector<GraphEntry> graphs;
+    unsigned long long graph_clock = 0;
+    int use_graph = 1;
+    int use_small = 1;  // LDS-resident one-launch path for small grids
+    DevBuf div_flag, div_amt, div_pct;
 };
 
 int fail(Ctx *c, int code, const char *fmt, ...) {
@@ -147,6 +154,10 @@ hipError_t raise_all_lds_limits() {
     if ((e = raise_pass_a<4, 1>()) != hipSuccess) return e;
     if ((e = raise_pass_a<8, 1>()) != hipSuccess) return e;
     if ((e = raise_pass_a<8, 2>()) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_small_kernel<1, 4, false>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_small_kernel<1, 4, true>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_small_kernel<2, 4, false>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_small_kernel<2, 4, true>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b<8, false>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b<8, true>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b<16, false>)) != hipSuccess) return e;
@@ -226,40 +237,133 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
             c->kev.push_back(e);
         }
     }
-    HIP_TRY(c, hipEventRecord(c->ev[1], s));
-    int cur = 0;
-    for (int nstep = 1; nstep <= d.Nmax; nstep++) {
-        if (dividend) {
-            // device_solver.hpp:426-447,508-516; n*delta_t in floating point decides the step
-            const double t = nstep * d.dt0;
-            if (cur < d.num_div && t <= d.div_dates[cur] && d.div_dates[cur] < (nstep + 1) * d.dt0) {
-                HIP_TRY(c, hipMemcpyAsync(c->UT.p, c->U.p, st, hipMemcpyDeviceToDevice, s));
-                const size_t npts = (size_t)d.n * L.nrows * (L.m1 + 1);
-                hipLaunchKernelGGL(hadi_dividend_kernel, dim3(grid1d(npts)), dim3(256), 0, s, L, d.n, d.d_vec_s,
-                                   ptr<double>(c->UT), ptr<double>(c->U), d.div_amounts[cur], d.div_pcts[cur]);
+    // The whole time loop as a function of the stream, so it can be enqueued directly or captured.
+    auto enqueue_loop = [&](hipStream_t q) -> int {
+        int cur = 0;
+        for (int nstep = 1; nstep <= d.Nmax; nstep++) {
+            if (dividend) {
+                // device_solver.hpp:426-447,508-516; n*delta_t in floating point decides the step
+                const double t = nstep * d.dt0;
+                if (cur < d.num_div && t <= d.div_dates[cur] && d.div_dates[cur] < (nstep + 1) * d.dt0) {
+                    HIP_TRY(c, hipMemcpyAsync(c->UT.p, c->U.p, st, hipMemcpyDeviceToDevice, q));
+                    const size_t npts = (size_t)d.n * L.nrows * (L.m1 + 1);
+                    hipLaunchKernelGGL(hadi_dividend_kernel, dim3(grid1d(npts)), dim3(256), 0, q, L, d.n, d.d_vec_s,
+                                       ptr<double>(c->UT), ptr<double>(c->U), d.div_amounts[cur], d.div_pcts[cur]);
+                }
+                if (cur < d.num_div && t > d.div_dates[cur]) cur++;
             }
-            if (cur < d.num_div && t > d.div_dates[cur]) cur++;
+            if (prof) HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 0], q));
+            switch (L.B * 10 + L.G) {
+                case 11: launch_pass_a<1, 1>(pl, a, nstep, q); break;
+                case 21: launch_pass_a<2, 1>(pl, a, nstep, q); break;
+                case 41: launch_pass_a<4, 1>(pl, a, nstep, q); break;
+                case 81: launch_pass_a<8, 1>(pl, a, nstep, q); break;
+                default: launch_pass_a<8, 2>(pl, a, nstep, q); break;
+            }
+            if (prof) {
+                HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 1], q));
+                HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 2], q));
+            }
+            if (L.P <= 8) {
+                if (american) hipLaunchKernelGGL((hadi_pass_b<8, true>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, q, a, nstep);
+                else hipLaunchKernelGGL((hadi_pass_b<8, false>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, q, a, nstep);
+            } else {
+                if (american) hipLaunchKernelGGL((hadi_pass_b<16, true>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, q, a, nstep);
+                else hipLaunchKernelGGL((hadi_pass_b<16, false>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, q, a, nstep);
+            }
+            if (prof) HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 3], q));
         }
-        if (prof) HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 0], s));
-        switch (L.B * 10 + L.G) {
-            case 11: launch_pass_a<1, 1>(pl, a, nstep, s); break;
-            case 21: launch_pass_a<2, 1>(pl, a, nstep, s); break;
-            case 41: launch_pass_a<4, 1>(pl, a, nstep, s); break;
-            case 81: launch_pass_a<8, 1>(pl, a, nstep, s); break;
-            default: launch_pass_a<8, 2>(pl, a, nstep, s); break;
+        return HADI_OK;
+    };
+
+    // ---- small grids: the whole instance fits in LDS -> one launch runs the entire time loop ----------
+    const size_t smem_small = american ? pl.smem_small_am : pl.smem_small_eu;
+    if (c->use_small && !prof && smem_small > 0) {
+        HadiSmallArgs sm;
+        sm.div_flag = nullptr; sm.div_amounts = nullptr; sm.div_pcts = nullptr; sm.vec_s = d.d_vec_s; sm.Nmax = d.Nmax;
+        std::vector<int> flags;
+        if (dividend && d.num_div > 0) {
+            flags.assign(d.Nmax, -1);
+            int cur = 0;
+            for (int nstep = 1; nstep <= d.Nmax; nstep++) {  // device_solver.hpp:426-447,508-516
+                const double t = nstep * d.dt0;
+                if (cur < d.num_div && t <= d.div_dates[cur] && d.div_dates[cur] < (nstep + 1) * d.dt0) flags[nstep - 1] = cur;
+                if (cur < d.num_div && t > d.div_dates[cur]) cur++;
+            }
+            if ((rc = ensure(c, c->div_flag, d.Nmax * sizeof(int))) || (rc = ensure(c, c->div_amt, d.num_div * 8)) ||
+                (rc = ensure(c, c->div_pct, d.num_div * 8)))
+                return rc;
+            HIP_TRY(c, hipMemcpyAsync(c->div_flag.p, flags.data(), d.Nmax * sizeof(int), hipMemcpyHostToDevice, s));
+            HIP_TRY(c, hipMemcpyAsync(c->div_amt.p, d.div_amounts, d.num_div * 8, hipMemcpyHostToDevice, s));
+            HIP_TRY(c, hipMemcpyAsync(c->div_pct.p, d.div_pcts, d.num_div * 8, hipMemcpyHostToDevice, s));
+            sm.div_flag = ptr<int>(c->div_flag); sm.div_amounts = ptr<double>(c->div_amt); sm.div_pcts = ptr<double>(c->div_pct);
         }
-        if (prof) {
-            HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 1], s));
-            HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 2], s));
-        }
-        if (L.P <= 8) {
-            if (american) hipLaunchKernelGGL((hadi_pass_b<8, true>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, s, a, nstep);
-            else hipLaunchKernelGGL((hadi_pass_b<8, false>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, s, a, nstep);
+        HIP_TRY(c, hipEventRecord(c->ev[1], s));
+        if (L.B == 1) {
+            if (american) hipLaunchKernelGGL((hadi_small_kernel<1, 4, true>), dim3(d.n), dim3(256), smem_small, s, a, sm);
+            else hipLaunchKernelGGL((hadi_small_kernel<1, 4, false>), dim3(d.n), dim3(256), smem_small, s, a, sm);
         } else {
-            if (american) hipLaunchKernelGGL((hadi_pass_b<16, true>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, s, a, nstep);
-            else hipLaunchKernelGGL((hadi_pass_b<16, false>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, s, a, nstep);
+            if (american) hipLaunchKernelGGL((hadi_small_kernel<2, 4, true>), dim3(d.n), dim3(256), smem_small, s, a, sm);
+            else hipLaunchKernelGGL((hadi_small_kernel<2, 4, false>), dim3(d.n), dim3(256), smem_small, s, a, sm);
         }
-        if (prof) HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 3], s));
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(c->ev[2], s));
+        if (!flags.empty()) HIP_TRY(c, hipStreamSynchronize(s));  // host staging vector leaves scope
+        return HADI_OK;
+    }
+
+    HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    // Small batches are launch-bound (2*N dependent launches of a few microseconds each): replay the loop
+    // from a cached hipGraph.  Every kernel argument is baked into the nodes, so the key is everything they
+    // depend on; the library's own buffers are stable between calls.
+    const bool graphable = c->use_graph && !prof && (long long)d.n * L.inst_stride <= (8ll << 20);
+    if (graphable) {
+        std::string key;
+        auto put = [&](const void *p_, size_t nbytes) { key.append(static_cast<const char *>(p_), nbytes); };
+        {  // field by field: struct padding is not initialised
+            const void *ptrs[] = {a.U, a.Y, a.LAM, a.U0, a.scoef, a.b2row, a.rowc, a.pb, a.rinv, a.ipar};
+            const int ints[] = {a.L.m1, a.L.m2, a.L.B, a.L.G, a.L.P, a.n_inst, a.R, a.ntiles, a.ctiles, a.btpw, a.bgroups,
+                                a.american, a.pos_m1, pl.grid_a, pl.grid_b, pl.block_b, pl.W, (int)pl.smem_a, (int)pl.smem_b};
+            put(ptrs, sizeof(ptrs));
+            put(ints, sizeof(ints));
+        }
+        put(&d.Nmax, sizeof(int)); put(&d.dt0, sizeof(double));
+        put(&d.variant, sizeof(int)); put(&d.d_vec_s, sizeof(void *));
+        void *ut = c->UT.p; put(&ut, sizeof(ut));
+        if (dividend) {
+            put(&d.num_div, sizeof(int));
+            put(d.div_dates, d.num_div * sizeof(double));
+            put(d.div_amounts, d.num_div * sizeof(double));
+            put(d.div_pcts, d.num_div * sizeof(double));
+        }
+        Ctx::GraphEntry *hit = nullptr;
+        for (auto &g : c->graphs)
+            if (g.key == key) { hit = &g; break; }
+        if (!hit) {
+            if (c->graphs.size() >= 8) {  // evict the least recently used entry
+                size_t lru = 0;
+                for (size_t k = 1; k < c->graphs.size(); k++)
+                    if (c->graphs[k].stamp < c->graphs[lru].stamp) lru = k;
+                (void)hipGraphExecDestroy(c->graphs[lru].exec);
+                (void)hipGraphDestroy(c->graphs[lru].graph);
+                c->graphs.erase(c->graphs.begin() + lru);
+            }
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            HIP_TRY(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            const int rcl = enqueue_loop(s);
+            hipError_t ec = hipStreamEndCapture(s, &graph);
+            if (rcl) return rcl;
+            HIP_TRY(c, ec);
+            HIP_TRY(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            c->graphs.push_back(Ctx::GraphEntry{key, graph, exec, 0});
+            hit = &c->graphs.back();
+        }
+        hit->stamp = ++c->graph_clock;
+        HIP_TRY(c, hipGraphLaunch(hit->exec, s));
+    } else {
+        const int rcl = enqueue_loop(s);
+        if (rcl) return rcl;
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
@@ -582,6 +686,8 @@ int hadi_create(hadi_ctx **out, int device_id) {
     c->arch = prop.gcnArchName;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return HADI_ERR_HIP; }
     if (raise_all_lds_limits() != hipSuccess) { delete c; return HADI_ERR_HIP; }
+    if (const char *e = std::getenv("HADI_NO_GRAPH")) c->use_graph = std::atoi(e) ? 0 : 1;
+    if (const char *e = std::getenv("HADI_NO_SMALL")) c->use_small = std::atoi(e) ? 0 : 1;
     for (auto &e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete c; return HADI_ERR_HIP; }
     *out = reinterpret_cast<hadi_ctx *>(c);
@@ -596,9 +702,10 @@ int hadi_destroy(hadi_ctx *ctx) {
     DevBuf *bufs[] = {&c->U, &c->Y, &c->LAM, &c->U0, &c->UT, &c->scoef, &c->b2row, &c->rowc, &c->a2i, &c->pb,
                       &c->rinv, &c->rwork, &c->ipar, &c->par8, &c->g_s, &c->g_v, &c->g_ds, &c->g_dv, &c->src_v,
                       &c->src_dv, &c->sel_a, &c->sel_b, &c->v0_i, &c->natU, &c->natU0, &c->natOut, &c->prices,
-                      &c->status};
+                      &c->status, &c->div_flag, &c->div_amt, &c->div_pct};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
+    for (auto &g : c->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
     for (auto e : c->kev) (void)hipEventDestroy(e);
     for (auto e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -616,6 +723,15 @@ int hadi_set_profiling(hadi_ctx *ctx, int enabled) {
     Ctx *c = reinterpret_cast<Ctx *>(ctx);
     if (!c) return HADI_ERR_INVALID;
     c->profiling = enabled ? 1 : 0;
+    return HADI_OK;
+}
+
+int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c || !key) return HADI_ERR_INVALID;
+    if (!std::strcmp(key, "graph")) c->use_graph = value ? 1 : 0;
+    else if (!std::strcmp(key, "small_grid")) c->use_small = value ? 1 : 0;
+    else return fail(c, HADI_ERR_INVALID, "unknown tuning key '%s'", key);
     return HADI_OK;
 }
 

@@ -765,6 +765,165 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Small grids (the reference's calibration / perf-harness sizes, e.g. 50x25: perfomance_test.cpp:46-57):
+// the whole instance lives in LDS and ONE launch runs the entire time loop -- no HBM traffic and no kernel
+// boundaries inside the loop.  Block = W wavefronts <-> one instance (W = 4: measured faster than 16 on MI355X,
+// 0.37 vs 0.46 ms for 500 instances of 50x25x20 -- more blocks per CU beat more waves per instance).  Per step: the row pass is the same
+// hadi_row_step as above (rows taken straight from the LDS-resident state, Y written to LDS), then the
+// column pass walks each column sequentially in LDS (single chunk: m2+1 <= HADI_LC), with the American
+// projection; discrete dividends are applied in place.
+struct HadiSmallArgs {
+    const int *div_flag;        // [Nmax] dividend index applied at the START of step n (n = 1..Nmax), or -1; nullptr = none
+    const double *div_amounts;  // device copies of the schedule
+    const double *div_pcts;
+    const double *vec_s;        // [n_inst][m1+1] (dividend interpolation)
+    int Nmax;
+};
+
+template <int B, int W, bool AMER>
+__global__ void __launch_bounds__(64 * W) hadi_small_kernel(HadiSweepArgs a, HadiSmallArgs sm) {
+    HADI_DYN_SMEM(double, smem);
+    constexpr int G = 1, NT = 64 * W;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = HADI_UNIFORM((int)(threadIdx.x >> 6));
+    const int inst = blockIdx.x;
+    if (inst >= a.n_inst) return;
+    const HadiInstPar ip = a.ipar[inst];
+    const int nrows = a.L.nrows, rowp = a.L.rowp, m1 = a.L.m1;
+    constexpr int c0slot = 64 * B;
+    // LDS map: U with two zero rows above and below, Y, [lambda, payoff], coefficients, row table, column table
+    const int rows_l = nrows + 4;
+    double *Ul = smem + 2 * rowp;                 // row 0 of U (rows -2, -1 and nrows, nrows+1 are zero)
+    double *Yl = smem + (size_t)rows_l * rowp;    // nrows rows
+    double *LAMl = Yl + (size_t)nrows * rowp;
+    double *U0l = LAMl + (AMER ? (size_t)nrows * rowp : 0);
+    double *coef = U0l + (AMER ? (size_t)nrows * rowp : 0);
+    double *rtab = coef + 4 * 64 * B;
+    double *ptab = rtab + (size_t)nrows * HADI_RC;
+
+    double *__restrict__ Ug = a.U + (size_t)inst * a.L.inst_stride;
+    for (int e = tid; e < rows_l * rowp; e += NT) smem[e] = 0.0;
+    __syncthreads();
+    for (int e = tid; e < nrows * rowp; e += NT) Ul[e] = Ug[e];
+    if constexpr (AMER) {
+        const double *__restrict__ P0g = a.U0 + (size_t)inst * a.L.inst_stride;
+        for (int e = tid; e < nrows * rowp; e += NT) {
+            U0l[e] = P0g[e];
+            LAMl[e] = 0.0;  // lambda_bar <- 0, device_solver.hpp:310-313
+        }
+    }
+    {
+        const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B;
+        for (int e = tid; e < 4 * 64 * B; e += NT) coef[e] = sc[e];
+        const double *__restrict__ rg = a.rowc + (size_t)inst * nrows * HADI_RC;
+        for (int e = tid; e < nrows * HADI_RC; e += NT) rtab[e] = rg[e];
+        const double *__restrict__ pg = a.pb + (size_t)inst * a.L.nrows_pad * HADI_PBW;
+        for (int e = tid; e < nrows * HADI_PBW; e += NT) ptab[e] = pg[e];
+    }
+    HadiRowCtx c;
+    c.lane = lane; c.half = 0; c.wrow = wave; c.rowp = rowp;
+    c.dt = ip.dt; c.thdt = ip.thdt; c.qd = ip.q; c.half_rd = ip.half_rd;
+    c.Yi = Yl; c.Li = AMER ? LAMl : nullptr;
+    c.rowc = rtab; c.j0 = 0;
+    c.b2r = a.b2row + (size_t)inst * rowp;
+    c.coef = coef; c.xch = nullptr;
+    {
+        const int ifirst = 1 + B * lane;
+        c.posL = hadi_pos(B, G, ifirst - 1);
+        c.posR = (ifirst + B <= 64 * B) ? hadi_pos(B, G, ifirst + B) : c0slot + 1;
+    }
+#if defined(HADI_STAMPS) && !defined(HADI_EMU)
+    unsigned long long stamp_store_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    c.stamp_acc_ = stamp_store_;
+#endif
+    __syncthreads();
+
+    const int N = ip.N < sm.Nmax ? ip.N : sm.Nmax;
+    const double *__restrict__ vs = sm.vec_s ? sm.vec_s + (size_t)inst * (m1 + 1) : nullptr;
+    for (int n = 1; n <= N; n++) {
+        // ---- discrete dividend at the start of the step (device_solver.hpp:448-504) ---------------
+        const int dv = sm.div_flag ? sm.div_flag[n - 1] : -1;
+        if (dv >= 0) {
+            for (int e = tid; e < nrows * rowp; e += NT) Yl[e] = Ul[e];  // U_temp
+            __syncthreads();
+            const double amount = sm.div_amounts[dv], pct = sm.div_pcts[dv];
+            for (int e = tid; e < nrows * (m1 + 1); e += NT) {
+                const int j = e / (m1 + 1), i = e - j * (m1 + 1);
+                const double *src = Yl + (size_t)j * rowp;
+                const double new_s = vs[i] * (1.0 - pct) - amount;
+                double out = 0.0;
+                if (new_s > 0) {
+                    int lo = 0, hi = m1 + 1;  // first k with s[k] > new_s (0 if none)
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (vs[mid] > new_s) hi = mid;
+                        else lo = mid + 1;
+                    }
+                    const int idx = (lo <= m1) ? lo : 0;
+                    if (idx > 0) {
+                        const double s_low = vs[idx - 1], s_high = vs[idx];
+                        const double weight = (new_s - s_low) / (s_high - s_low);
+                        out = (1.0 - weight) * src[hadi_pos(B, G, idx - 1)] + weight * src[hadi_pos(B, G, idx)];
+                    } else {
+                        out = src[c0slot];
+                    }
+                }
+                Ul[(size_t)j * rowp + hadi_pos(B, G, i)] = out;
+            }
+            __syncthreads();
+        }
+        // ---- row pass: 4 rows at a time, straight out of LDS -----------------------------------------
+        c.e_nm1 = exp(ip.r_f * ip.dt * (n - 1));
+        c.e_n = exp(ip.r_f * ip.dt * n);
+        for (int J = 0; J < nrows; J += W) {
+            const int j = J + wave;
+            if (j < nrows) {
+                const double *r0 = Ul + (size_t)j * rowp;
+                if (j == nrows - 1)
+                    hadi_row_step<B, G, AMER, true>(c, true, j, r0 - 2 * rowp, r0 - rowp, r0, r0 + rowp, r0 + 2 * rowp);
+                else
+                    hadi_row_step<B, G, AMER, false>(c, true, j, r0 - 2 * rowp, r0 - rowp, r0, r0 + rowp, r0 + 2 * rowp);
+            }
+        }
+        __syncthreads();
+        // ---- column pass: one thread per storage column, sequential pentadiagonal sweeps in LDS --------
+        for (int col = tid; col < rowp; col += NT) {
+            double ym1 = 0.0, ym2 = 0.0;
+            for (int k = 0; k < nrows; k++) {
+                const double *t = ptab + (size_t)k * HADI_PBW;
+                const double yk = (Yl[(size_t)k * rowp + col] - t[PB_L] * ym1 - t[PB_L2] * ym2) * t[PB_Q];
+                Yl[(size_t)k * rowp + col] = yk;
+                ym2 = ym1;
+                ym1 = yk;
+            }
+            double xp1 = 0.0, xp2 = 0.0;
+            for (int k = nrows - 1; k >= 0; k--) {
+                const double *t = ptab + (size_t)k * HADI_PBW;
+                const double xk = Yl[(size_t)k * rowp + col] - t[PB_C] * xp1 - t[PB_C2] * xp2;
+                xp2 = xp1;
+                xp1 = xk;
+                if constexpr (AMER) {  // Ikonen-Toivanen projection, device_solver.hpp:358-372
+                    const size_t off = (size_t)k * rowp + col;
+                    const double lamv = LAMl[off], pay = U0l[off];
+                    Ul[off] = fmax(xk - ip.dt * lamv, pay);
+                    double ln = fmax(0.0, lamv + (pay - xk) / ip.dt);
+                    if (col == a.pos_m1) ln = 0.0;
+                    LAMl[off] = ln;
+                } else {
+                    Ul[(size_t)k * rowp + col] = xk;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < nrows * rowp; e += NT) Ug[e] = Ul[e];
+    if constexpr (AMER) {
+        double *__restrict__ Lg = a.LAM + (size_t)inst * a.L.inst_stride;
+        for (int e = tid; e < nrows * rowp; e += NT) Lg[e] = LAMl[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Setup: one block per instance builds all operator tables (replaces bounds.initialize and the three
 // build_matrix calls at the top of every reference launcher, e.g. jacobian_computation.cpp:255-261).
 struct HadiSetupArgs {

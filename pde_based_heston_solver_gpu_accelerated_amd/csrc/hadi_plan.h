@@ -15,6 +15,8 @@ struct HadiPlan {
     int pos_m1;
     // table sizes per instance (doubles)
     size_t n_scoef, n_b2row, n_rowc, n_a2i, n_pb, n_rinv, n_rwork;
+    // small-grid path: whole instance in LDS, one launch for the whole time loop (0 = not applicable)
+    size_t smem_small_eu, smem_small_am;
 };
 
 // Returns 0 on success, 1 if the shape is outside what the kernels cover.
@@ -71,6 +73,14 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
     p.n_pb = (size_t)L.nrows_pad * HADI_PBW;
     p.n_rinv = (size_t)16 * L.P * L.P;
     p.n_rwork = (size_t)32 * L.P * L.P;
+    p.smem_small_eu = p.smem_small_am = 0;
+    if (L.G == 1 && L.B <= 2 && L.P == 1) {
+        const size_t fixed = (size_t)(L.nrows + 4) * L.rowp + (size_t)L.nrows * L.rowp + (size_t)4 * 64 * L.B +
+                             (size_t)L.nrows * HADI_RC + (size_t)L.nrows * HADI_PBW;
+        const size_t eu = fixed * sizeof(double), am = (fixed + (size_t)2 * L.nrows * L.rowp) * sizeof(double);
+        if (eu <= 76 * 1024) p.smem_small_eu = eu;   // two blocks per CU
+        if (am <= 150 * 1024) p.smem_small_am = am;
+    }
     *out = p;
     return 0;
 }

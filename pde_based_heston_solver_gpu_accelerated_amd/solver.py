@@ -105,6 +105,12 @@ class HestonADI:
     def set_profiling(self, enabled):
         self._lib.hadi_set_profiling(self._h, 1 if enabled else 0)
 
+    def set_tuning(self, key, value):
+        """Execution-path switch ('small_grid', 'graph'); never changes results."""
+        rc = self._lib.hadi_set_tuning(self._h, key.encode(), int(value))
+        if rc != nat.HADI_OK:
+            self._raise(rc)
+
     def timing(self):
         t = nat.Timing()
         self._lib.hadi_get_timing(self._h, C.byref(t))

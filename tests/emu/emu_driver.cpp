@@ -30,7 +30,7 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
                          const double *par /*[n][4] rho sigma kappa eta*/, int variant, const double *vec_s,
                          const double *vec_v, const double *delta_s, const double *delta_v, double *U,
                          const double *U0, double *lam_out, int target_waves, int ndiv, const double *ddates,
-                         const double *damounts, const double *dpcts, int setup_threads) {
+                         const double *damounts, const double *dpcts, int setup_threads, int use_small) {
     HadiPlan pl;
     if (hadi_make_plan(m1, m2, n_inst, target_waves, &pl)) return 1;
     const HadiLayout &L = pl.L;
@@ -65,6 +65,29 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
     a.ipar = ipar.data(); a.L = L; a.n_inst = n_inst; a.R = pl.R; a.ntiles = pl.ntiles; a.ctiles = pl.ctiles; a.btpw = pl.btpw; a.bgroups = pl.bgroups;
     a.american = american; a.pos_m1 = pl.pos_m1;
 
+    const size_t smem_small = american ? pl.smem_small_am : pl.smem_small_eu;
+    if (use_small && smem_small > 0) {
+        std::vector<int> flags(N, -1);
+        int cc = 0;
+        for (int n = 1; n <= N; n++) {
+            const double t = n * dt;
+            if (dividend && cc < ndiv && t <= ddates[cc] && ddates[cc] < (n + 1) * dt) flags[n - 1] = cc;
+            if (dividend && cc < ndiv && t > ddates[cc]) cc++;
+        }
+        HadiSmallArgs sm;
+        sm.div_flag = dividend ? flags.data() : nullptr; sm.div_amounts = damounts; sm.div_pcts = dpcts;
+        sm.vec_s = vec_s; sm.Nmax = N;
+        if (L.B == 1) {
+            if (american) emu::launch(n_inst, 256, [&]() { hadi_small_kernel<1, 4, true>(a, sm); }, smem_small);
+            else emu::launch(n_inst, 256, [&]() { hadi_small_kernel<1, 4, false>(a, sm); }, smem_small);
+        } else {
+            if (american) emu::launch(n_inst, 256, [&]() { hadi_small_kernel<2, 4, true>(a, sm); }, smem_small);
+            else emu::launch(n_inst, 256, [&]() { hadi_small_kernel<2, 4, false>(a, sm); }, smem_small);
+        }
+        emu::launch(8, 64, [&]() { hadi_unpack_kernel(L, n_inst, dU.data(), U); });
+        if (american && lam_out) emu::launch(8, 64, [&]() { hadi_unpack_kernel(L, n_inst, dLAM.data(), lam_out); });
+        return 0;
+    }
     int cur = 0;
     for (int n = 1; n <= N; n++) {
         if (dividend) {  // device_solver.hpp:426-517 (host decides, kernel applies)

@@ -35,7 +35,7 @@ def emu():
     return C.CDLL(EMU_SO)
 
 
-def _run(emu, m1, m2, N, strikes, variant, target_waves, r_f=0.0):
+def _run(emu, m1, m2, N, strikes, variant, target_waves, r_f=0.0, small=0):
     n = len(strikes)
     vs, vv, ds, dv, U0 = Cm.oracle_grids(m1, m2, strikes)
     p = Cm.oracle_params(m1, m2, N, variant, r_f=r_f)
@@ -45,7 +45,7 @@ def _run(emu, m1, m2, N, strikes, variant, target_waves, r_f=0.0):
     dd = [np.array(x, dtype=np.float64) for x in Cm.DIVS]
     rc = emu.emu_solve(n, m1, m2, N, C.c_double(Cm.T / N), C.c_double(Cm.THETA), C.c_double(Cm.R_D),
                        C.c_double(r_f), _P(par), variant, _P(vs), _P(vv), _P(ds), _P(dv), _P(U), _P(U0), _P(lam),
-                       target_waves, len(dd[0]), _P(dd[0]), _P(dd[1]), _P(dd[2]), 64)
+                       target_waves, len(dd[0]), _P(dd[0]), _P(dd[1]), _P(dd[2]), 64, small)
     assert rc == 0
     scale = np.abs(Uo).max()
     assert np.abs(U - Uo).max() < 1e-11 * scale
@@ -74,6 +74,14 @@ def test_two_waves_per_row_split_solve(emu):
     # m1 > 512: the row's tridiagonal system is split over two wavefronts and re-coupled by a 2x2 system
     _run(emu, 600, 12, 2, [100.0, 93.0], O.EU, 8)
     _run(emu, 530, 10, 2, [100.0], O.AM, 8, r_f=0.01)
+
+
+def test_small_grid_lds_resident_kernel(emu):
+    # whole instance in LDS, one launch for the time loop: all four variants on the reference's 50x25 grid
+    _run(emu, 50, 25, 6, [100.0, 95.0], O.EU, 8, small=1)
+    _run(emu, 50, 25, 20, [100.0], O.AM_DIV, 8, small=1)
+    _run(emu, 100, 30, 4, [100.0], O.AM, 8, r_f=0.01, small=1)
+    _run(emu, 40, 12, 12, [100.0], O.DIV, 8, small=1)
 
 
 def test_setup_tables_against_oracle_operators(emu):

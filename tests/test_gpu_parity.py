@@ -91,6 +91,32 @@ def test_american_dividend_variants_vs_oracle(solver, variant, name, m1, m2, N, 
         assert np.abs(lam - lamo).max() <= 1e-8 * max(1.0, np.abs(lamo).max())
 
 
+@pytest.mark.parametrize("variant,name", [(H.EU, "EU"), (H.AM, "AM"), (H.DIV, "DIV"), (H.AM_DIV, "AM_DIV")])
+def test_small_grid_kernel_and_streaming_kernels_agree(solver, variant, name):
+    """Grids that fit in LDS run through the one-launch LDS-resident kernel by default; the two-pass
+    streaming kernels must give the same field (both within 1e-10 of the oracle, 1e-11 of each other),
+    with and without hipGraph replay of the time loop."""
+    m1, m2, N, strikes = 50, 25, 20, Cm.strikes_for(6)
+    p = Cm.oracle_params(m1, m2, N, name)
+    fields = []
+    for small, graph in ((1, 1), (0, 1), (0, 0)):
+        solver.set_tuning("small_grid", small)
+        solver.set_tuning("graph", graph)
+        try:
+            grids, U0, U, lam = _hadi_solve(solver, m1, m2, N, strikes, variant, want_lambda=variant in (H.AM, H.AM_DIV))
+        finally:
+            solver.set_tuning("small_grid", 1)
+            solver.set_tuning("graph", 1)
+        fields.append((U, lam))
+    Uo, lamo, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0, want_lambda=True)
+    for U, lam in fields:
+        _assert_field(U, Uo)
+        if lamo is not None:
+            assert np.abs(lam - lamo).max() <= 1e-8 * max(1.0, np.abs(lamo).max())
+    assert np.abs(fields[0][0] - fields[1][0]).max() <= 1e-11 * np.abs(Uo).max()
+    assert np.array_equal(fields[1][0], fields[2][0])  # graph replay == direct launches, bit for bit
+
+
 def test_foreign_rate_boundary_terms(solver):
     """r_f != 0 switches on the time-dependent boundary factors exp(r_f dt n) (device_solver.hpp:238-247)
     that every reference test leaves at 1."""
