@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--timesteps", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-single", action="store_true", help="skip the 1-instance latency run (profiling)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal only: every rank uses GPU 0 (a 1-GPU box cannot host one GPU per rank)")
     args = ap.parse_args()
 
     import numpy as np
@@ -54,13 +57,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    dev_index = 0 if args.share_device else local_rank
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=args.backend)
     n_gpus = world if world > 1 else 1
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     # ---- workload C2: this rank's shard of the strike ladder ---------------------------------------
@@ -76,7 +83,7 @@ def main():
     U0 = torch.from_numpy(U0_h).to(dev)
     U = torch.empty_like(U0)
     m = (m1 + 1) * (m2 + 1)
-    solver = H.HestonADI(local_rank)
+    solver = H.HestonADI(dev_index)
 
     def step():
         U.copy_(U0)  # workspace.U <- U_0 before every call (heston_calibration.cpp:216); D2D, part of the pass
@@ -100,7 +107,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     units = float(n_glob) * m * N * args.steps

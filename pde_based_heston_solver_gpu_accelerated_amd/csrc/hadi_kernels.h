@@ -839,6 +839,7 @@ __global__ void __launch_bounds__(64 * W) hadi_small_kernel(HadiSweepArgs a, Had
     __syncthreads();
 
     const int N = ip.N < sm.Nmax ? ip.N : sm.Nmax;
+    HADI_STAMP_DECL(c.stamp_acc_)
     const double *__restrict__ vs = sm.vec_s ? sm.vec_s + (size_t)inst * (m1 + 1) : nullptr;
     for (int n = 1; n <= N; n++) {
         // ---- discrete dividend at the start of the step (device_solver.hpp:448-504) ---------------
@@ -875,6 +876,7 @@ __global__ void __launch_bounds__(64 * W) hadi_small_kernel(HadiSweepArgs a, Had
         // ---- row pass: 4 rows at a time, straight out of LDS -----------------------------------------
         c.e_nm1 = exp(ip.r_f * ip.dt * (n - 1));
         c.e_n = exp(ip.r_f * ip.dt * n);
+        HADI_STAMP(8);
         for (int J = 0; J < nrows; J += W) {
             const int j = J + wave;
             if (j < nrows) {
@@ -885,7 +887,9 @@ __global__ void __launch_bounds__(64 * W) hadi_small_kernel(HadiSweepArgs a, Had
                     hadi_row_step<B, G, AMER, false>(c, true, j, r0 - 2 * rowp, r0 - rowp, r0, r0 + rowp, r0 + 2 * rowp);
             }
         }
+        HADI_STAMP(10);  // row pass
         __syncthreads();
+        HADI_STAMP(9);  // barrier
         // ---- column pass: one thread per storage column, sequential pentadiagonal sweeps in LDS --------
         for (int col = tid; col < rowp; col += NT) {
             double ym1 = 0.0, ym2 = 0.0;
@@ -916,6 +920,10 @@ __global__ void __launch_bounds__(64 * W) hadi_small_kernel(HadiSweepArgs a, Had
         }
         __syncthreads();
     }
+#if defined(HADI_STAMPS) && !defined(HADI_EMU)
+    if (lane == 0)
+        for (int k = 0; k < 12; k++) atomicAdd(&g_hadi_stamps[k], stamp_store_[k]);
+#endif
     for (int e = tid; e < nrows * rowp; e += NT) Ug[e] = Ul[e];
     if constexpr (AMER) {
         double *__restrict__ Lg = a.LAM + (size_t)inst * a.L.inst_stride;
