@@ -1,5 +1,7 @@
 // hadi_plan.h -- host-side choice of layout and launch geometry for one batch shape.
 #pragma once
+#include <stdlib.h>
+
 #include "hadi_core.h"
 
 struct HadiPlan {
@@ -46,6 +48,7 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
     ntiles = (L.nrows + R - 1) / R;
     R = ((L.nrows + ntiles - 1) / ntiles + W - 1) / W * W;  // balance
     ntiles = (L.nrows + R - 1) / R;
+    if (const char *e = getenv("HADI_TUNE_R")) { R = atoi(e); if (R < W) R = W; R = (R + W - 1) / W * W; ntiles = (L.nrows + R - 1) / R; }
     p.R = R;
     p.ntiles = ntiles;
     p.smem_a = ((size_t)(2 * W + 4) * L.rowp + (size_t)4 * 64 * L.B * L.G + 4 * W + (size_t)R * HADI_RC) * sizeof(double);
@@ -57,6 +60,8 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
     {
         const int want_blocks = (3 * target_waves) / 8;  // target_waves = 8 per CU
         int groups = (want_blocks + n_inst - 1) / n_inst;
+        if (groups < 1) groups = 1;
+        if (const char *e = getenv("HADI_TUNE_BG")) groups = atoi(e);
         if (groups < 1) groups = 1;
         if (groups > p.ctiles) groups = p.ctiles;
         p.btpw = (p.ctiles + groups - 1) / groups;
