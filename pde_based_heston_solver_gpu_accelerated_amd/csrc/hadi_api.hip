@@ -129,12 +129,12 @@ struct SweepDesc {
     const double *div_dates = nullptr, *div_amounts = nullptr, *div_pcts = nullptr;
 };
 
-template <int B, int G>
+template <int B, int G, int NG, int PD>
 void launch_pass_a(const HadiPlan &pl, const HadiSweepArgs &a, int n, hipStream_t s) {
     if (a.american)
-        hipLaunchKernelGGL((hadi_pass_a<B, G, 4, true>), dim3(pl.grid_a), dim3(64 * pl.W * G), pl.smem_a, s, a, n);
+        hipLaunchKernelGGL((hadi_pass_a<B, G, 4, NG, PD, true>), dim3(pl.grid_a), dim3(64 * pl.W * G * NG), pl.smem_a, s, a, n);
     else
-        hipLaunchKernelGGL((hadi_pass_a<B, G, 4, false>), dim3(pl.grid_a), dim3(64 * pl.W * G), pl.smem_a, s, a, n);
+        hipLaunchKernelGGL((hadi_pass_a<B, G, 4, NG, PD, false>), dim3(pl.grid_a), dim3(64 * pl.W * G * NG), pl.smem_a, s, a, n);
 }
 
 // Kernels whose dynamic LDS can exceed the 64 KiB default need the limit raised once.
@@ -142,18 +142,18 @@ template <class K>
 hipError_t raise_lds_limit(K kernel) {
     return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
-template <int B, int G>
+template <int B, int G, int NG, int PD>
 hipError_t raise_pass_a() {
-    hipError_t e = raise_lds_limit(hadi_pass_a<B, G, 4, false>);
-    return e != hipSuccess ? e : raise_lds_limit(hadi_pass_a<B, G, 4, true>);
+    hipError_t e = raise_lds_limit(hadi_pass_a<B, G, 4, NG, PD, false>);
+    return e != hipSuccess ? e : raise_lds_limit(hadi_pass_a<B, G, 4, NG, PD, true>);
 }
 hipError_t raise_all_lds_limits() {
     hipError_t e;
-    if ((e = raise_pass_a<1, 1>()) != hipSuccess) return e;
-    if ((e = raise_pass_a<2, 1>()) != hipSuccess) return e;
-    if ((e = raise_pass_a<4, 1>()) != hipSuccess) return e;
-    if ((e = raise_pass_a<8, 1>()) != hipSuccess) return e;
-    if ((e = raise_pass_a<8, 2>()) != hipSuccess) return e;
+    if ((e = raise_pass_a<1, 1, 1, 2>()) != hipSuccess) return e;
+    if ((e = raise_pass_a<2, 1, 1, 2>()) != hipSuccess) return e;
+    if ((e = raise_pass_a<4, 1, 1, 2>()) != hipSuccess) return e;
+    if ((e = raise_pass_a<8, 1, 1, 1>()) != hipSuccess) return e;
+    if ((e = raise_pass_a<8, 2, 1, 1>()) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_kernel<1, 4, false>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_kernel<1, 4, true>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_kernel<2, 4, false>)) != hipSuccess) return e;
@@ -254,11 +254,11 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
             }
             if (prof) HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 0], q));
             switch (L.B * 10 + L.G) {
-                case 11: launch_pass_a<1, 1>(pl, a, nstep, q); break;
-                case 21: launch_pass_a<2, 1>(pl, a, nstep, q); break;
-                case 41: launch_pass_a<4, 1>(pl, a, nstep, q); break;
-                case 81: launch_pass_a<8, 1>(pl, a, nstep, q); break;
-                default: launch_pass_a<8, 2>(pl, a, nstep, q); break;
+                case 11: launch_pass_a<1, 1, 1, 2>(pl, a, nstep, q); break;
+                case 21: launch_pass_a<2, 1, 1, 2>(pl, a, nstep, q); break;
+                case 41: launch_pass_a<4, 1, 1, 2>(pl, a, nstep, q); break;
+                case 81: launch_pass_a<8, 1, 1, 1>(pl, a, nstep, q); break;
+                default: launch_pass_a<8, 2, 1, 1>(pl, a, nstep, q); break;
             }
             if (prof) {
                 HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 1], q));

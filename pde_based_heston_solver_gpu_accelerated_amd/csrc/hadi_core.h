@@ -14,6 +14,7 @@
 #include "hadi_device.h"
 
 #define HADI_RC 16   // doubles per v-row in the row table
+#define HADI_RCL 12  // of which the first 12 are used (compact stride of the LDS copies)
 #define HADI_PBW 12  // doubles per v-row in the column-pass table
 #define HADI_MAX_P 16 // max chunks (waves) per column in the column pass
 #define HADI_LC 33   // max rows per chunk in the column pass

@@ -178,23 +178,6 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_to_lds(const double *__restrict__ grow, 
     }
 }
 
-// Wait until this wavefront's LDS-DMA transfers have completed; pair with a barrier.  vmcnt retires in
-// issue order, and a wave that solved a row issued KEEP result stores AFTER its DMA: those may stay in
-// flight (waiting for their write acknowledgements costs microseconds under load).
-template <int KEEP>
-HADI_DEV HADI_FORCEINLINE void hadi_dma_wait(bool stores_behind) {
-#if !defined(HADI_EMU)
-    if (stores_behind) {
-        if constexpr (KEEP == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else if constexpr (KEEP == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else if constexpr (KEEP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-#endif
-}
-
 template <int B>
 HADI_DEV HADI_FORCEINLINE void hadi_lds_row(const double *lrow, int lane, double (&u)[B]) {
     if constexpr (B == 1) {
@@ -279,7 +262,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtx &c, bool active, i
     if (active) {
         // (LDS, not global: an ordinary global load here would make hipcc drain the in-flight LDS-DMA
         // prefetch with vmcnt(0) at the start of every row)
-        const double *rc = c.rowc + (size_t)(j - c.j0) * HADI_RC;
+        const double *rc = c.rowc + (size_t)(j - c.j0) * HADI_RCL;
         const double v = rc[RC_V];
         const double wm = rc[RC_WM], wz = rc[RC_WZ], wp = rc[RC_WP];
         const double a2l2 = rc[RC_L2], a2l1 = rc[RC_L1], a2m = rc[RC_M], a2u1 = rc[RC_U1], a2u2 = rc[RC_U2];
@@ -503,23 +486,60 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtx &c, bool active, i
     }
 }
 
-template <int B, int G, int W, bool AMER>
-__global__ void __launch_bounds__(64 * W * G, (B >= 8 ? 2 : 4)) hadi_pass_a(HadiSweepArgs a, int n) {
+// Counted wait: at most `n` of this wavefront's youngest vector-memory operations may still be in flight.
+HADI_DEV HADI_FORCEINLINE void hadi_wait_vmcnt(int n) {
+#if !defined(HADI_EMU)
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+    }
+#else
+    (void)n;
+#endif
+}
+
+// NG = row tiles handled by one block (each by its own group of W*G wavefronts with its own LDS ring; the
+// s-coefficient arrays are shared), PD = prefetch depth in iterations: the ring holds (PD+1)*W + 4 rows.
+// (B, G) = (8, 1) runs NG = 2, PD = 2: one 8-wave block per CU whose 158 KB of LDS keep two iterations of
+// rows in flight per wavefront -- the latency-bandwidth product of a CU needs more than one.
+template <int B, int G, int W, int NG, int PD, bool AMER>
+__global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : 4)) hadi_pass_a(HadiSweepArgs a, int n) {
     HADI_DYN_SMEM(double, smem);
-    constexpr int RING = 2 * W + 4;
+    constexpr int RING = (PD + 1) * W + 4;
+    constexpr int NT = 64 * W * G * NG;
     const int lane = threadIdx.x & 63;
     const int wave = HADI_UNIFORM((int)(threadIdx.x >> 6));
-    const int wrow = wave / G, half = wave - wrow * G;
-    const int total = a.n_inst * a.ntiles;
+    const int grp = wave / (W * G), wv = wave - grp * (W * G);
+    const int wrow = wv / G, half = wv - wrow * G;
+    const int tblocks = (a.ntiles + NG - 1) / NG;  // blocks per instance
+    const int total = a.n_inst * tblocks;
     const int logical = hadi_xcd_remap(blockIdx.x, gridDim.x);
     if (logical >= total) return;
-    const int inst = logical / a.ntiles, tile = logical - inst * a.ntiles;
+    const int inst = logical / tblocks, tb = logical - inst * tblocks;
     const HadiInstPar ip = a.ipar[inst];
     if (n > ip.N) return;
     const int nrows = a.L.nrows, npad = a.L.nrows_pad, rowp = a.L.rowp;
-    const int j0 = tile * a.R;
+    const int tile = tb * NG + grp;
+    const int j0 = tile * a.R;  // may be >= nrows for the last block's spare group: that group only joins barriers
     const int j1 = (j0 + a.R < nrows) ? j0 + a.R : nrows;
-    if (j0 >= j1) return;
 
     HadiRowCtx c;
     c.lane = lane;
@@ -543,43 +563,61 @@ __global__ void __launch_bounds__(64 * W * G, (B >= 8 ? 2 : 4)) hadi_pass_a(Hadi
         c.posR = (ifirst + B <= 64 * B * G) ? hadi_pos(B, G, ifirst + B) : c0slot + 1;
     }
 
-    // LDS: [RING rows of rowp] [4 coefficient arrays of 64*B*G] [W*4 exchange] [row table of the tile]
-    double *coef = smem + (size_t)RING * rowp;
+    // LDS: [NG rings of RING rows] [4 coefficient arrays of 64*B*G] [NG*W*4 exchange] [NG compact row tables]
+    double *ring = smem + (size_t)grp * RING * rowp;
+    double *coef = smem + (size_t)NG * RING * rowp;
     {
         const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B * G;
-        for (int e = threadIdx.x; e < 4 * 64 * B * G; e += 64 * W * G) coef[e] = sc[e];
+        for (int e = threadIdx.x; e < 4 * 64 * B * G; e += NT) coef[e] = sc[e];
     }
     c.coef = coef;
-    c.xch = coef + 4 * 64 * B * G;
+    c.xch = coef + 4 * 64 * B * G + grp * 4 * W;
     {
-        double *rtab = c.xch + 4 * W;
+        double *rtab = coef + 4 * 64 * B * G + NG * 4 * W + (size_t)grp * a.R * HADI_RCL;
         const double *__restrict__ rg = a.rowc + ((size_t)inst * nrows + j0) * HADI_RC;
-        for (int e = threadIdx.x; e < (j1 - j0) * HADI_RC; e += 64 * W * G) rtab[e] = rg[e];
+        const int tl = threadIdx.x - grp * 64 * W * G;
+        for (int e = tl; e < (j1 - j0) * HADI_RCL; e += 64 * W * G) rtab[e] = rg[(e / HADI_RCL) * HADI_RC + e % HADI_RCL];
         c.rowc = rtab;
     }
 
-    auto slot = [&](int jj) { return smem + (size_t)((jj + RING) % RING) * rowp; };
-    auto fetch = [&](int jj) { hadi_row_to_lds(Ub + (size_t)jj * rowp, slot(jj), rowp, lane, jj >= 0 && jj < npad); };
-    for (int rr = wave; rr < W + 4; rr += W * G) fetch(j0 - 2 + rr);
+    const int iters = (j1 > j0) ? (j1 - j0 + W - 1) / W : 0;  // this group's iterations
+    const int iters_all = (a.R + W - 1) / W;                   // every group of the block runs this many barriers
+    auto slot = [&](int jj) { return ring + (size_t)((jj + 4 * RING) % RING) * rowp; };
+    // fetch returns the number of vector-memory instructions it issued
+    auto fetch = [&](int jj) -> int {
+        const bool exists = jj >= 0 && jj < npad;
+        hadi_row_to_lds(Ub + (size_t)jj * rowp, slot(jj), rowp, lane, exists);
+        return exists ? (rowp / 2 + 63) / 64 : 0;
+    };
+    // prologue: rows of iterations 0 .. PD-1
+    if (iters > 0)
+        for (int rr = wv; rr < PD * W + 4; rr += W * G) fetch(j0 - 2 + rr);
 
-    const int iters = (j1 - j0 + W - 1) / W;
-    bool stored = false;  // did this wave issue result stores after its last DMA?
+    // Vector-memory operations retire in issue order.  ya[k] = (lower bound of the) number of operations this
+    // wavefront issued after the DMA batch that iteration it+k needs, so hadi_wait_vmcnt(ya[0]) retires that
+    // batch and leaves younger batches and result stores in flight.
+    int ya[PD];
+#pragma unroll
+    for (int k = 0; k < PD; k++) ya[k] = 0;
 #if defined(HADI_STAMPS) && !defined(HADI_EMU)
     unsigned long long stamp_store_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     c.stamp_acc_ = stamp_store_;
 #endif
     HADI_STAMP_DECL(stamp_store_)
     HADI_STAMP(8);  // prologue
-    for (int it = 0; it < iters; it++) {
+    for (int it = 0; it < iters_all; it++) {
         const int J = j0 + it * W;
-        // a row step issues B/2 (one for B = 1) vector stores of its block (+ possibly the i = 0 node)
-        hadi_dma_wait<(B == 1 ? 1 : B / 2)>(stored);
+        hadi_wait_vmcnt(ya[0]);
         __syncthreads();  // this iteration's rows have landed; everyone is done with the rows replaced below
         HADI_STAMP(9);  // barrier wait (incl. DMA drain)
-        if (it + 1 < iters && wave < W) fetch(J + W + 2 + wave);
+        int z = 0;
+        if (it + PD < iters && wv < W) z = fetch(J + PD * W + 2 + wv);
+#pragma unroll
+        for (int k = 0; k + 1 < PD; k++) ya[k] = ya[k + 1] + z;
+        ya[PD - 1] = 0;
+        if constexpr (PD == 1) ya[0] = 0;
         const int j = J + wrow;
-        const bool active = j < j1;
-        stored = active;
+        const bool active = it < iters && j < j1;
         if constexpr (G == 1) {
             if (!active) continue;
         }
@@ -587,6 +625,10 @@ __global__ void __launch_bounds__(64 * W * G, (B >= 8 ? 2 : 4)) hadi_pass_a(Hadi
             hadi_row_step<B, G, AMER, true>(c, active, j, slot(j - 2), slot(j - 1), slot(j), slot(j + 1), slot(j + 2));
         else
             hadi_row_step<B, G, AMER, false>(c, active, j, slot(j - 2), slot(j - 1), slot(j), slot(j + 1), slot(j + 2));
+        if (active) {  // B/2 (one for B = 1) vector stores of the block; the i = 0 store is not counted (lower bound)
+#pragma unroll
+            for (int k = 0; k < PD; k++) ya[k] += (B == 1 ? 1 : B / 2);
+        }
         HADI_STAMP(10);  // whole row step (+ fetch issue)
     }
 #if defined(HADI_STAMPS) && !defined(HADI_EMU)
@@ -799,7 +841,7 @@ __global__ void __launch_bounds__(64 * W) hadi_small_kernel(HadiSweepArgs a, Had
     double *U0l = LAMl + (AMER ? (size_t)nrows * rowp : 0);
     double *coef = U0l + (AMER ? (size_t)nrows * rowp : 0);
     double *rtab = coef + 4 * 64 * B;
-    double *ptab = rtab + (size_t)nrows * HADI_RC;
+    double *ptab = rtab + (size_t)nrows * HADI_RCL;
 
     double *__restrict__ Ug = a.U + (size_t)inst * a.L.inst_stride;
     for (int e = tid; e < rows_l * rowp; e += NT) smem[e] = 0.0;
@@ -816,7 +858,7 @@ __global__ void __launch_bounds__(64 * W) hadi_small_kernel(HadiSweepArgs a, Had
         const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B;
         for (int e = tid; e < 4 * 64 * B; e += NT) coef[e] = sc[e];
         const double *__restrict__ rg = a.rowc + (size_t)inst * nrows * HADI_RC;
-        for (int e = tid; e < nrows * HADI_RC; e += NT) rtab[e] = rg[e];
+        for (int e = tid; e < nrows * HADI_RCL; e += NT) rtab[e] = rg[(e / HADI_RCL) * HADI_RC + e % HADI_RCL];
         const double *__restrict__ pg = a.pb + (size_t)inst * a.L.nrows_pad * HADI_PBW;
         for (int e = tid; e < nrows * HADI_PBW; e += NT) ptab[e] = pg[e];
     }

@@ -6,10 +6,11 @@
 
 struct HadiPlan {
     HadiLayout L;
-    int W;               // pass A: wavefronts per block = v-rows solved concurrently by one block
+    int W;               // pass A: v-rows solved concurrently by one tile group (W*G wavefronts)
+    int NG, PD;          // pass A: tile groups per block, prefetch depth in iterations
     int R, ntiles;       // pass A: v-rows per block tile, tiles per instance
     int grid_a;          // pass A grid (64*W-thread blocks), padded to a multiple of 8 for the XCD remap
-    size_t smem_a;       // pass A dynamic LDS bytes: ring of 2W+4 rows + the 4 s-coefficient arrays
+    size_t smem_a;       // pass A dynamic LDS bytes: NG rings of (PD+1)W+4 rows + the 4 s-coefficient arrays + tables
     int ctiles;          // pass B: 64-column tiles per instance
     int btpw, bgroups;   // pass B: column tiles per block (register double-buffered), blocks per instance
     int grid_b, block_b; // pass B grid / block (P*64 threads)
@@ -35,24 +36,33 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
     if (L.P > HADI_MAX_P) return 1;
     L.nrows_pad = L.P * HADI_LC;
     L.inst_stride = (long long)L.rowp * L.nrows_pad;
-    // Row tiles: as tall as possible (halo re-reads cost 4/R) while the launch still has about three
-    // blocks per CU (target_waves = 8 per CU), a multiple of W rows each.
+    // Row tiles: as tall as possible (halo re-reads cost 4/R) while the launch still has a few blocks per CU
+    // (target_waves = 8 per CU), a multiple of W rows each.
     p.W = 4;
     const int W = p.W;
+    // One tile group per block and one iteration of prefetch at 8 nodes per lane (two 4-wave blocks per CU).
+    // Measured on MI355X at m1 = 512: NG = 2 groups sharing a block with PD = 2 (one 8-wave block per CU,
+    // 158 KB LDS) runs 0.170 ms/launch against 0.159 -- the wider barrier costs more than the deeper
+    // prefetch gains.  Narrower rows have LDS to spare and prefetch two iterations ahead.
+    p.NG = 1;
+    p.PD = (L.B == 8) ? 1 : 2;
+    const int Rmax = (p.NG == 2) ? 44 : 64;  // LDS: NG compact row tables of R rows
     int ntiles = ((3 * target_waves) / 8 + n_inst - 1) / n_inst;
     if (ntiles < 1) ntiles = 1;
     int R = (L.nrows + ntiles - 1) / ntiles;
     R = (R + W - 1) / W * W;
     if (R < W) R = W;
-    if (R > 64) R = 64;
+    if (R > Rmax) R = Rmax;
     ntiles = (L.nrows + R - 1) / R;
+    if (p.NG == 2 && (ntiles & 1) && ntiles > 1) ntiles++;  // pair the tiles up
     R = ((L.nrows + ntiles - 1) / ntiles + W - 1) / W * W;  // balance
     ntiles = (L.nrows + R - 1) / R;
-    if (const char *e = getenv("HADI_TUNE_R")) { R = atoi(e); if (R < W) R = W; R = (R + W - 1) / W * W; ntiles = (L.nrows + R - 1) / R; }
+    if (const char *e = getenv("HADI_TUNE_R")) { R = atoi(e); if (R < W) R = W; R = (R + W - 1) / W * W; if (R > Rmax) R = Rmax; ntiles = (L.nrows + R - 1) / R; }
     p.R = R;
     p.ntiles = ntiles;
-    p.smem_a = ((size_t)(2 * W + 4) * L.rowp + (size_t)4 * 64 * L.B * L.G + 4 * W + (size_t)R * HADI_RC) * sizeof(double);
-    const long long total = (long long)n_inst * ntiles;
+    p.smem_a = ((size_t)p.NG * ((p.PD + 1) * W + 4) * L.rowp + (size_t)4 * 64 * L.B * L.G + (size_t)p.NG * 4 * W +
+                (size_t)p.NG * R * HADI_RCL) * sizeof(double);
+    const long long total = (long long)n_inst * ((ntiles + p.NG - 1) / p.NG);
     p.grid_a = (int)((total + 7) / 8 * 8);
     p.ctiles = (L.rowp + 63) / 64;
     // Each block walks over btpw column tiles (loads of the next tile overlap the solve of the current
@@ -81,7 +91,7 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
     p.smem_small_eu = p.smem_small_am = 0;
     if (L.G == 1 && L.B <= 2 && L.P == 1) {
         const size_t fixed = (size_t)(L.nrows + 4) * L.rowp + (size_t)L.nrows * L.rowp + (size_t)4 * 64 * L.B +
-                             (size_t)L.nrows * HADI_RC + (size_t)L.nrows * HADI_PBW;
+                             (size_t)L.nrows * HADI_RCL + (size_t)L.nrows * HADI_PBW;
         const size_t eu = fixed * sizeof(double), am = (fixed + (size_t)2 * L.nrows * L.rowp) * sizeof(double);
         if (eu <= 76 * 1024) p.smem_small_eu = eu;   // two blocks per CU
         if (am <= 150 * 1024) p.smem_small_am = am;

@@ -12,10 +12,10 @@ thread_local WaveState *t_wave;
 thread_local int t_lane;
 }  // namespace emu
 
-template <int B, int G>
+template <int B, int G, int NG, int PD>
 static void run_pass_a(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
-    if (a.american) emu::launch(pl.grid_a, 64 * pl.W * G, [&]() { hadi_pass_a<B, G, 4, true>(a, n); }, pl.smem_a);
-    else emu::launch(pl.grid_a, 64 * pl.W * G, [&]() { hadi_pass_a<B, G, 4, false>(a, n); }, pl.smem_a);
+    if (a.american) emu::launch(pl.grid_a, 64 * pl.W * G * NG, [&]() { hadi_pass_a<B, G, 4, NG, PD, true>(a, n); }, pl.smem_a);
+    else emu::launch(pl.grid_a, 64 * pl.W * G * NG, [&]() { hadi_pass_a<B, G, 4, NG, PD, false>(a, n); }, pl.smem_a);
 }
 
 extern "C" int emu_plan(int m1, int m2, int n_inst, int target_waves, int *out /*B,rowp,P,R,ntiles,ctiles*/) {
@@ -101,11 +101,11 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
             if (cur < ndiv && t > ddates[cur]) cur++;
         }
         switch (L.B * 10 + L.G) {
-            case 11: run_pass_a<1, 1>(pl, a, n); break;
-            case 21: run_pass_a<2, 1>(pl, a, n); break;
-            case 41: run_pass_a<4, 1>(pl, a, n); break;
-            case 81: run_pass_a<8, 1>(pl, a, n); break;
-            case 82: run_pass_a<8, 2>(pl, a, n); break;
+            case 11: run_pass_a<1, 1, 1, 2>(pl, a, n); break;
+            case 21: run_pass_a<2, 1, 1, 2>(pl, a, n); break;
+            case 41: run_pass_a<4, 1, 1, 2>(pl, a, n); break;
+            case 81: run_pass_a<8, 1, 1, 1>(pl, a, n); break;
+            case 82: run_pass_a<8, 2, 1, 1>(pl, a, n); break;
             default: return 2;
         }
         if (a.american) emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b<16, true>(a, n); }, pl.smem_b);
