@@ -14,6 +14,7 @@
  *                                      + Device_BoundaryConditions::initialize (hes_boundary_kernels.hpp:41-75)
  *                                      + Device_A{0,1,2}::build_matrix (hes_a0_kernels.hpp:30,
  *                                        hes_a1_kernels.hpp:51, hes_a2_shuffled_kernels.hpp:103)
+ *                                      with scheme = HADI_SCHEME_CRAIG_SNEYD: CS_scheme_shuffled (src/solver.hpp:781-907)
  *   hadi_parallel_DO_solve          <- parallel_DO_solve (src/device_solver.hpp:52-185)
  *   hadi_compute_base_prices[_*]    <- compute_base_prices{,_american,_dividends,_american_dividends}
  *                                      (src/jacobian_computation.cpp:368, 629, 922, 1232)
@@ -63,6 +64,10 @@ enum hadi_status {
 
 enum hadi_variant { HADI_EU = 0, HADI_AM = 1, HADI_DIV = 2, HADI_AM_DIV = 3 };
 enum hadi_memspace { HADI_MEM_HOST = 0, HADI_MEM_DEVICE = 1 };
+/* Splitting scheme.  The reference's device path is Douglas only (src/device_solver.hpp:194-266); Craig-Sneyd
+ * exists in its host family (CS_scheme_shuffled, src/solver.hpp:781-907, European) and is offered here on the
+ * device for the European variant. */
+enum hadi_scheme { HADI_SCHEME_DOUGLAS = 0, HADI_SCHEME_CRAIG_SNEYD = 1 };
 
 /* One batch of independent option instances = one league of teams in the reference
  * (TeamPolicy(nInstances, AUTO), device_solver.hpp:83-88). */
@@ -103,6 +108,8 @@ typedef struct hadi_problem {
     const double *U_0;
     /* optional output: lambda_bar at T (DO_solver_workspace.hpp:22); [n][m] or NULL */
     double *lambda_bar;
+    /* enum hadi_scheme; 0 (Douglas) is what every reference launcher runs */
+    int scheme;
 } hadi_problem;
 
 /* Timing of the last sweep on this handle, measured with HIP events on the handle's

@@ -429,9 +429,48 @@ static void build_all(ho_ws *w, const ho_params *p, const double *vec_s, const d
     a2_build(w, vec_v, dv, p->r_d, kappa, eta, sigma, p->theta, p->delta_t);
 }
 
+/* ---- solver.hpp:781-907 CS_scheme_shuffled (European): Douglas predictor, then a corrector that re-adds
+ * half of the explicit mixed-derivative increment A0 Y2 - A0 U and repeats the two implicit solves.  The
+ * reference runs it on its host operator family, which produces the same digits as the device family
+ * (SURVEY.md 8(c)); here it reuses the device-family restatement above. */
+static void cs_timestepping(ho_ws *w, const ho_params *p, double *U) {
+    const int m = w->m, N = p->N;
+    const double delta_t = p->delta_t, theta = p->theta, r_f = p->r_f;
+    double *Y_0 = zalloc(m), *Y_1 = zalloc(m), *Y_2 = zalloc(m), *A0Y2 = zalloc(m), *Yt = zalloc(m);
+    for (int n = 1; n <= N; n++) {
+        a0_multiply(w, U, w->A0U);
+        a1_multiply(w, U, w->A1U);
+        a2_multiply(w, U, w->A2U);
+        const double exp_factor_now = exp(r_f * delta_t * n);
+        const double exp_factor_prev = exp(r_f * delta_t * (n - 1));
+        for (int i = 0; i < m; i++)
+            Y_0[i] = U[i] + delta_t * (w->A0U[i] + w->A1U[i] + w->A2U[i] + w->b[i] * exp_factor_prev);
+        for (int i = 0; i < m; i++)
+            Y_1[i] = Y_0[i] + theta * delta_t * (w->b1[i] * exp_factor_now - (w->A1U[i] + w->b1[i] * exp_factor_prev));
+        a1_solve(w, Y_1, Y_1);
+        for (int i = 0; i < m; i++)
+            Y_2[i] = Y_1[i] + theta * delta_t * (w->b2[i] * exp_factor_now - (w->A2U[i] + w->b2[i] * exp_factor_prev));
+        a2_solve(w, Y_2, Y_2);
+        a0_multiply(w, Y_2, A0Y2);
+        for (int i = 0; i < m; i++)
+            Yt[i] = Y_0[i] + 0.5 * delta_t * ((A0Y2[i] + w->b0[i] * exp_factor_now) - (w->A0U[i] + w->b0[i] * exp_factor_prev));
+        for (int i = 0; i < m; i++)
+            Yt[i] = Yt[i] + theta * delta_t * (w->b1[i] * exp_factor_now - (w->A1U[i] + w->b1[i] * exp_factor_prev));
+        a1_solve(w, Yt, Yt);
+        for (int i = 0; i < m; i++)
+            U[i] = Yt[i] + theta * delta_t * (w->b2[i] * exp_factor_now - (w->A2U[i] + w->b2[i] * exp_factor_prev));
+        a2_solve(w, U, U);
+    }
+    free(Y_0); free(Y_1); free(Y_2); free(A0Y2); free(Yt);
+}
+
 /* ---- device_solver.hpp:194-942, all four variants ---------------------------- */
 static void timestepping(ho_ws *w, const ho_params *p, const double *vec_s,
                          double *U, const double *U_0, double *lambda_bar, ho_dump *dump) {
+    if (p->scheme == 1) {
+        cs_timestepping(w, p, U);
+        return;
+    }
     const int m1 = w->m1, m = w->m, N = p->N;
     const double delta_t = p->delta_t, theta = p->theta, r_f = p->r_f;
     const int american = (p->variant == HO_AM || p->variant == HO_AM_DIV);
@@ -496,6 +535,7 @@ int ho_solve(const ho_params *p, const double *vec_s, const double *vec_v,
              const double *delta_s, const double *delta_v,
              double *U, const double *U_0, double *lambda_bar, ho_dump *dump) {
     if (p->m1 < 2 || p->m2 < 3) return -1;
+    if (p->scheme == 1 && p->variant != HO_EU) return -4; /* the reference has CS for European only */
     double *lam_own = NULL;
     if (variant_needs_payoff(p->variant)) {
         if (!U_0) return -2;

@@ -28,6 +28,7 @@ typedef struct ho_params {
     double rho, sigma, kappa, eta;
     int num_dividends;
     const double *div_dates, *div_amounts, *div_percentages;
+    int scheme; /* 0 = Douglas (device_solver.hpp), 1 = Craig-Sneyd (solver.hpp:781-907, European only) */
 } ho_params;
 
 /* Optional capture of the intermediates of time step `step` (1-based); every

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libhadi.so")
 HADI_OK = 0
 EU, AM, DIV, AM_DIV = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
+SCHEME_DOUGLAS, SCHEME_CRAIG_SNEYD = 0, 1
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -36,6 +37,7 @@ class Problem(C.Structure):
         ("num_dividends", C.c_int),
         ("dividend_dates", _dp), ("dividend_amounts", _dp), ("dividend_percentages", _dp),
         ("U", _dp), ("U_0", _dp), ("lambda_bar", _dp),
+        ("scheme", C.c_int),
     ]
 
 

@@ -35,6 +35,7 @@ struct Ctx {
     hadi_timing timing{};
     // grow-only device buffers
     DevBuf U, Y, LAM, U0, UT;
+    DevBuf V, R1, C2;                 // Craig-Sneyd: predictor result and carry-over arrays
     DevBuf scoef, b2row, rowc, a2i, pb, rinv, rwork, ipar, par8;
     DevBuf g_s, g_v, g_ds, g_dv;      // grids owned by the library (staged / broadcast)
     DevBuf src_v, src_dv, sel_a, sel_b, v0_i;
@@ -115,7 +116,7 @@ void build_v(int m2, double V_0, double V, double d, double *vec_v, double *delt
 // ---- one batched sweep ----------------------------------------------------------------------------
 struct SweepDesc {
     int n = 0;               // instances actually solved (6x the caller's for a Jacobian)
-    int m1 = 0, m2 = 0, variant = 0;
+    int m1 = 0, m2 = 0, variant = 0, scheme = 0;
     double theta = 0, r_d = 0, r_f = 0;
     std::vector<double> par8;  // [n][8] rho sigma kappa eta dt N . .
     int Nmax = 0;
@@ -130,8 +131,12 @@ struct SweepDesc {
 };
 
 template <int B, int G, int NG, int PD>
-void launch_pass_a(const HadiPlan &pl, const HadiSweepArgs &a, int n, hipStream_t s) {
-    if (a.american)
+void launch_pass_a(const HadiPlan &pl, const HadiSweepArgs &a, int n, hipStream_t s, int mode = 0) {
+    if (mode == 1)
+        hipLaunchKernelGGL((hadi_pass_a<B, G, 4, NG, PD, false, 1>), dim3(pl.grid_a), dim3(64 * pl.W * G * NG), pl.smem_a, s, a, n);
+    else if (mode == 2)
+        hipLaunchKernelGGL((hadi_pass_a<B, G, 4, NG, PD, false, 2>), dim3(pl.grid_a), dim3(64 * pl.W * G * NG), pl.smem_a, s, a, n);
+    else if (a.american)
         hipLaunchKernelGGL((hadi_pass_a<B, G, 4, NG, PD, true>), dim3(pl.grid_a), dim3(64 * pl.W * G * NG), pl.smem_a, s, a, n);
     else
         hipLaunchKernelGGL((hadi_pass_a<B, G, 4, NG, PD, false>), dim3(pl.grid_a), dim3(64 * pl.W * G * NG), pl.smem_a, s, a, n);
@@ -145,6 +150,8 @@ hipError_t raise_lds_limit(K kernel) {
 template <int B, int G, int NG, int PD>
 hipError_t raise_pass_a() {
     hipError_t e = raise_lds_limit(hadi_pass_a<B, G, 4, NG, PD, false>);
+    if (e == hipSuccess) e = raise_lds_limit(hadi_pass_a<B, G, 4, NG, PD, false, 1>);
+    if (e == hipSuccess) e = raise_lds_limit(hadi_pass_a<B, G, 4, NG, PD, false, 2>);
     return e != hipSuccess ? e : raise_lds_limit(hadi_pass_a<B, G, 4, NG, PD, true>);
 }
 hipError_t raise_all_lds_limits() {
@@ -183,6 +190,8 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         if ((rc = ensure(c, c->U0, st))) return rc;
     }
     if (dividend && (rc = ensure(c, c->UT, st))) return rc;
+    const bool cs = d.scheme == HADI_SCHEME_CRAIG_SNEYD;
+    if (cs && ((rc = ensure(c, c->V, st)) || (rc = ensure(c, c->R1, st)) || (rc = ensure(c, c->C2, st)))) return rc;
     const size_t n = d.n;
     if ((rc = ensure(c, c->scoef, pl.n_scoef * n * 8))) return rc;
     if ((rc = ensure(c, c->b2row, pl.n_b2row * n * 8))) return rc;
@@ -227,6 +236,11 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     a.pb = ptr<double>(c->pb); a.rinv = ptr<double>(c->rinv); a.ipar = ptr<HadiInstPar>(c->ipar);
     a.L = L; a.n_inst = d.n; a.R = pl.R; a.ntiles = pl.ntiles; a.ctiles = pl.ctiles; a.btpw = pl.btpw; a.bgroups = pl.bgroups;
     a.american = american ? 1 : 0; a.pos_m1 = pl.pos_m1;
+    a.R1 = cs ? ptr<double>(c->R1) : nullptr;
+    a.C2 = cs ? ptr<double>(c->C2) : nullptr;
+    // Craig-Sneyd: the predictor's column pass writes V (= Y2), the corrector's row pass reads V
+    HadiSweepArgs av = a;
+    if (cs) av.U = ptr<double>(c->V);
 
     const bool prof = c->profiling != 0;
     if (prof) {
@@ -253,32 +267,42 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                 if (cur < d.num_div && t > d.div_dates[cur]) cur++;
             }
             if (prof) HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 0], q));
-            switch (L.B * 10 + L.G) {
-                case 11: launch_pass_a<1, 1, 1, 2>(pl, a, nstep, q); break;
-                case 21: launch_pass_a<2, 1, 1, 2>(pl, a, nstep, q); break;
-                case 41: launch_pass_a<4, 1, 1, 2>(pl, a, nstep, q); break;
-                case 81: launch_pass_a<8, 1, 1, 1>(pl, a, nstep, q); break;
-                default: launch_pass_a<8, 2, 1, 1>(pl, a, nstep, q); break;
-            }
+            auto row_pass = [&](const HadiSweepArgs &ar, int mode) {
+                switch (L.B * 10 + L.G) {
+                    case 11: launch_pass_a<1, 1, 1, 2>(pl, ar, nstep, q, mode); break;
+                    case 21: launch_pass_a<2, 1, 1, 2>(pl, ar, nstep, q, mode); break;
+                    case 41: launch_pass_a<4, 1, 1, 2>(pl, ar, nstep, q, mode); break;
+                    case 81: launch_pass_a<8, 1, 1, 1>(pl, ar, nstep, q, mode); break;
+                    default: launch_pass_a<8, 2, 1, 1>(pl, ar, nstep, q, mode); break;
+                }
+            };
+            auto col_pass = [&](const HadiSweepArgs &ar) {
+                if (L.P <= 8) {
+                    if (american) hipLaunchKernelGGL((hadi_pass_b<8, true>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, q, ar, nstep);
+                    else hipLaunchKernelGGL((hadi_pass_b<8, false>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, q, ar, nstep);
+                } else {
+                    if (american) hipLaunchKernelGGL((hadi_pass_b<16, true>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, q, ar, nstep);
+                    else hipLaunchKernelGGL((hadi_pass_b<16, false>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, q, ar, nstep);
+                }
+            };
+            row_pass(a, cs ? 1 : 0);
             if (prof) {
                 HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 1], q));
                 HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 2], q));
             }
-            if (L.P <= 8) {
-                if (american) hipLaunchKernelGGL((hadi_pass_b<8, true>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, q, a, nstep);
-                else hipLaunchKernelGGL((hadi_pass_b<8, false>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, q, a, nstep);
-            } else {
-                if (american) hipLaunchKernelGGL((hadi_pass_b<16, true>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, q, a, nstep);
-                else hipLaunchKernelGGL((hadi_pass_b<16, false>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, q, a, nstep);
-            }
+            col_pass(cs ? av : a);
             if (prof) HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 3], q));
+            if (cs) {  // corrector (profiling events cover the predictor's two passes only)
+                row_pass(av, 2);
+                col_pass(a);
+            }
         }
         return HADI_OK;
     };
 
     // ---- small grids: the whole instance fits in LDS -> one launch runs the entire time loop ----------
     const size_t smem_small = american ? pl.smem_small_am : pl.smem_small_eu;
-    if (c->use_small && !prof && smem_small > 0) {
+    if (c->use_small && !prof && !cs && smem_small > 0) {
         HadiSmallArgs sm;
         sm.div_flag = nullptr; sm.div_amounts = nullptr; sm.div_pcts = nullptr; sm.vec_s = d.d_vec_s; sm.Nmax = d.Nmax;
         std::vector<int> flags;
@@ -321,9 +345,9 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         std::string key;
         auto put = [&](const void *p_, size_t nbytes) { key.append(static_cast<const char *>(p_), nbytes); };
         {  // field by field: struct padding is not initialised
-            const void *ptrs[] = {a.U, a.Y, a.LAM, a.U0, a.scoef, a.b2row, a.rowc, a.pb, a.rinv, a.ipar};
+            const void *ptrs[] = {a.U, a.Y, a.LAM, a.U0, a.scoef, a.b2row, a.rowc, a.pb, a.rinv, a.ipar, a.R1, a.C2, av.U};
             const int ints[] = {a.L.m1, a.L.m2, a.L.B, a.L.G, a.L.P, a.n_inst, a.R, a.ntiles, a.ctiles, a.btpw, a.bgroups,
-                                a.american, a.pos_m1, pl.grid_a, pl.grid_b, pl.block_b, pl.W, (int)pl.smem_a, (int)pl.smem_b};
+                                a.american, a.pos_m1, d.scheme, pl.grid_a, pl.grid_b, pl.block_b, pl.W, (int)pl.smem_a, (int)pl.smem_b};
             put(ptrs, sizeof(ptrs));
             put(ints, sizeof(ints));
         }
@@ -430,6 +454,10 @@ int check_problem(Ctx *c, const hadi_problem *p, bool need_U, bool need_vgrid) {
     if (dividend && p->num_dividends > 0 && (!p->dividend_dates || !p->dividend_amounts || !p->dividend_percentages))
         return fail(c, HADI_ERR_INVALID, "dividend arrays missing");
     if (p->num_dividends < 0) return fail(c, HADI_ERR_INVALID, "num_dividends < 0");
+    if (p->scheme != HADI_SCHEME_DOUGLAS && p->scheme != HADI_SCHEME_CRAIG_SNEYD)
+        return fail(c, HADI_ERR_INVALID, "bad scheme %d", p->scheme);
+    if (p->scheme == HADI_SCHEME_CRAIG_SNEYD && p->variant != HADI_EU)
+        return fail(c, HADI_ERR_UNSUPPORTED, "Craig-Sneyd is available for the European variant only (as in the reference)");
     return HADI_OK;
 }
 
@@ -455,7 +483,7 @@ void fill_par(const hadi_problem *p, SweepDesc &d, int groups) {
 }
 
 void fill_common(const hadi_problem *p, SweepDesc &d) {
-    d.m1 = p->m1; d.m2 = p->m2; d.variant = p->variant;
+    d.m1 = p->m1; d.m2 = p->m2; d.variant = p->variant; d.scheme = p->scheme;
     d.theta = p->theta; d.r_d = p->r_d; d.r_f = p->r_f;
     const bool dividend = p->variant == HADI_DIV || p->variant == HADI_AM_DIV;
     d.num_div = dividend ? p->num_dividends : 0;
@@ -702,7 +730,7 @@ int hadi_destroy(hadi_ctx *ctx) {
     DevBuf *bufs[] = {&c->U, &c->Y, &c->LAM, &c->U0, &c->UT, &c->scoef, &c->b2row, &c->rowc, &c->a2i, &c->pb,
                       &c->rinv, &c->rwork, &c->ipar, &c->par8, &c->g_s, &c->g_v, &c->g_ds, &c->g_dv, &c->src_v,
                       &c->src_dv, &c->sel_a, &c->sel_b, &c->v0_i, &c->natU, &c->natU0, &c->natOut, &c->prices,
-                      &c->status, &c->div_flag, &c->div_amt, &c->div_pct};
+                      &c->status, &c->div_flag, &c->div_amt, &c->div_pct, &c->V, &c->R1, &c->C2};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto &g : c->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }

@@ -29,6 +29,7 @@ struct HadiSweepArgs {
     double *U;         // solution
     double *Y;         // A2 right-hand side between the passes
     double *LAM;       // lambda_bar (American) or nullptr
+    double *R1, *C2;   // Craig-Sneyd only: predictor quantities reused by the corrector (see hadi_row_step)
     const double *U0;  // payoff (American) or nullptr
     // tables
     const double *scoef, *b2row, *rowc, *pb, *rinv;
@@ -208,6 +209,7 @@ struct HadiRowCtx {
     const double *rowc;  // LDS copy of the row table of this block's tile: entry (j - j0)
     int j0;              // first v-row of the tile
     const double *b2r;   // instance b2 row (global)
+    double *R1i, *C2i;   // instance bases of the Craig-Sneyd carry-over arrays (MODE 1 writes, MODE 2 reads)
     int lane, half, wrow, posL, posR, rowp;
     double dt, thdt, qd, half_rd, e_nm1, e_n;
     HADI_STAMP_ACC
@@ -245,7 +247,12 @@ HADI_DEV HADI_FORCEINLINE void hadi_put_block(double *row, int half, int lane, c
 // One v-row: explicit stage, Y0, A1 line solve, A2 right-hand side.  LAST = this is the v-row that
 // carries b2 (hes_boundary_kernels.hpp:62-66); AMER adds lambda_bar (device_solver.hpp:325-331).
 // `active` is wave-uniform; with G = 2 every wave of the block must call this (it contains a barrier).
-template <int B, int G, bool AMER, bool LAST>
+// MODE 0: Douglas step.  MODE 1 / 2: predictor / corrector of Craig-Sneyd (solver.hpp:781-907).  With
+//   Y1rhs = Y0 + theta dt (b1 e_n - (A1U + b1 e_{n-1})),  C2 = theta dt (b2 e_n - (A2U + b2 e_{n-1}))
+// the corrector's A1 right-hand side is Y0~ + theta dt (...) = Y1rhs + dt/2 (A0 Y2 - A0 U): MODE 1 is a
+// Douglas row step that also stores R1 = Y1rhs - dt/2 A0U and C2; MODE 2 takes its rows from Y2, forms
+// R1 + dt/2 A0 Y2, runs the same A1 solve and adds C2 -- it never needs U, A1U or A2U again.
+template <int B, int G, bool AMER, bool LAST, int MODE = 0>
 HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtx &c, bool active, int j, const double *rm2,
                                              const double *rm1, const double *r0, const double *rp1,
                                              const double *rp2) {
@@ -255,7 +262,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtx &c, bool active, i
     const double dt = c.dt, thdt = c.thdt, qd = c.qd, half_rd = c.half_rd, e_nm1 = c.e_nm1, e_n = c.e_n;
     const bool first_half = (half == 0), last_half = (half == G - 1);
     // state that survives the exchange barrier
-    double ys[B], ps[B], gs[B], A2U[B], b2v[B];
+    double ys[B], ps[B], gs[B], A2U[B], b2v[B], r1v[B], c2v[B];
     double Ysol = 0.0, Ssol = 0.0, yout_c0 = 0.0;
 
     HADI_STAMP_DECL(c.stamp_acc_)
@@ -283,8 +290,19 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtx &c, bool active, i
         const double lamc0 = AMER ? c.Li[(size_t)j * rowp + c0slot] : 0.0;
         double y0c0 = c0 + dt * (a2c0 + (b1c0 + b2c0) * e_nm1 + lamc0);
         y0c0 = y0c0 + thdt * (b1c0 * e_n - (0.0 + b1c0 * e_nm1));
+        double c2c0 = thdt * (b2c0 * e_n - (a2c0 + b2c0 * e_nm1));
+        if constexpr (MODE == 1) {  // A0 is zero on i = 0: R1 = Y1rhs there
+            if (lane == 0 && first_half) {
+                c.R1i[(size_t)j * rowp + c0slot] = y0c0;
+                c.C2i[(size_t)j * rowp + c0slot] = c2c0;
+            }
+        }
+        if constexpr (MODE == 2) {
+            y0c0 = c.R1i[(size_t)j * rowp + c0slot];
+            c2c0 = c.C2i[(size_t)j * rowp + c0slot];
+        }
         const double x0 = y0c0;  // A1 row 0 is the identity (hes_a1_kernels.hpp:56-61)
-        yout_c0 = x0 + thdt * (b2c0 * e_n - (a2c0 + b2c0 * e_nm1));
+        yout_c0 = x0 + c2c0;
 
         HADI_STAMP(0);  // row scalars + column 0
         // ---- explicit operators.  A0 = (s-derivative) o (v-derivative): first the v-combination
@@ -316,6 +334,10 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtx &c, bool active, i
         double lam[B];
         if constexpr (AMER) hadi_get_block<B, G>(c.Li + (size_t)j * rowp, half, lane, lam);
         if constexpr (LAST) hadi_get_block<B, G>(c.b2r, half, lane, b2v);
+        if constexpr (MODE == 2) {
+            hadi_get_block<B, G>(c.R1i + (size_t)j * rowp, half, lane, r1v);
+            hadi_get_block<B, G>(c.C2i + (size_t)j * rowp, half, lane, c2v);
+        }
 
         // ---- Y0 (device_solver.hpp:236-250) fused with the forward sweep of the in-lane Thomas ----------
         //   x[r] = ys[r] - XL*ps[r] - X*gs[r],  XL = interface unknown of lane-1, X = own x[B-1]
@@ -347,6 +369,8 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtx &c, bool active, i
             double y = fma(dt, S, u0[r]);
             y = fma(-thdt, A1U, y);
             y = fma(b1h, cb1, y);
+            if constexpr (MODE == 1) r1v[r] = fma(-0.5 * dt, A0U, y);
+            if constexpr (MODE == 2) y = fma(0.5 * dt, A0U, r1v[r]);  // A0U is A0 applied to Y2 here
             double il = -thdt * lo;
             const double im = 1.0 - thdt * mn;
             iu[r] = -thdt * up;
@@ -477,8 +501,16 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtx &c, bool active, i
             double x;
             if (r < NB) x = ys[r] - XL * ps[r] - X * gs[r];
             else x = X;
-            if constexpr (LAST) yo[r] = x + thdt * (b2v[r] * e_n - (A2U[r] + b2v[r] * e_nm1));
-            else yo[r] = x - thdt * A2U[r];
+            double corr;
+            if constexpr (MODE == 2) corr = c2v[r];
+            else if constexpr (LAST) corr = thdt * (b2v[r] * e_n - (A2U[r] + b2v[r] * e_nm1));
+            else corr = -thdt * A2U[r];
+            yo[r] = x + corr;
+            if constexpr (MODE == 1) c2v[r] = corr;
+        }
+        if constexpr (MODE == 1) {
+            hadi_put_block<B, G>(c.R1i + (size_t)j * rowp, half, lane, r1v);
+            hadi_put_block<B, G>(c.C2i + (size_t)j * rowp, half, lane, c2v);
         }
         hadi_put_block<B, G>(c.Yi + (size_t)j * rowp, half, lane, yo);
         if (lane == 0 && first_half) c.Yi[(size_t)j * rowp + c0slot] = yout_c0;
@@ -520,7 +552,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_wait_vmcnt(int n) {
 // s-coefficient arrays are shared), PD = prefetch depth in iterations: the ring holds (PD+1)*W + 4 rows.
 // (B, G) = (8, 1) runs NG = 2, PD = 2: one 8-wave block per CU whose 158 KB of LDS keep two iterations of
 // rows in flight per wavefront -- the latency-bandwidth product of a CU needs more than one.
-template <int B, int G, int W, int NG, int PD, bool AMER>
+template <int B, int G, int W, int NG, int PD, bool AMER, int MODE = 0>
 __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : 4)) hadi_pass_a(HadiSweepArgs a, int n) {
     HADI_DYN_SMEM(double, smem);
     constexpr int RING = (PD + 1) * W + 4;
@@ -553,6 +585,8 @@ __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : 4)) hadi_pass_a
     c.Yi = a.Y + (size_t)inst * a.L.inst_stride;
     c.Li = AMER ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
     c.b2r = a.b2row + (size_t)inst * rowp;
+    c.R1i = MODE ? a.R1 + (size_t)inst * a.L.inst_stride : nullptr;
+    c.C2i = MODE ? a.C2 + (size_t)inst * a.L.inst_stride : nullptr;
     c.j0 = j0;
     constexpr int c0slot = 64 * B * G;
     // storage positions of the s-neighbours of this lane's block (node before its first, node after its
@@ -622,9 +656,9 @@ __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : 4)) hadi_pass_a
             if (!active) continue;
         }
         if (j == nrows - 1)
-            hadi_row_step<B, G, AMER, true>(c, active, j, slot(j - 2), slot(j - 1), slot(j), slot(j + 1), slot(j + 2));
+            hadi_row_step<B, G, AMER, true, MODE>(c, active, j, slot(j - 2), slot(j - 1), slot(j), slot(j + 1), slot(j + 2));
         else
-            hadi_row_step<B, G, AMER, false>(c, active, j, slot(j - 2), slot(j - 1), slot(j), slot(j + 1), slot(j + 2));
+            hadi_row_step<B, G, AMER, false, MODE>(c, active, j, slot(j - 2), slot(j - 1), slot(j), slot(j + 1), slot(j + 2));
         if (active) {  // B/2 (one for B = 1) vector stores of the block; the i = 0 store is not counted (lower bound)
 #pragma unroll
             for (int k = 0; k < PD; k++) ya[k] += (B == 1 ? 1 : B / 2);
@@ -868,7 +902,7 @@ __global__ void __launch_bounds__(64 * W) hadi_small_kernel(HadiSweepArgs a, Had
     c.Yi = Yl; c.Li = AMER ? LAMl : nullptr;
     c.rowc = rtab; c.j0 = 0;
     c.b2r = a.b2row + (size_t)inst * rowp;
-    c.coef = coef; c.xch = nullptr;
+    c.coef = coef; c.xch = nullptr; c.R1i = nullptr; c.C2i = nullptr;
     {
         const int ifirst = 1 + B * lane;
         c.posL = hadi_pos(B, G, ifirst - 1);

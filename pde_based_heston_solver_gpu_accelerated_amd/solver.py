@@ -123,7 +123,7 @@ class HestonADI:
 
     # ---- problem assembly ---------------------------------------------------------------------
     def _problem(self, variant, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids,
-                 U=None, U_0=None, lambda_bar=None, dividends=None, per_instance=None, need_vgrid=True):
+                 U=None, U_0=None, lambda_bar=None, dividends=None, per_instance=None, need_vgrid=True, scheme=0):
         n = grids.Vec_s.shape[0]
         m = (m1 + 1) * (m2 + 1)
         p = nat.Problem()
@@ -137,6 +137,7 @@ class HestonADI:
             return ptr
 
         p.n_instances, p.m1, p.m2, p.variant = n, m1, m2, variant
+        p.scheme = int(scheme)
         p.N, p.delta_t, p.theta = int(N), float(delta_t), float(theta)
         p.r_d, p.r_f = float(r_d), float(r_f)
         p.rho, p.sigma, p.kappa, p.eta = float(rho), float(sigma), float(kappa), float(eta)
@@ -188,15 +189,23 @@ class HestonADI:
 
     # ---- device_DO_timestepping* (src/device_solver.hpp:194-942) -------------------------------
     def DO_timestepping(self, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids, U,
-                        variant=EU, U_0=None, lambda_bar=None, dividends=None, per_instance=None):
+                        variant=EU, U_0=None, lambda_bar=None, dividends=None, per_instance=None, scheme=0):
         """Boundary init + operator build + N Douglas steps on the caller's grids; U is updated in
-        place (initial condition in, solution at T out)."""
+        place (initial condition in, solution at T out).  scheme=1 runs Craig-Sneyd (European only)."""
         p = self._problem(variant, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids,
-                          U=U, U_0=U_0, lambda_bar=lambda_bar, dividends=dividends, per_instance=per_instance)
+                          U=U, U_0=U_0, lambda_bar=lambda_bar, dividends=dividends, per_instance=per_instance,
+                          scheme=scheme)
         rc = self._lib.hadi_DO_timestepping(self._h, C.byref(p))
         if rc != nat.HADI_OK:
             self._raise(rc)
         return U
+
+    # ---- CS_scheme_shuffled (src/solver.hpp:781-907), batched on the device -----------------------
+    def CS_scheme(self, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids, U, per_instance=None):
+        """Craig-Sneyd time stepping of European options: Douglas predictor + corrector that re-adds half of
+        the explicit mixed-derivative increment (the reference has it in its host operator family only)."""
+        return self.DO_timestepping(m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids, U,
+                                    per_instance=per_instance, scheme=nat.SCHEME_CRAIG_SNEYD)
 
     # ---- parallel_DO_solve (src/device_solver.hpp:52-185) --------------------------------------
     def parallel_DO_solve(self, nInstances, S_0, V_0, m1, m2, N, T, delta_t, theta, r_d, r_f, rho, sigma,

@@ -13,9 +13,29 @@ thread_local int t_lane;
 }  // namespace emu
 
 template <int B, int G, int NG, int PD>
-static void run_pass_a(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
-    if (a.american) emu::launch(pl.grid_a, 64 * pl.W * G * NG, [&]() { hadi_pass_a<B, G, 4, NG, PD, true>(a, n); }, pl.smem_a);
-    else emu::launch(pl.grid_a, 64 * pl.W * G * NG, [&]() { hadi_pass_a<B, G, 4, NG, PD, false>(a, n); }, pl.smem_a);
+static void run_pass_a(const HadiPlan &pl, const HadiSweepArgs &a, int n, int mode) {
+    const unsigned nt = 64 * pl.W * G * NG;
+    if (mode == 1) emu::launch(pl.grid_a, nt, [&]() { hadi_pass_a<B, G, 4, NG, PD, false, 1>(a, n); }, pl.smem_a);
+    else if (mode == 2) emu::launch(pl.grid_a, nt, [&]() { hadi_pass_a<B, G, 4, NG, PD, false, 2>(a, n); }, pl.smem_a);
+    else if (a.american) emu::launch(pl.grid_a, nt, [&]() { hadi_pass_a<B, G, 4, NG, PD, true>(a, n); }, pl.smem_a);
+    else emu::launch(pl.grid_a, nt, [&]() { hadi_pass_a<B, G, 4, NG, PD, false>(a, n); }, pl.smem_a);
+}
+
+static int run_row_pass(const HadiPlan &pl, const HadiSweepArgs &a, int n, int mode) {
+    switch (pl.L.B * 10 + pl.L.G) {
+        case 11: run_pass_a<1, 1, 1, 2>(pl, a, n, mode); break;
+        case 21: run_pass_a<2, 1, 1, 2>(pl, a, n, mode); break;
+        case 41: run_pass_a<4, 1, 1, 2>(pl, a, n, mode); break;
+        case 81: run_pass_a<8, 1, 1, 1>(pl, a, n, mode); break;
+        case 82: run_pass_a<8, 2, 1, 1>(pl, a, n, mode); break;
+        default: return 2;
+    }
+    return 0;
+}
+
+static void run_col_pass(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
+    if (a.american) emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b<16, true>(a, n); }, pl.smem_b);
+    else emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b<16, false>(a, n); }, pl.smem_b);
 }
 
 extern "C" int emu_plan(int m1, int m2, int n_inst, int target_waves, int *out /*B,rowp,P,R,ntiles,ctiles*/) {
@@ -30,12 +50,14 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
                          const double *par /*[n][4] rho sigma kappa eta*/, int variant, const double *vec_s,
                          const double *vec_v, const double *delta_s, const double *delta_v, double *U,
                          const double *U0, double *lam_out, int target_waves, int ndiv, const double *ddates,
-                         const double *damounts, const double *dpcts, int setup_threads, int use_small) {
+                         const double *damounts, const double *dpcts, int setup_threads, int use_small, int scheme) {
     HadiPlan pl;
     if (hadi_make_plan(m1, m2, n_inst, target_waves, &pl)) return 1;
     const HadiLayout &L = pl.L;
     const int american = variant & 1, dividend = (variant >> 1) & 1;
     const size_t st = (size_t)L.inst_stride * n_inst;
+    const bool cs = scheme == 1;
+    std::vector<double> dV(cs ? st : 0), dR1(cs ? st : 0), dC2(cs ? st : 0);
     std::vector<double> dU(st), dY(st, 0.0), dLAM(american ? st : 0), dU0(american ? st : 0), dUT(dividend ? st : 0);
     std::vector<double> scoef(pl.n_scoef * n_inst), b2row(pl.n_b2row * n_inst), rowc(pl.n_rowc * n_inst),
         a2i(pl.n_a2i * n_inst), pb(pl.n_pb * n_inst), rinv(pl.n_rinv * n_inst), rwork(pl.n_rwork * n_inst);
@@ -64,9 +86,12 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
     a.scoef = scoef.data(); a.b2row = b2row.data(); a.rowc = rowc.data(); a.pb = pb.data(); a.rinv = rinv.data();
     a.ipar = ipar.data(); a.L = L; a.n_inst = n_inst; a.R = pl.R; a.ntiles = pl.ntiles; a.ctiles = pl.ctiles; a.btpw = pl.btpw; a.bgroups = pl.bgroups;
     a.american = american; a.pos_m1 = pl.pos_m1;
+    a.R1 = cs ? dR1.data() : nullptr; a.C2 = cs ? dC2.data() : nullptr;
+    HadiSweepArgs av = a;
+    if (cs) av.U = dV.data();
 
     const size_t smem_small = american ? pl.smem_small_am : pl.smem_small_eu;
-    if (use_small && smem_small > 0) {
+    if (use_small && !cs && smem_small > 0) {
         std::vector<int> flags(N, -1);
         int cc = 0;
         for (int n = 1; n <= N; n++) {
@@ -100,16 +125,12 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
             }
             if (cur < ndiv && t > ddates[cur]) cur++;
         }
-        switch (L.B * 10 + L.G) {
-            case 11: run_pass_a<1, 1, 1, 2>(pl, a, n); break;
-            case 21: run_pass_a<2, 1, 1, 2>(pl, a, n); break;
-            case 41: run_pass_a<4, 1, 1, 2>(pl, a, n); break;
-            case 81: run_pass_a<8, 1, 1, 1>(pl, a, n); break;
-            case 82: run_pass_a<8, 2, 1, 1>(pl, a, n); break;
-            default: return 2;
+        if (run_row_pass(pl, a, n, cs ? 1 : 0)) return 2;
+        run_col_pass(pl, cs ? av : a, n);
+        if (cs) {
+            run_row_pass(pl, av, n, 2);
+            run_col_pass(pl, a, n);
         }
-        if (a.american) emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b<16, true>(a, n); }, pl.smem_b);
-        else emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b<16, false>(a, n); }, pl.smem_b);
     }
     emu::launch(8, 64, [&]() { hadi_unpack_kernel(L, n_inst, dU.data(), U); });
     if (american && lam_out) emu::launch(8, 64, [&]() { hadi_unpack_kernel(L, n_inst, dLAM.data(), lam_out); });

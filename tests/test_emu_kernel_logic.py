@@ -35,17 +35,18 @@ def emu():
     return C.CDLL(EMU_SO)
 
 
-def _run(emu, m1, m2, N, strikes, variant, target_waves, r_f=0.0, small=0):
+def _run(emu, m1, m2, N, strikes, variant, target_waves, r_f=0.0, small=0, scheme=0):
     n = len(strikes)
     vs, vv, ds, dv, U0 = Cm.oracle_grids(m1, m2, strikes)
     p = Cm.oracle_params(m1, m2, N, variant, r_f=r_f)
+    p.scheme = scheme
     Uo, lamo, _ = O.solve_batch(p, vs, vv, ds, dv, U0, U0, want_lambda=True)
     U, lam = U0.copy(), np.zeros_like(U0)
     par = np.tile(np.array([Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA]), (n, 1)).copy()
     dd = [np.array(x, dtype=np.float64) for x in Cm.DIVS]
     rc = emu.emu_solve(n, m1, m2, N, C.c_double(Cm.T / N), C.c_double(Cm.THETA), C.c_double(Cm.R_D),
                        C.c_double(r_f), _P(par), variant, _P(vs), _P(vv), _P(ds), _P(dv), _P(U), _P(U0), _P(lam),
-                       target_waves, len(dd[0]), _P(dd[0]), _P(dd[1]), _P(dd[2]), 64, small)
+                       target_waves, len(dd[0]), _P(dd[0]), _P(dd[1]), _P(dd[2]), 64, small, scheme)
     assert rc == 0
     scale = np.abs(Uo).max()
     assert np.abs(U - Uo).max() < 1e-11 * scale
@@ -74,6 +75,12 @@ def test_two_waves_per_row_split_solve(emu):
     # m1 > 512: the row's tridiagonal system is split over two wavefronts and re-coupled by a 2x2 system
     _run(emu, 600, 12, 2, [100.0, 93.0], O.EU, 8)
     _run(emu, 530, 10, 2, [100.0], O.AM, 8, r_f=0.01)
+
+
+def test_craig_sneyd_predictor_corrector(emu):
+    # solver.hpp:781-907: Douglas predictor + corrector re-adding dt/2 (A0 Y2 - A0 U); r_f != 0 exercises the b terms
+    _run(emu, 40, 12, 3, [100.0, 91.0], O.EU, 8, r_f=0.01, scheme=1)
+    _run(emu, 100, 20, 2, [100.0], O.EU, 8, scheme=1)
 
 
 def test_small_grid_lds_resident_kernel(emu):

@@ -117,6 +117,35 @@ def test_small_grid_kernel_and_streaming_kernels_agree(solver, variant, name):
     assert np.array_equal(fields[1][0], fields[2][0])  # graph replay == direct launches, bit for bit
 
 
+@pytest.mark.parametrize("m1,m2,N,n", [(50, 25, 20, 4), (128, 64, 8, 2), (512, 256, 6, 2), (700, 300, 3, 1)])
+def test_craig_sneyd_vs_oracle(solver, m1, m2, N, n):
+    """Craig-Sneyd on the device (N3: the reference has it host-side only, solver.hpp:781-907) against the
+    oracle's restatement, full field, incl. the streaming kernels at 1 and 2 wavefronts per row."""
+    strikes = Cm.strikes_for(n)
+    grids, U0 = _batch(m1, m2, strikes)
+    U = U0.copy()
+    solver.CS_scheme(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.007, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U)
+    p = Cm.oracle_params(m1, m2, N, "EU", r_f=0.007)
+    p.scheme = 1
+    Uo, _, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0)
+    _assert_field(U, Uo)
+
+
+def test_craig_sneyd_reference_price_and_restrictions(solver):
+    c = Cm.GOLDEN["craig_sneyd"]
+    m1, m2, N, K = c["m1"], c["m2"], c["N"], float(c["K"])
+    grids, U0 = _batch(m1, m2, [K])
+    U = U0.copy()
+    solver.CS_scheme(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U)
+    g = H.Grid(m1, 8 * K, Cm.S_0, K, K / 5, m2, 5.0, Cm.V_0, 0.01)
+    price = U[0, g.find_s_index(Cm.S_0) + g.find_v0_index(Cm.V_0) * (m1 + 1)]
+    assert abs(price - c["price"]) <= PRICE_ATOL
+    with pytest.raises(H.HadiError) as e:  # European only, as in the reference
+        solver.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids,
+                               U0.copy(), variant=H.AM, U_0=U0, scheme=1)
+    assert e.value.status == 2
+
+
 def test_foreign_rate_boundary_terms(solver):
     """r_f != 0 switches on the time-dependent boundary factors exp(r_f dt n) (device_solver.hpp:238-247)
     that every reference test leaves at 1."""

@@ -50,6 +50,22 @@ def test_jacobian_row_matches_reference_output():
     assert np.abs(J[0] - np.array(j["J_row_0"])).max() < 0.5e-12  # printed to 12 decimals
 
 
+def test_craig_sneyd_price_matches_reference_output():
+    """CS_scheme_shuffled (solver.hpp:781-907) on the reference's 50x25x20 test grid: all 16 recorded digits."""
+    c = Cm.GOLDEN["craig_sneyd"]
+    m1, m2, N, K = c["m1"], c["m2"], c["N"], float(c["K"])
+    vs, vv, ds, dv, U0 = Cm.oracle_grids(m1, m2, [K])
+    p = Cm.oracle_params(m1, m2, N, "EU")
+    p.scheme = 1
+    U, _, _ = O.solve(p, vs[0], vv[0], ds[0], dv[0], U0[0])
+    price = U[O.find_s_index(vs[0], Cm.S_0) + O.find_v_index(vv[0], Cm.V_0) * (m1 + 1)]
+    assert abs(price - c["price"]) <= 1e-15 * c["price"]
+    pa = Cm.oracle_params(m1, m2, N, "AM")
+    pa.scheme = 1
+    with pytest.raises(RuntimeError):  # the reference has CS for European options only
+        O.solve(pa, vs[0], vv[0], ds[0], dv[0], U0[0], U0[0])
+
+
 def test_external_targets_are_loose():
     """The prices hard-coded in the reference's prints are external targets ~1e-3 away from the
     scheme's own 50x25x20 output -- documents why they cannot pin parity."""
