@@ -11,7 +11,8 @@ from .solver import (HestonADI, DOWorkspace, Dividends, compute_parameter_update
                      lm_partials, lm_solve)
 from .distributed import Communicator, shard_range  # noqa: F401
 from .calibration import calibrate_european, clamp_parameters  # noqa: F401
+from . import market  # noqa: F401
 
 __all__ = ["EU", "AM", "DIV", "AM_DIV", "HadiError", "Grid", "GridViewsBatch", "HestonADI", "DOWorkspace",
            "Dividends", "compute_parameter_update", "lm_partials", "lm_solve", "LIB_PATH", "Communicator",
-           "shard_range", "calibrate_european", "clamp_parameters"]
+           "shard_range", "calibrate_european", "clamp_parameters", "market"]

@@ -365,6 +365,16 @@ def test_lm_calibration_trajectory_vs_oracle_driven_loop(solver):
     assert got["history"][-1]["error"] < 0.5 * got["history"][0]["error"]
 
 
+def test_full_lm_calibration_reproduces_reference_run_on_gpu(solver):
+    """N1 end to end on the device: the reference's test_calibration_european (60 strikes, 50x25x20, BS market at 20 %)
+    run through libhadi lands on the recorded result -- 4 iterations, 1620 PDE solves, final error 0.0836893 and the
+    five parameters to the printed 6 digits (tests/golden)."""
+    import test_oracle_golden as G
+    g, args = G._reference_calibration_setup()
+    res = H.calibrate_european(solver, *args, max_iter=15, tol=0.1)
+    G.check_calibration_against_record(res, g)
+
+
 def test_profiling_reports_kernel_times(solver):
     m1, m2, N = 128, 64, 20
     solver.set_profiling(True)

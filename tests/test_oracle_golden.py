@@ -3,6 +3,7 @@ tests/golden/reference_known_answers.json).  CPU only."""
 import numpy as np
 import pytest
 
+import pde_based_heston_solver_gpu_accelerated_amd as H
 from oracle import oracle as O
 
 import common as Cm
@@ -90,3 +91,32 @@ def test_implicit_solve_residuals():
     _, _, d3 = O.solve(p, vs[0], vv[0], ds[0], dv[0], d["Unext"], d["Unext"], dump_step=1)
     res2 = d["Unext"] - thdt * d3["A2U"] - d["Y1rhs"]
     assert np.abs(res2).max() < 1e-10 * max(1.0, np.abs(d["Y1rhs"]).max())
+
+
+def _reference_calibration_setup():
+    """test_calibration_european's setup, heston_calibration.cpp:26-120."""
+    g = Cm.GOLDEN["calibration_european"]
+    strikes = [Cm.S_0 * 0.7 + i for i in range(60)]
+    m1, m2, N = 50, 25, 20
+    grids = H.GridViewsBatch.for_strikes(m1, m2, Cm.S_0, Cm.V_0, strikes)
+    U0 = grids.call_payoff(strikes)
+    market = H.market.generate_market_data(Cm.S_0, Cm.T, Cm.R_D, strikes)
+    args = (Cm.S_0, Cm.T, Cm.R_D, Cm.R_F, Cm.KAPPA, Cm.ETA, Cm.SIGMA, Cm.RHO, Cm.V_0, m1, m2, N, Cm.THETA, grids, U0, market)
+    return g, args
+
+
+def check_calibration_against_record(res, g):
+    tol = 0.5 * 10.0 ** (1 - g["digits"])  # the record prints 6 significant digits
+    assert res["converged"] and res["iterations"] == g["iterations"] and res["pde_solves"] == g["pde_solves"]
+    assert abs(res["final_error"] - g["final_error"]) <= tol * g["final_error"]
+    for k in ("kappa", "eta", "sigma", "rho", "v0"):
+        assert abs(res[k] - g[k]) <= tol * abs(g[k]), (k, res[k], g[k])
+
+
+def test_full_lm_calibration_reproduces_reference_run():
+    """N1 + N4 pin: oracle solves + the LM host loop + Black-Scholes market data reproduce the recorded output of
+    the reference's test_calibration_european: 4 iterations, 1620 PDE solves, final error and all
+    five calibrated parameters to the 6 printed digits."""
+    g, args = _reference_calibration_setup()
+    res = H.calibrate_european(Cm.OracleSolver(), *args, max_iter=15, tol=0.1)
+    check_calibration_against_record(res, g)
