@@ -10,9 +10,15 @@ from .grid import Grid, GridViewsBatch  # noqa: F401
 from .solver import (HestonADI, DOWorkspace, Dividends, compute_parameter_update,  # noqa: F401
                      lm_partials, lm_solve)
 from .distributed import Communicator, shard_range  # noqa: F401
-from .calibration import calibrate_european, clamp_parameters  # noqa: F401
+from .calibration import (CalibrationPoint, calibrate, calibrate_american, calibrate_american_dividends,  # noqa: F401
+                          calibrate_american_dividends_multi_maturity, calibrate_dividends, calibrate_european,
+                          calibrate_european_multi_maturity, clamp_parameters, export_calibration_csv,
+                          make_calibration_points)
 from . import market  # noqa: F401
 
 __all__ = ["EU", "AM", "DIV", "AM_DIV", "HadiError", "Grid", "GridViewsBatch", "HestonADI", "DOWorkspace",
            "Dividends", "compute_parameter_update", "lm_partials", "lm_solve", "LIB_PATH", "Communicator",
-           "shard_range", "calibrate_european", "clamp_parameters", "market"]
+           "shard_range", "calibrate_european", "clamp_parameters", "market", "CalibrationPoint", "calibrate",
+           "calibrate_american", "calibrate_dividends", "calibrate_american_dividends",
+           "calibrate_european_multi_maturity", "calibrate_american_dividends_multi_maturity",
+           "make_calibration_points", "export_calibration_csv"]

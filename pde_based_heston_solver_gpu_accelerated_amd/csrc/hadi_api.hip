@@ -179,8 +179,6 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     const HadiLayout &L = pl.L;
     const bool american = d.variant == HADI_AM || d.variant == HADI_AM_DIV;
     const bool dividend = d.variant == HADI_DIV || d.variant == HADI_AM_DIV;
-    if (dividend && !d.uniform_steps)
-        return fail(c, HADI_ERR_UNSUPPORTED, "dividends need one shared (N, delta_t) for the batch");
     const size_t st = (size_t)L.inst_stride * d.n * sizeof(double);
     int rc;
     if ((rc = ensure(c, c->U, st))) return rc;
@@ -206,6 +204,31 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     hipStream_t s = c->stream;
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     HIP_TRY(c, hipMemcpyAsync(c->par8.p, d.par8.data(), 8 * 8 * n, hipMemcpyHostToDevice, s));
+    // Discrete dividends: host-built table "which dividend does instance k pay at the start of step n" (one shared
+    // row when the batch has a single (N, delta_t)), plus the set of steps where anybody pays.
+    std::vector<int> div_flags;
+    std::vector<char> div_step(d.Nmax + 1, 0);
+    const int flag_stride = d.uniform_steps ? 0 : d.Nmax;
+    const bool have_div = dividend && d.num_div > 0;
+    if (have_div) {
+        const int rows = d.uniform_steps ? 1 : d.n;
+        div_flags.resize((size_t)rows * d.Nmax);
+        for (int k = 0; k < rows; k++) {
+            const double dt = d.par8[(size_t)k * 8 + 4];
+            const int N = (int)d.par8[(size_t)k * 8 + 5];
+            int *f = div_flags.data() + (size_t)k * d.Nmax;
+            hadi_dividend_steps(N, dt, d.num_div, d.div_dates, f, d.Nmax);
+            for (int q = 0; q < d.Nmax; q++)
+                if (f[q] >= 0) div_step[q + 1] = 1;
+        }
+        if ((rc = ensure(c, c->div_flag, div_flags.size() * sizeof(int))) || (rc = ensure(c, c->div_amt, d.num_div * 8)) ||
+            (rc = ensure(c, c->div_pct, d.num_div * 8)))
+            return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->div_flag.p, div_flags.data(), div_flags.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->div_amt.p, d.div_amounts, d.num_div * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->div_pct.p, d.div_pcts, d.num_div * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipStreamSynchronize(s));  // pageable staging: the vectors may be reused by the next call
+    }
     // identity padding rows of Y must read as zeros in the column pass (the row pass never writes them)
     HIP_TRY(c, hipMemsetAsync(c->Y.p, 0, st, s));
 
@@ -253,18 +276,13 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     }
     // The whole time loop as a function of the stream, so it can be enqueued directly or captured.
     auto enqueue_loop = [&](hipStream_t q) -> int {
-        int cur = 0;
         for (int nstep = 1; nstep <= d.Nmax; nstep++) {
-            if (dividend) {
-                // device_solver.hpp:426-447,508-516; n*delta_t in floating point decides the step
-                const double t = nstep * d.dt0;
-                if (cur < d.num_div && t <= d.div_dates[cur] && d.div_dates[cur] < (nstep + 1) * d.dt0) {
-                    HIP_TRY(c, hipMemcpyAsync(c->UT.p, c->U.p, st, hipMemcpyDeviceToDevice, q));
-                    const size_t npts = (size_t)d.n * L.nrows * (L.m1 + 1);
-                    hipLaunchKernelGGL(hadi_dividend_kernel, dim3(grid1d(npts)), dim3(256), 0, q, L, d.n, d.d_vec_s,
-                                       ptr<double>(c->UT), ptr<double>(c->U), d.div_amounts[cur], d.div_pcts[cur]);
-                }
-                if (cur < d.num_div && t > d.div_dates[cur]) cur++;
+            if (have_div && div_step[nstep]) {  // device_solver.hpp:426-517: U_temp <- U, U <- interpolated jump
+                HIP_TRY(c, hipMemcpyAsync(c->UT.p, c->U.p, st, hipMemcpyDeviceToDevice, q));
+                const size_t npts = (size_t)d.n * L.nrows * (L.m1 + 1);
+                hipLaunchKernelGGL(hadi_dividend_kernel, dim3(grid1d(npts)), dim3(256), 0, q, L, d.n, d.d_vec_s,
+                                   ptr<double>(c->UT), ptr<double>(c->U), ptr<int>(c->div_flag), flag_stride, nstep,
+                                   ptr<double>(c->div_amt), ptr<double>(c->div_pct));
             }
             if (prof) HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 0], q));
             auto row_pass = [&](const HadiSweepArgs &ar, int mode) {
@@ -305,21 +323,8 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     if (c->use_small && !prof && !cs && smem_small > 0) {
         HadiSmallArgs sm;
         sm.div_flag = nullptr; sm.div_amounts = nullptr; sm.div_pcts = nullptr; sm.vec_s = d.d_vec_s; sm.Nmax = d.Nmax;
-        std::vector<int> flags;
-        if (dividend && d.num_div > 0) {
-            flags.assign(d.Nmax, -1);
-            int cur = 0;
-            for (int nstep = 1; nstep <= d.Nmax; nstep++) {  // device_solver.hpp:426-447,508-516
-                const double t = nstep * d.dt0;
-                if (cur < d.num_div && t <= d.div_dates[cur] && d.div_dates[cur] < (nstep + 1) * d.dt0) flags[nstep - 1] = cur;
-                if (cur < d.num_div && t > d.div_dates[cur]) cur++;
-            }
-            if ((rc = ensure(c, c->div_flag, d.Nmax * sizeof(int))) || (rc = ensure(c, c->div_amt, d.num_div * 8)) ||
-                (rc = ensure(c, c->div_pct, d.num_div * 8)))
-                return rc;
-            HIP_TRY(c, hipMemcpyAsync(c->div_flag.p, flags.data(), d.Nmax * sizeof(int), hipMemcpyHostToDevice, s));
-            HIP_TRY(c, hipMemcpyAsync(c->div_amt.p, d.div_amounts, d.num_div * 8, hipMemcpyHostToDevice, s));
-            HIP_TRY(c, hipMemcpyAsync(c->div_pct.p, d.div_pcts, d.num_div * 8, hipMemcpyHostToDevice, s));
+        sm.flag_stride = flag_stride;
+        if (have_div) {
             sm.div_flag = ptr<int>(c->div_flag); sm.div_amounts = ptr<double>(c->div_amt); sm.div_pcts = ptr<double>(c->div_pct);
         }
         HIP_TRY(c, hipEventRecord(c->ev[1], s));
@@ -332,7 +337,6 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         }
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(c->ev[2], s));
-        if (!flags.empty()) HIP_TRY(c, hipStreamSynchronize(s));  // host staging vector leaves scope
         return HADI_OK;
     }
 
@@ -354,11 +358,12 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         put(&d.Nmax, sizeof(int)); put(&d.dt0, sizeof(double));
         put(&d.variant, sizeof(int)); put(&d.d_vec_s, sizeof(void *));
         void *ut = c->UT.p; put(&ut, sizeof(ut));
-        if (dividend) {
-            put(&d.num_div, sizeof(int));
-            put(d.div_dates, d.num_div * sizeof(double));
-            put(d.div_amounts, d.num_div * sizeof(double));
-            put(d.div_pcts, d.num_div * sizeof(double));
+        if (have_div) {  // amounts / percentages / per-instance tables are re-uploaded every call; the node list
+                         // only depends on which steps carry a dividend launch
+            put(&flag_stride, sizeof(int));
+            put(div_step.data(), div_step.size());
+            void *fl = c->div_flag.p, *am = c->div_amt.p, *pc = c->div_pct.p;
+            put(&fl, sizeof(fl)); put(&am, sizeof(am)); put(&pc, sizeof(pc));
         }
         Ctx::GraphEntry *hit = nullptr;
         for (auto &g : c->graphs)

@@ -849,7 +849,9 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
 // column pass walks each column sequentially in LDS (single chunk: m2+1 <= HADI_LC), with the American
 // projection; discrete dividends are applied in place.
 struct HadiSmallArgs {
-    const int *div_flag;        // [Nmax] dividend index applied at the START of step n (n = 1..Nmax), or -1; nullptr = none
+    const int *div_flag;        // dividend index applied at the START of step n (n = 1..Nmax), or -1; nullptr = none.
+                                // Instance k reads div_flag[k*flag_stride + n-1]: flag_stride 0 = one shared (N, dt)
+    int flag_stride;
     const double *div_amounts;  // device copies of the schedule
     const double *div_pcts;
     const double *vec_s;        // [n_inst][m1+1] (dividend interpolation)
@@ -919,7 +921,7 @@ __global__ void __launch_bounds__(64 * W) hadi_small_kernel(HadiSweepArgs a, Had
     const double *__restrict__ vs = sm.vec_s ? sm.vec_s + (size_t)inst * (m1 + 1) : nullptr;
     for (int n = 1; n <= N; n++) {
         // ---- discrete dividend at the start of the step (device_solver.hpp:448-504) ---------------
-        const int dv = sm.div_flag ? sm.div_flag[n - 1] : -1;
+        const int dv = sm.div_flag ? sm.div_flag[(size_t)inst * sm.flag_stride + n - 1] : -1;
         if (dv >= 0) {
             for (int e = tid; e < nrows * rowp; e += NT) Yl[e] = Ul[e];  // U_temp
             __syncthreads();
@@ -1089,10 +1091,13 @@ __global__ void __launch_bounds__(256) hadi_fill_kernel(double *__restrict__ p, 
 // ------------------------------------------------------------------------------------------------
 // Discrete dividend jump (device_solver.hpp:448-504) on the internal layout: U <- interp(UT) where
 // UT is a copy of U taken before the jump.  One thread per (row, s-node); the reference's linear
-// search "first k with s_k > new_s" is a binary search on the ascending s-grid.
+// search "first k with s_k > new_s" is a binary search on the ascending s-grid.  Which dividend (if any) an
+// instance pays at the start of step n comes from the host-built table div_flag (see HadiSmallArgs).
 __global__ void __launch_bounds__(256) hadi_dividend_kernel(HadiLayout L, int n_inst, const double *__restrict__ vec_s,
                                                             const double *__restrict__ UT, double *__restrict__ U,
-                                                            double amount, double pct) {
+                                                            const int *__restrict__ div_flag, int flag_stride, int n,
+                                                            const double *__restrict__ div_amounts,
+                                                            const double *__restrict__ div_pcts) {
     const int m1 = L.m1;
     const size_t per = (size_t)L.nrows * (m1 + 1);
     const size_t total = (size_t)n_inst * per;
@@ -1101,6 +1106,9 @@ __global__ void __launch_bounds__(256) hadi_dividend_kernel(HadiLayout L, int n_
         const size_t rowid = e / (m1 + 1);
         const int j = (int)(rowid % L.nrows);
         const size_t inst = rowid / L.nrows;
+        const int dv = div_flag[inst * flag_stride + n - 1];
+        if (dv < 0) continue;
+        const double amount = div_amounts[dv], pct = div_pcts[dv];
         const double *__restrict__ s = vec_s + inst * (m1 + 1);
         const double *__restrict__ src = UT + inst * L.inst_stride + (size_t)j * L.rowp;
         const double old_s = s[i];

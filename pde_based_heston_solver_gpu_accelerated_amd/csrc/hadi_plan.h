@@ -99,3 +99,18 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
     *out = p;
     return 0;
 }
+
+// Which dividend an instance with (N, dt) pays at the START of step n = 1..N (device_solver.hpp:426-447,508-516):
+// flags[n-1] = index into the schedule or -1.  n*dt is evaluated in floating point exactly as the reference
+// does (12*0.05 = 0.6000000000000001 decides the step a dividend lands on).  flags has `len` >= N entries;
+// entries beyond N are -1.
+inline void hadi_dividend_steps(int N, double dt, int num_div, const double *dates, int *flags, int len) {
+    int cur = 0;
+    for (int n = 1; n <= len; n++) {
+        flags[n - 1] = -1;
+        if (n > N) continue;
+        const double t = n * dt;
+        if (cur < num_div && t <= dates[cur] && dates[cur] < (n + 1) * dt) flags[n - 1] = cur;
+        if (cur < num_div && t > dates[cur]) cur++;
+    }
+}

@@ -248,20 +248,23 @@ class HestonADI:
                                  delta_t, num_strikes, deviceGrids, workspace, per_instance=per_instance)
 
     def compute_base_prices_american(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N,
-                                     theta, delta_t, num_strikes, deviceGrids, U_0, workspace):
+                                     theta, delta_t, num_strikes, deviceGrids, U_0, workspace, per_instance=None):
         return self._base_prices(AM, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
-                                 delta_t, num_strikes, deviceGrids, workspace, U_0=U_0)
+                                 delta_t, num_strikes, deviceGrids, workspace, U_0=U_0, per_instance=per_instance)
 
     def compute_base_prices_dividends(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N,
-                                      theta, delta_t, num_strikes, deviceGrids, workspace, dividends):
+                                      theta, delta_t, num_strikes, deviceGrids, workspace, dividends,
+                                      per_instance=None):
         return self._base_prices(DIV, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
-                                 delta_t, num_strikes, deviceGrids, workspace, dividends=dividends)
+                                 delta_t, num_strikes, deviceGrids, workspace, dividends=dividends,
+                                 per_instance=per_instance)
 
     def compute_base_prices_american_dividends(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2,
                                                total_size, N, theta, delta_t, num_strikes, deviceGrids, U_0,
-                                               workspace, dividends):
+                                               workspace, dividends, per_instance=None):
         return self._base_prices(AM_DIV, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N,
-                                 theta, delta_t, num_strikes, deviceGrids, workspace, U_0=U_0, dividends=dividends)
+                                 theta, delta_t, num_strikes, deviceGrids, workspace, U_0=U_0, dividends=dividends,
+                                 per_instance=per_instance)
 
     # ---- compute_jacobian* (src/jacobian_computation.cpp:204, 457, 726, 1031) ------------------
     def _jacobian(self, variant, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
@@ -284,20 +287,63 @@ class HestonADI:
                               delta_t, num_strikes, deviceGrids, U_0, eps, per_instance=per_instance)
 
     def compute_jacobian_american(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N,
-                                  theta, delta_t, num_strikes, deviceGrids, U_0, eps=1e-6):
+                                  theta, delta_t, num_strikes, deviceGrids, U_0, eps=1e-6, per_instance=None):
         return self._jacobian(AM, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
-                              delta_t, num_strikes, deviceGrids, U_0, eps)
+                              delta_t, num_strikes, deviceGrids, U_0, eps, per_instance=per_instance)
 
     def compute_jacobian_dividends(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N,
-                                   theta, delta_t, num_strikes, deviceGrids, U_0, dividends, eps=1e-6):
+                                   theta, delta_t, num_strikes, deviceGrids, U_0, dividends, eps=1e-6,
+                                   per_instance=None):
         return self._jacobian(DIV, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
-                              delta_t, num_strikes, deviceGrids, U_0, eps, dividends=dividends)
+                              delta_t, num_strikes, deviceGrids, U_0, eps, dividends=dividends,
+                              per_instance=per_instance)
 
     def compute_jacobian_american_dividends(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2,
                                             total_size, N, theta, delta_t, num_strikes, deviceGrids, U_0,
-                                            dividends, eps=1e-6):
+                                            dividends, eps=1e-6, per_instance=None):
         return self._jacobian(AM_DIV, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
-                              delta_t, num_strikes, deviceGrids, U_0, eps, dividends=dividends)
+                              delta_t, num_strikes, deviceGrids, U_0, eps, dividends=dividends,
+                              per_instance=per_instance)
+
+    # ---- multi-maturity launchers (src/heston_calibration.cpp:2174-2424, 2936-3243) ----------------------
+    # One instance per CalibrationPoint{strike, maturity, time_steps, delta_t, global_index}: the batch shares the
+    # grid shape and the model parameters, every instance steps its own (N, delta_t).
+    @staticmethod
+    def _steps(calibration_points, total_calibration_size):
+        if len(calibration_points) != total_calibration_size:
+            raise ValueError("total_calibration_size does not match the calibration points")
+        N_i = np.array([pt.time_steps for pt in calibration_points], dtype=np.int32)
+        dt_i = np.array([pt.delta_t for pt in calibration_points], dtype=np.float64)
+        return {"N_i": N_i, "delta_t_i": dt_i}, int(N_i.max()) if len(N_i) else 1, float(dt_i[0]) if len(dt_i) else 1.0
+
+    def compute_jacobian_multi_maturity(self, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, theta,
+                                        calibration_points, total_calibration_size, deviceGrids, U_0, eps=1e-6):
+        per, N, dt = self._steps(calibration_points, total_calibration_size)
+        return self._jacobian(EU, S_0, V_0, None, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta, dt,
+                              total_calibration_size, deviceGrids, U_0, eps, per_instance=per)
+
+    def compute_base_prices_multi_maturity(self, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, theta,
+                                           calibration_points, total_calibration_size, deviceGrids, workspace):
+        per, N, dt = self._steps(calibration_points, total_calibration_size)
+        return self._base_prices(EU, S_0, V_0, None, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
+                                 dt, total_calibration_size, deviceGrids, workspace, per_instance=per)
+
+    def compute_jacobian_multi_maturity_american_dividends(self, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2,
+                                                           total_size, theta, calibration_points,
+                                                           total_calibration_size, deviceGrids, U_0, dividends,
+                                                           eps=1e-6):
+        per, N, dt = self._steps(calibration_points, total_calibration_size)
+        return self._jacobian(AM_DIV, S_0, V_0, None, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
+                              dt, total_calibration_size, deviceGrids, U_0, eps, dividends=dividends, per_instance=per)
+
+    def compute_base_prices_multi_maturity_american_dividends(self, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2,
+                                                              total_size, theta, calibration_points,
+                                                              total_calibration_size, deviceGrids, U_0, workspace,
+                                                              dividends):
+        per, N, dt = self._steps(calibration_points, total_calibration_size)
+        return self._base_prices(AM_DIV, S_0, V_0, None, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N,
+                                 theta, dt, total_calibration_size, deviceGrids, workspace, U_0=U_0,
+                                 dividends=dividends, per_instance=per)
 
 
 # ---- LM linear algebra (host; jacobian_computation.cpp:20-195) -------------------------------------

@@ -35,16 +35,100 @@ def strikes_for(n):
 
 
 class OracleSolver:
-    """Oracle-backed stand-in with the call signatures of HestonADI.compute_jacobian /
-    compute_base_prices -- TESTS ONLY (drives the host-side LM loop where no GPU is available and
-    serves as the reference trajectory on the GPU box)."""
+    """Oracle-backed stand-in with the call signatures of HestonADI's compute_jacobian* / compute_base_prices*
+    launchers -- TESTS ONLY (drives the host-side LM loops where no GPU is available and serves as the
+    reference trajectory on the GPU box).  Multi-maturity batches are solved one (N, delta_t) group at a time."""
+
+    @staticmethod
+    def _div(dividends):
+        return None if dividends is None else (dividends.dates, dividends.amounts, dividends.percentages)
+
+    def _jac(self, variant, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2, N, theta, delta_t, grids, U_0, eps,
+             dividends=None, rows=slice(None)):
+        p = O.make_params(m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, variant, self._div(dividends))
+        return O.jacobian(p, S_0, V_0, grids.Vec_s[rows], grids.Vec_v[rows], grids.Delta_s[rows], grids.Delta_v[rows],
+                          np.asarray(U_0)[rows], eps=eps)
+
+    def _base(self, variant, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2, N, theta, delta_t, grids, U, U_0=None,
+              dividends=None, rows=slice(None)):
+        p = O.make_params(m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, variant, self._div(dividends))
+        return O.base_prices(p, S_0, V_0, grids.Vec_s[rows], grids.Vec_v[rows], grids.Delta_s[rows], grids.Delta_v[rows],
+                             np.asarray(U)[rows], None if U_0 is None else np.asarray(U_0)[rows])[0]
 
     def compute_jacobian(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
                          delta_t, num_strikes, grids, U_0, eps=1e-6):
-        p = O.make_params(m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta)
-        return O.jacobian(p, S_0, V_0, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U_0, eps=eps)
+        return self._jac(O.EU, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2, N, theta, delta_t, grids, U_0, eps)
 
     def compute_base_prices(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
                             delta_t, num_strikes, grids, ws):
-        p = O.make_params(m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta)
-        return O.base_prices(p, S_0, V_0, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, ws.U)[0]
+        return self._base(O.EU, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2, N, theta, delta_t, grids, ws.U)
+
+    def compute_jacobian_american(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
+                                  delta_t, num_strikes, grids, U_0, eps=1e-6):
+        return self._jac(O.AM, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2, N, theta, delta_t, grids, U_0, eps)
+
+    def compute_base_prices_american(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
+                                     delta_t, num_strikes, grids, U_0, ws):
+        return self._base(O.AM, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2, N, theta, delta_t, grids, ws.U, U_0)
+
+    def compute_jacobian_dividends(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
+                                   delta_t, num_strikes, grids, U_0, dividends, eps=1e-6):
+        return self._jac(O.DIV, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2, N, theta, delta_t, grids, U_0, eps,
+                         dividends)
+
+    def compute_base_prices_dividends(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
+                                      delta_t, num_strikes, grids, ws, dividends):
+        return self._base(O.DIV, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2, N, theta, delta_t, grids, ws.U,
+                          dividends=dividends)
+
+    def compute_jacobian_american_dividends(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N,
+                                            theta, delta_t, num_strikes, grids, U_0, dividends, eps=1e-6):
+        return self._jac(O.AM_DIV, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2, N, theta, delta_t, grids, U_0, eps,
+                         dividends)
+
+    def compute_base_prices_american_dividends(self, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size,
+                                               N, theta, delta_t, num_strikes, grids, U_0, ws, dividends):
+        return self._base(O.AM_DIV, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2, N, theta, delta_t, grids, ws.U,
+                          U_0, dividends)
+
+    # ---- multi-maturity: group the points by (N, delta_t) ----------------------------------------------
+    @staticmethod
+    def _groups(points):
+        g = {}
+        for k, pt in enumerate(points):
+            g.setdefault((pt.time_steps, pt.delta_t), []).append(k)
+        return [(N, dt, np.array(rows)) for (N, dt), rows in g.items()]
+
+    def _mm_jac(self, variant, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2, theta, points, grids, U_0, eps,
+                dividends=None):
+        J, base = np.empty((len(points), 5)), np.empty(len(points))
+        for N, dt, rows in self._groups(points):
+            J[rows], base[rows] = self._jac(variant, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2, N, theta, dt,
+                                            grids, U_0, eps, dividends, rows)
+        return J, base
+
+    def _mm_base(self, variant, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2, theta, points, grids, U, U_0=None,
+                 dividends=None):
+        base = np.empty(len(points))
+        for N, dt, rows in self._groups(points):
+            base[rows] = self._base(variant, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2, N, theta, dt, grids, U,
+                                    U_0, dividends, rows)
+        return base
+
+    def compute_jacobian_multi_maturity(self, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, theta,
+                                        points, n, grids, U_0, eps=1e-6):
+        return self._mm_jac(O.EU, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2, theta, points, grids, U_0, eps)
+
+    def compute_base_prices_multi_maturity(self, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, theta,
+                                           points, n, grids, ws):
+        return self._mm_base(O.EU, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2, theta, points, grids, ws.U)
+
+    def compute_jacobian_multi_maturity_american_dividends(self, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2,
+                                                           total_size, theta, points, n, grids, U_0, dividends, eps=1e-6):
+        return self._mm_jac(O.AM_DIV, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2, theta, points, grids, U_0, eps,
+                            dividends)
+
+    def compute_base_prices_multi_maturity_american_dividends(self, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2,
+                                                              total_size, theta, points, n, grids, U_0, ws, dividends):
+        return self._mm_base(O.AM_DIV, S_0, V_0, r_d, r_f, rho, sigma, kappa, eta, m1, m2, theta, points, grids, ws.U, U_0,
+                             dividends)

@@ -90,17 +90,12 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
     HadiSweepArgs av = a;
     if (cs) av.U = dV.data();
 
+    std::vector<int> flags(N, -1);
+    if (dividend) hadi_dividend_steps(N, dt, ndiv, ddates, flags.data(), N);
     const size_t smem_small = american ? pl.smem_small_am : pl.smem_small_eu;
     if (use_small && !cs && smem_small > 0) {
-        std::vector<int> flags(N, -1);
-        int cc = 0;
-        for (int n = 1; n <= N; n++) {
-            const double t = n * dt;
-            if (dividend && cc < ndiv && t <= ddates[cc] && ddates[cc] < (n + 1) * dt) flags[n - 1] = cc;
-            if (dividend && cc < ndiv && t > ddates[cc]) cc++;
-        }
         HadiSmallArgs sm;
-        sm.div_flag = dividend ? flags.data() : nullptr; sm.div_amounts = damounts; sm.div_pcts = dpcts;
+        sm.div_flag = dividend ? flags.data() : nullptr; sm.flag_stride = 0; sm.div_amounts = damounts; sm.div_pcts = dpcts;
         sm.vec_s = vec_s; sm.Nmax = N;
         if (L.B == 1) {
             if (american) emu::launch(n_inst, 256, [&]() { hadi_small_kernel<1, 4, true>(a, sm); }, smem_small);
@@ -113,17 +108,12 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
         if (american && lam_out) emu::launch(8, 64, [&]() { hadi_unpack_kernel(L, n_inst, dLAM.data(), lam_out); });
         return 0;
     }
-    int cur = 0;
     for (int n = 1; n <= N; n++) {
-        if (dividend) {  // device_solver.hpp:426-517 (host decides, kernel applies)
-            const double t = n * dt;
-            if (cur < ndiv && t <= ddates[cur] && ddates[cur] < (n + 1) * dt) {
-                dUT = dU;
-                emu::launch(8, 64, [&]() {
-                    hadi_dividend_kernel(L, n_inst, vec_s, dUT.data(), dU.data(), damounts[cur], dpcts[cur]);
-                });
-            }
-            if (cur < ndiv && t > ddates[cur]) cur++;
+        if (dividend && flags[n - 1] >= 0) {  // device_solver.hpp:426-517 (host builds the step table, kernel applies)
+            dUT = dU;
+            emu::launch(8, 64, [&]() {
+                hadi_dividend_kernel(L, n_inst, vec_s, dUT.data(), dU.data(), flags.data(), 0, n, damounts, dpcts);
+            });
         }
         if (run_row_pass(pl, a, n, cs ? 1 : 0)) return 2;
         run_col_pass(pl, cs ? av : a, n);
