@@ -106,10 +106,18 @@ __device__ unsigned long long g_hadi_stamps[32];
 #define HADI_STAMP(k) do { if ((k) >= 8 || HADI_STAMPS >= 2) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
     sacc_[k] += t_ - stamp_prev_; stamp_prev_ = t_; } } while (0)
+// HADI_STAMPS=3: column-pass phases (16..23) instead
+#define HADI_STAMPB(k) do { if (HADI_STAMPS >= 3) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    sacc_[k] += t_ - stamp_prev_; stamp_prev_ = t_; } } while (0)
+#define HADI_STAMPB_WAIT(n) do { if (HADI_STAMPS >= 3) { if ((n) >= 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); \
+    else if ((n) >= 33) asm volatile("s_waitcnt vmcnt(33)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } } while (0)
 #else
 #define HADI_STAMP_ACC
 #define HADI_STAMP_DECL(accptr)
 #define HADI_STAMP(k)
+#define HADI_STAMPB(k)
+#define HADI_STAMPB_WAIT(n)
 #endif
 
 // ---- buffer addressing: wave-uniform base + scalar row offset + one per-lane 32-bit offset ----------
@@ -684,10 +692,12 @@ struct HadiPassBCtx {
     double *Li;         // instance base of lambda_bar (American)
     const double *P0i;  // instance base of the payoff (American)
     const double *pb;   // this chunk's table in LDS
-    const double *Ri;   // reduced inverse (global, uniform)
+    const double *Ri;   // this wavefront's four rows of the reduced inverse in LDS, [4P][4]: for column m the
+                        // coefficients of (left-neighbour last two, right-neighbour first two)
     double *zsh;        // LDS exchange, 2 buffers of P*4*64
     int lane, wave, P, ja, rowp, american, pos_m1;
     double dt;
+    HADI_STAMP_ACC
 };
 
 HADI_DEV HADI_FORCEINLINE void hadi_pb_load(const HadiPassBCtx &c, int ctile, double (&y)[HADI_LC]) {
@@ -700,8 +710,12 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_load(const HadiPassBCtx &c, int ctile, do
 }
 
 template <bool AMER>
-HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ctile, int parity, double (&y)[HADI_LC]) {
+HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ctile, int parity, double (&y)[HADI_LC],
+                                                   int younger = 0) {
     const double *__restrict__ pb = c.pb;
+    HADI_STAMP_DECL(c.stamp_acc_)
+    HADI_STAMPB_WAIT(younger);
+    HADI_STAMPB(16);  // this tile's loads have landed
     // forward elimination with the chunk-local factorisation
     {
         double ym1 = 0.0, ym2 = 0.0;
@@ -714,6 +728,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ct
             ym1 = yk;
         }
     }
+    HADI_STAMPB(17);  // forward
     // back substitution
     {
         double xp1 = 0.0, xp2 = 0.0;
@@ -726,6 +741,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ct
             xp1 = xk;
         }
     }
+    HADI_STAMPB(18);  // backward
     const int P = c.P;
     if (P > 1) {
         // interface exchange.  Two LDS buffers alternate by tile parity, so one barrier per tile is
@@ -737,18 +753,20 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ct
         z[(c.wave * 4 + 2) * 64 + c.lane] = y[HADI_LC - 2];
         z[(c.wave * 4 + 3) * 64 + c.lane] = y[HADI_LC - 1];
         __syncthreads();
+        HADI_STAMPB(19);  // exchange + barrier
         // t = Rinv z : this chunk needs the previous chunk's last two and the next chunk's first two
         const int n4 = 4 * P;
         const double *__restrict__ Ri = c.Ri;
         double tl0 = 0.0, tl1 = 0.0, tr0 = 0.0, tr1 = 0.0;
-        const int rl0 = (c.wave > 0) ? 4 * (c.wave - 1) + 2 : 0, rr0 = (c.wave < P - 1) ? 4 * (c.wave + 1) : 0;
+#pragma unroll 8
         for (int m = 0; m < n4; m++) {
             const double zz = z[m * 64 + c.lane];
-            tl0 = fma(Ri[(size_t)rl0 * n4 + m], zz, tl0);
-            tl1 = fma(Ri[(size_t)(rl0 + 1) * n4 + m], zz, tl1);
-            tr0 = fma(Ri[(size_t)rr0 * n4 + m], zz, tr0);
-            tr1 = fma(Ri[(size_t)(rr0 + 1) * n4 + m], zz, tr1);
+            tl0 = fma(Ri[4 * m + 0], zz, tl0);
+            tl1 = fma(Ri[4 * m + 1], zz, tl1);
+            tr0 = fma(Ri[4 * m + 2], zz, tr0);
+            tr1 = fma(Ri[4 * m + 3], zz, tr1);
         }
+        HADI_STAMPB(20);  // reduced system
         // spikes are zero where there is no neighbour (first chunk: V = 0, last chunk: W = 0)
 #pragma unroll
         for (int k = 0; k < HADI_LC; k++) {
@@ -756,6 +774,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ct
             y[k] = y[k] - t[PB_V0] * tl0 - t[PB_V1] * tl1 - t[PB_W0] * tr0 - t[PB_W1] * tr1;
         }
     }
+    HADI_STAMPB(21);  // spike correction
     const int col = ctile * 64 + c.lane;
     const bool valid = col < c.rowp;
     const int colc = valid ? col : c.rowp - 1;
@@ -789,9 +808,11 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ct
             }
         }
     }
+    HADI_STAMPB(22);  // projection + store issue
 }
 
-// Dynamic LDS: P * (2*4*64 + HADI_LC*HADI_PBW) doubles (two interface-exchange buffers + the chunk tables).
+// Dynamic LDS: P * (2*4*64 + HADI_LC*HADI_PBW + 16*P) doubles (two interface-exchange buffers, the chunk tables,
+// each wavefront's four rows of the reduced inverse).
 // MAXP only sets the launch bound (register budget): 8 -> 512 threads, 16 -> 1024 threads.
 template <int MAXP, bool AMER>
 __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n) {
@@ -814,13 +835,16 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
     c.Ub = hadi_make_buf(c.Ui, (size_t)a.L.inst_stride * sizeof(double));
     c.Li = AMER ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
     c.P0i = AMER ? a.U0 + (size_t)inst * a.L.inst_stride : nullptr;
-    c.Ri = a.rinv + (size_t)inst * 16 * c.P * c.P;
     c.american = a.american;
     c.pos_m1 = a.pos_m1;
     c.dt = ip.dt;
     const int t0 = grp * a.btpw;
     const int t1 = (t0 + a.btpw < a.ctiles) ? t0 + a.btpw : a.ctiles;
 
+#if defined(HADI_STAMPS) && !defined(HADI_EMU)
+    unsigned long long stamp_store_[32] = {0};
+    c.stamp_acc_ = stamp_store_;
+#endif
     double ya[HADI_LC], yb[HADI_LC];
     hadi_pb_load(c, t0, ya);
     // the chunk's table (HADI_LC x HADI_PBW doubles, identical for every column) goes through LDS once per
@@ -830,14 +854,31 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
         double *__restrict__ tw = tsh + c.wave * (HADI_LC * HADI_PBW);
         for (int e = c.lane; e < HADI_LC * HADI_PBW; e += 64) tw[e] = pbg[e];
         c.pb = tw;
+        // t = Rinv z needs, for this chunk, the rows of the previous chunk's last two and the next chunk's first two
+        // unknowns (spikes are zero where there is no neighbour, so any row will do there)
+        const int n4 = 4 * c.P;
+        const double *__restrict__ Rg = a.rinv + (size_t)inst * 16 * c.P * c.P;
+        double *__restrict__ rw = tsh + (size_t)c.P * (HADI_LC * HADI_PBW) + (size_t)c.wave * 4 * n4;
+        const int rl0 = (c.wave > 0) ? 4 * (c.wave - 1) + 2 : 0, rr0 = (c.wave < c.P - 1) ? 4 * (c.wave + 1) : 0;
+        for (int e = c.lane; e < 4 * n4; e += 64) {
+            const int m = e >> 2, q = e & 3;
+            const int row = (q < 2) ? rl0 + q : rr0 + (q - 2);
+            rw[e] = Rg[(size_t)row * n4 + m];
+        }
+        c.Ri = rw;
     }
     __syncthreads();
     for (int t = t0; t < t1; t += 2) {
+        // `younger` = vector-memory operations issued after the loads of the tile being solved (diagnostic build only)
         if (t + 1 < t1) hadi_pb_load(c, t + 1, yb);
-        hadi_pb_solve_store<AMER>(c, t, 0, ya);
+        hadi_pb_solve_store<AMER>(c, t, 0, ya, (t + 1 < t1 ? HADI_LC : 0) + (t > t0 ? HADI_LC : 0));
         if (t + 2 < t1) hadi_pb_load(c, t + 2, ya);
-        if (t + 1 < t1) hadi_pb_solve_store<AMER>(c, t + 1, 1, yb);
+        if (t + 1 < t1) hadi_pb_solve_store<AMER>(c, t + 1, 1, yb, (t + 2 < t1 ? HADI_LC : 0) + HADI_LC);
     }
+#if defined(HADI_STAMPS) && !defined(HADI_EMU)
+    if (HADI_STAMPS >= 3 && c.lane == 0)
+        for (int k = 16; k < 24; k++) atomicAdd(&g_hadi_stamps[k], stamp_store_[k]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

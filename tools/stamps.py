@@ -25,6 +25,15 @@ s.DO_timestepping(m1, m2, N, 1.0 / 1000, 0.8, 0.025, 0.0, -0.9, 0.3, 1.5, 0.04, 
 L.hadi_debug_stamps(buf, 1)
 names = {0: "row scalars + col0", 1: "LDS rows -> tt,A2U", 2: "coef + Y0 + fwd Thomas", 3: "bwd Thomas + reduced row",
          4: "PCR", 5: "final + store", 8: "prologue", 9: "barrier wait", 10: "row step total (+fetch issue)"}
+if os.environ.get("STAMP_LEVEL") == "3":
+    bn = {16: "wait for the tile's loads", 17: "forward", 18: "backward", 19: "exchange + barrier", 20: "reduced system",
+          21: "spike correction", 22: "store issue"}
+    tiles = n * 8 * 9 * N  # P chunks x ceil(520/64) column tiles
+    tb = sum(buf[k] for k in bn)
+    print("sweep_ms", s.timing()["sweep_ms"])
+    for k, nm in bn.items():
+        print("%-32s %8.0f cycles/tile  %5.1f %%" % (nm, buf[k] / tiles, 100.0 * buf[k] / tb))
+    sys.exit(0)
 rows = n * 257 * N
 tot = sum(buf[k] for k in (8, 9, 10))
 print("sweep_ms", s.timing()["sweep_ms"])
