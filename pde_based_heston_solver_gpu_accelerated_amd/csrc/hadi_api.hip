@@ -167,8 +167,8 @@ hipError_t raise_all_lds_limits() {
     if ((e = raise_lds_limit(hadi_small_kernel<2, 4, true>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b<8, false>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b<8, true>)) != hipSuccess) return e;
-    if ((e = raise_lds_limit(hadi_pass_b<16, false>)) != hipSuccess) return e;
-    return raise_lds_limit(hadi_pass_b<16, true>);
+    if ((e = raise_lds_limit(hadi_pass_b1<16, false>)) != hipSuccess) return e;
+    return raise_lds_limit(hadi_pass_b1<16, true>);
 }
 
 int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
@@ -295,12 +295,16 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                 }
             };
             auto col_pass = [&](const HadiSweepArgs &ar) {
+                // up to 8 chunks: 512-thread blocks with two register buffers (2 waves per SIMD); 9..16 chunks: the
+                // 1024-thread block leaves 128 VGPRs per lane, which only the single-buffer kernel fits
+                // (measured at 1024x512: 0.250 vs 0.382 ms/launch for the double-buffered code, which spills)
+                const dim3 g(pl.grid_b), b(pl.block_b);
                 if (L.P <= 8) {
-                    if (american) hipLaunchKernelGGL((hadi_pass_b<8, true>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, q, ar, nstep);
-                    else hipLaunchKernelGGL((hadi_pass_b<8, false>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, q, ar, nstep);
+                    if (american) hipLaunchKernelGGL((hadi_pass_b<8, true>), g, b, pl.smem_b, q, ar, nstep);
+                    else hipLaunchKernelGGL((hadi_pass_b<8, false>), g, b, pl.smem_b, q, ar, nstep);
                 } else {
-                    if (american) hipLaunchKernelGGL((hadi_pass_b<16, true>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, q, ar, nstep);
-                    else hipLaunchKernelGGL((hadi_pass_b<16, false>), dim3(pl.grid_b), dim3(pl.block_b), pl.smem_b, q, ar, nstep);
+                    if (american) hipLaunchKernelGGL((hadi_pass_b1<16, true>), g, b, pl.smem_b, q, ar, nstep);
+                    else hipLaunchKernelGGL((hadi_pass_b1<16, false>), g, b, pl.smem_b, q, ar, nstep);
                 }
             };
             row_pass(a, cs ? 1 : 0);

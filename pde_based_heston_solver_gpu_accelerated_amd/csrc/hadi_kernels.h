@@ -130,6 +130,7 @@ HADI_DEV HADI_FORCEINLINE double hadi_buf_load(HadiBuf b, unsigned voff_bytes, u
     return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(b.p) + voff_bytes + soff_bytes);
 }
 HADI_DEV HADI_FORCEINLINE void hadi_buf_store(HadiBuf b, unsigned voff_bytes, unsigned soff_bytes, double v) {
+    if (voff_bytes >= 0x80000000u) return;  // HADI_BUF_DROP: the hardware range check discards the lane's store
     *reinterpret_cast<double *>(const_cast<char *>(reinterpret_cast<const char *>(b.p)) + voff_bytes + soff_bytes) = v;
 }
 #else
@@ -149,6 +150,10 @@ HADI_DEV HADI_FORCEINLINE void hadi_buf_store(HadiBuf b, unsigned voff_bytes, un
     __builtin_amdgcn_raw_buffer_store_b64(d, b.r, voff_bytes, soff_bytes, 0);
 }
 #endif
+
+// A raw buffer store whose VGPR offset is >= num_records is dropped by the hardware (the SGPR offset takes no part
+// in the range check): lanes that must not store get this offset instead of an exec-mask branch per row.
+#define HADI_BUF_DROP 0x80000000u
 
 // ---- LDS row ring helpers ---------------------------------------------------------------------------
 // Asynchronous copy of one state row (rowp doubles, HBM layout == LDS layout) into the ring by LDS-DMA
@@ -709,9 +714,8 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_load(const HadiPassBCtx &c, int ctile, do
     for (int k = 0; k < HADI_LC; k++) y[k] = hadi_buf_load(c.Yb, voff, row0 + (unsigned)k * rstride);
 }
 
-template <bool AMER>
-HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ctile, int parity, double (&y)[HADI_LC],
-                                                   int younger = 0) {
+// Chunk-local solve + interface exchange + spike correction of one 64-column tile held in y (no memory traffic).
+HADI_DEV HADI_FORCEINLINE void hadi_pb_solve(const HadiPassBCtx &c, int parity, double (&y)[HADI_LC], int younger = 0) {
     const double *__restrict__ pb = c.pb;
     HADI_STAMP_DECL(c.stamp_acc_)
     HADI_STAMPB_WAIT(younger);
@@ -775,6 +779,16 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ct
         }
     }
     HADI_STAMPB(21);  // spike correction
+}
+
+// Stores the solved tile `ctile` (with the Ikonen-Toivanen projection for American).  RELOAD: every row's register
+// is refilled with the same row of tile `ctile + 1` right behind its store, so one register buffer serves both
+// tiles and the loads of the next tile are in flight as soon as the stores have been issued.
+template <bool AMER, bool RELOAD>
+HADI_DEV HADI_FORCEINLINE void hadi_pb_store(const HadiPassBCtx &c, int ctile, double (&y)[HADI_LC]) {
+    HADI_STAMP_DECL(c.stamp_acc_)
+    const int coln = (ctile + 1) * 64 + c.lane;
+    const unsigned voffn = (unsigned)(coln < c.rowp ? coln : c.rowp - 1) * 8u;
     const int col = ctile * 64 + c.lane;
     const bool valid = col < c.rowp;
     const int colc = valid ? col : c.rowp - 1;
@@ -782,11 +796,19 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ct
     if constexpr (!AMER) {
         const unsigned voff = (unsigned)colc * 8u;
         const unsigned row0 = (unsigned)c.ja * (unsigned)c.rowp * 8u, rstride = (unsigned)c.rowp * 8u;
-        if (valid) {
+        if constexpr (RELOAD) {
+            const unsigned voffs = valid ? voff : HADI_BUF_DROP;
+#pragma unroll
+            for (int k = 0; k < HADI_LC; k++) {
+                hadi_buf_store(c.Ub, voffs, row0 + (unsigned)k * rstride, y[k]);
+                y[k] = hadi_buf_load(c.Yb, voffn, row0 + (unsigned)k * rstride);
+            }
+        } else if (valid) {
 #pragma unroll
             for (int k = 0; k < HADI_LC; k++) hadi_buf_store(c.Ub, voff, row0 + (unsigned)k * rstride, y[k]);
         }
     } else {
+        const unsigned row0 = (unsigned)c.ja * (unsigned)c.rowp * 8u, rstride = (unsigned)c.rowp * 8u;
         // Ikonen-Toivanen projection, device_solver.hpp:358-372
         double *__restrict__ dst = c.Ui + base;
         double *__restrict__ Lb = c.Li + base;
@@ -806,9 +828,17 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ct
                 dst[off] = un;
                 Lb[off] = ln;
             }
+            if constexpr (RELOAD) y[k] = hadi_buf_load(c.Yb, voffn, row0 + (unsigned)k * rstride);
         }
     }
     HADI_STAMPB(22);  // projection + store issue
+}
+
+template <bool AMER>
+HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ctile, int parity, double (&y)[HADI_LC],
+                                                   int younger = 0) {
+    hadi_pb_solve(c, parity, y, younger);
+    hadi_pb_store<AMER, false>(c, ctile, y);
 }
 
 // Dynamic LDS: P * (2*4*64 + HADI_LC*HADI_PBW + 16*P) doubles (two interface-exchange buffers, the chunk tables,
@@ -874,6 +904,75 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
         hadi_pb_solve_store<AMER>(c, t, 0, ya, (t + 1 < t1 ? HADI_LC : 0) + (t > t0 ? HADI_LC : 0));
         if (t + 2 < t1) hadi_pb_load(c, t + 2, ya);
         if (t + 1 < t1) hadi_pb_solve_store<AMER>(c, t + 1, 1, yb, (t + 2 < t1 ? HADI_LC : 0) + HADI_LC);
+    }
+#if defined(HADI_STAMPS) && !defined(HADI_EMU)
+    if (HADI_STAMPS >= 3 && c.lane == 0)
+        for (int k = 16; k < 24; k++) atomicAdd(&g_hadi_stamps[k], stamp_store_[k]);
+#endif
+}
+
+// Single-buffer variant for more than 8 chunks (m2 > 263): a 1024-thread block has 128 VGPRs per lane, too few for two
+// 33-row register buffers (the double-buffered code spills 650 B per lane there).  The next tile is loaded into the
+// registers of the current one row by row, right behind the stores.  Measured on MI355X: 1024x512 grid 0.250 ms per
+// launch against 0.382; at 512x256 (P = 8) the double-buffered kernel above wins, 0.144 against 0.206.
+template <int MAXP, bool AMER>
+__global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, int n) {
+    HADI_DYN_SMEM(double, smem);
+    HadiPassBCtx c;
+    c.lane = threadIdx.x & 63;
+    c.wave = HADI_UNIFORM((int)(threadIdx.x >> 6));
+    c.P = a.L.P;
+    c.zsh = smem;
+    double *__restrict__ tsh = smem + (size_t)c.P * 2 * 4 * 64;
+    const int inst = blockIdx.x / a.bgroups, grp = blockIdx.x - inst * a.bgroups;
+    const HadiInstPar ip = a.ipar[inst];
+    if (n > ip.N) return;  // whole block: uniform
+    const int nrows = a.L.nrows_pad;
+    c.rowp = a.L.rowp;
+    c.ja = c.wave * HADI_LC;
+    c.Yi = a.Y + (size_t)inst * a.L.inst_stride;
+    c.Ui = a.U + (size_t)inst * a.L.inst_stride;
+    c.Yb = hadi_make_buf(c.Yi, (size_t)a.L.inst_stride * sizeof(double));
+    c.Ub = hadi_make_buf(c.Ui, (size_t)a.L.inst_stride * sizeof(double));
+    c.Li = AMER ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
+    c.P0i = AMER ? a.U0 + (size_t)inst * a.L.inst_stride : nullptr;
+    c.american = a.american;
+    c.pos_m1 = a.pos_m1;
+    c.dt = ip.dt;
+    const int t0 = grp * a.btpw;
+    const int t1 = (t0 + a.btpw < a.ctiles) ? t0 + a.btpw : a.ctiles;
+
+#if defined(HADI_STAMPS) && !defined(HADI_EMU)
+    unsigned long long stamp_store_[32] = {0};
+    c.stamp_acc_ = stamp_store_;
+#endif
+    double y[HADI_LC];
+    hadi_pb_load(c, t0, y);
+    // the chunk's table (HADI_LC x HADI_PBW doubles, identical for every column) goes through LDS once per
+    // block: coalesced load, then every use is a conflict-free broadcast read with a compile-time offset
+    {
+        const double *__restrict__ pbg = a.pb + ((size_t)inst * nrows + c.ja) * HADI_PBW;
+        double *__restrict__ tw = tsh + c.wave * (HADI_LC * HADI_PBW);
+        for (int e = c.lane; e < HADI_LC * HADI_PBW; e += 64) tw[e] = pbg[e];
+        c.pb = tw;
+        // t = Rinv z needs, for this chunk, the rows of the previous chunk's last two and the next chunk's first two
+        // unknowns (spikes are zero where there is no neighbour, so any row will do there)
+        const int n4 = 4 * c.P;
+        const double *__restrict__ Rg = a.rinv + (size_t)inst * 16 * c.P * c.P;
+        double *__restrict__ rw = tsh + (size_t)c.P * (HADI_LC * HADI_PBW) + (size_t)c.wave * 4 * n4;
+        const int rl0 = (c.wave > 0) ? 4 * (c.wave - 1) + 2 : 0, rr0 = (c.wave < c.P - 1) ? 4 * (c.wave + 1) : 0;
+        for (int e = c.lane; e < 4 * n4; e += 64) {
+            const int m = e >> 2, q = e & 3;
+            const int row = (q < 2) ? rl0 + q : rr0 + (q - 2);
+            rw[e] = Rg[(size_t)row * n4 + m];
+        }
+        c.Ri = rw;
+    }
+    __syncthreads();
+    for (int t = t0; t < t1; t++) {
+        hadi_pb_solve(c, (t - t0) & 1, y, 0);
+        if (t + 1 < t1) hadi_pb_store<AMER, true>(c, t, y);
+        else hadi_pb_store<AMER, false>(c, t, y);
     }
 #if defined(HADI_STAMPS) && !defined(HADI_EMU)
     if (HADI_STAMPS >= 3 && c.lane == 0)

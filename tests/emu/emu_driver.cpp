@@ -34,8 +34,13 @@ static int run_row_pass(const HadiPlan &pl, const HadiSweepArgs &a, int n, int m
 }
 
 static void run_col_pass(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
-    if (a.american) emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b<16, true>(a, n); }, pl.smem_b);
-    else emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b<16, false>(a, n); }, pl.smem_b);
+    if (pl.L.P <= 8) {  // same choice as hadi_api.hip
+        if (a.american) emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b<8, true>(a, n); }, pl.smem_b);
+        else emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b<8, false>(a, n); }, pl.smem_b);
+    } else {
+        if (a.american) emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b1<16, true>(a, n); }, pl.smem_b);
+        else emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b1<16, false>(a, n); }, pl.smem_b);
+    }
 }
 
 extern "C" int emu_plan(int m1, int m2, int n_inst, int target_waves, int *out /*B,rowp,P,R,ntiles,ctiles*/) {

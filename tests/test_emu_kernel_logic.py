@@ -71,6 +71,13 @@ def test_dividends_and_chunked_column_pass(emu):
     _run(emu, 72, 70, 10, [100.0], O.DIV, 3)
 
 
+def test_single_buffer_column_pass_for_more_than_8_chunks(emu):
+    # m2 = 270 -> 271 v-rows -> 9 chunks -> the 16-wave single-buffer kernel; few blocks per instance so that a block
+    # walks several column tiles (store + reload of the same registers), American adds the projection
+    _run(emu, 300, 270, 2, [100.0], O.EU, 1)
+    _run(emu, 280, 265, 2, [97.0], O.AM, 1, r_f=0.01)
+
+
 def test_two_waves_per_row_split_solve(emu):
     # m1 > 512: the row's tridiagonal system is split over two wavefronts and re-coupled by a 2x2 system
     _run(emu, 600, 12, 2, [100.0, 93.0], O.EU, 8)
