@@ -853,7 +853,10 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
     c.P = a.L.P;
     c.zsh = smem;
     double *__restrict__ tsh = smem + (size_t)c.P * 2 * 4 * 64;
-    const int inst = blockIdx.x / a.bgroups, grp = blockIdx.x - inst * a.bgroups;
+    // blocks walk the instances in DESCENDING order: the row pass writes Y ascending, so the column pass starts on the
+    // part of Y that is still in the memory-side cache (and leaves the low instances of U there for the next row pass)
+    const int binst = blockIdx.x / a.bgroups, grp = blockIdx.x - binst * a.bgroups;
+    const int inst = a.n_inst - 1 - binst;
     const HadiInstPar ip = a.ipar[inst];
     if (n > ip.N) return;  // whole block: uniform
     const int nrows = a.L.nrows_pad;
@@ -924,7 +927,10 @@ __global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, in
     c.P = a.L.P;
     c.zsh = smem;
     double *__restrict__ tsh = smem + (size_t)c.P * 2 * 4 * 64;
-    const int inst = blockIdx.x / a.bgroups, grp = blockIdx.x - inst * a.bgroups;
+    // blocks walk the instances in DESCENDING order: the row pass writes Y ascending, so the column pass starts on the
+    // part of Y that is still in the memory-side cache (and leaves the low instances of U there for the next row pass)
+    const int binst = blockIdx.x / a.bgroups, grp = blockIdx.x - binst * a.bgroups;
+    const int inst = a.n_inst - 1 - binst;
     const HadiInstPar ip = a.ipar[inst];
     if (n > ip.N) return;  // whole block: uniform
     const int nrows = a.L.nrows_pad;
