@@ -83,7 +83,8 @@ namespace emu {
 // holds for the wave- or block-uniform early exits the kernels use).
 template <class F>
 void launch(unsigned grid, unsigned block, F body, size_t dyn_smem_bytes = 0) {
-    std::vector<double> smem_store((dyn_smem_bytes + 7) / 8 + 2);
+    // LDS is NOT zero on a GPU: poison it so that reads of never-written LDS surface here
+    std::vector<double> smem_store((dyn_smem_bytes + 7) / 8 + 2, std::nan(""));
     for (unsigned b = 0; b < grid; b++) {
         BlockState bs;
         bs.dyn_smem = reinterpret_cast<unsigned char *>(smem_store.data());
