@@ -161,6 +161,8 @@ hipError_t raise_all_lds_limits() {
     if ((e = raise_pass_a<4, 1, 1, 2>()) != hipSuccess) return e;
     if ((e = raise_pass_a<8, 1, 1, 1>()) != hipSuccess) return e;
     if ((e = raise_pass_a<8, 2, 1, 1>()) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a_strip<8, false>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a_strip<8, true>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_kernel<1, 4, false>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_kernel<1, 4, true>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_kernel<2, 4, false>)) != hipSuccess) return e;
@@ -259,6 +261,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     a.pb = ptr<double>(c->pb); a.rinv = ptr<double>(c->rinv); a.ipar = ptr<HadiInstPar>(c->ipar);
     a.L = L; a.n_inst = d.n; a.R = pl.R; a.ntiles = pl.ntiles; a.ctiles = pl.ctiles; a.btpw = pl.btpw; a.bgroups = pl.bgroups;
     a.american = american ? 1 : 0; a.pos_m1 = pl.pos_m1;
+    a.RS = pl.RS; a.sblocks = pl.sblocks;
     a.R1 = cs ? ptr<double>(c->R1) : nullptr;
     a.C2 = cs ? ptr<double>(c->C2) : nullptr;
     // Craig-Sneyd: the predictor's column pass writes V (= Y2), the corrector's row pass reads V
@@ -286,6 +289,11 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
             }
             if (prof) HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 0], q));
             auto row_pass = [&](const HadiSweepArgs &ar, int mode) {
+                if (pl.use_strip && mode == 0) {  // barrier-free strips (Douglas step, 8 nodes per lane)
+                    if (american) hipLaunchKernelGGL((hadi_pass_a_strip<8, true>), dim3(pl.grid_as), dim3(512), pl.smem_as, q, ar, nstep);
+                    else hipLaunchKernelGGL((hadi_pass_a_strip<8, false>), dim3(pl.grid_as), dim3(512), pl.smem_as, q, ar, nstep);
+                    return;
+                }
                 switch (L.B * 10 + L.G) {
                     case 11: launch_pass_a<1, 1, 1, 2>(pl, ar, nstep, q, mode); break;
                     case 21: launch_pass_a<2, 1, 1, 2>(pl, ar, nstep, q, mode); break;
@@ -355,7 +363,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         {  // field by field: struct padding is not initialised
             const void *ptrs[] = {a.U, a.Y, a.LAM, a.U0, a.scoef, a.b2row, a.rowc, a.pb, a.rinv, a.ipar, a.R1, a.C2, av.U};
             const int ints[] = {a.L.m1, a.L.m2, a.L.B, a.L.G, a.L.P, a.n_inst, a.R, a.ntiles, a.ctiles, a.btpw, a.bgroups,
-                                a.american, a.pos_m1, d.scheme, pl.grid_a, pl.grid_b, pl.block_b, pl.W, (int)pl.smem_a, (int)pl.smem_b};
+                                a.american, a.pos_m1, d.scheme, pl.use_strip, pl.RS, pl.sblocks, pl.grid_as, pl.grid_a, pl.grid_b, pl.block_b, pl.W, (int)pl.smem_a, (int)pl.smem_b};
             put(ptrs, sizeof(ptrs));
             put(ints, sizeof(ints));
         }

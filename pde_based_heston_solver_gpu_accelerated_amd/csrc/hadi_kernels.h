@@ -37,6 +37,7 @@ struct HadiSweepArgs {
     HadiLayout L;
     int n_inst;
     int R, ntiles;   // pass A: rows per wave, tiles per instance
+    int RS, sblocks; // strip row pass: v-rows per wavefront strip, 8-strip blocks per instance
     int ctiles;      // pass B: 64-column tiles per instance
     int btpw, bgroups;  // pass B: column tiles per block, blocks per instance
     int american;
@@ -107,16 +108,21 @@ __device__ unsigned long long g_hadi_stamps[32];
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
     sacc_[k] += t_ - stamp_prev_; stamp_prev_ = t_; } } while (0)
 // HADI_STAMPS=3: column-pass phases (16..23) instead
-#define HADI_STAMPB(k) do { if (HADI_STAMPS >= 3) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+#define HADI_STAMPB(k) do { if (HADI_STAMPS == 3) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
     sacc_[k] += t_ - stamp_prev_; stamp_prev_ = t_; } } while (0)
-#define HADI_STAMPB_WAIT(n) do { if (HADI_STAMPS >= 3) { if ((n) >= 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); \
+// HADI_STAMPS=4: strip row pass phases (24..29)
+#define HADI_STAMPC(k) do { if (HADI_STAMPS == 4) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    sacc_[k] += t_ - stamp_prev_; stamp_prev_ = t_; } } while (0)
+#define HADI_STAMPB_WAIT(n) do { if (HADI_STAMPS == 3) { if ((n) >= 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); \
     else if ((n) >= 33) asm volatile("s_waitcnt vmcnt(33)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } } while (0)
 #else
 #define HADI_STAMP_ACC
 #define HADI_STAMP_DECL(accptr)
 #define HADI_STAMP(k)
 #define HADI_STAMPB(k)
+#define HADI_STAMPC(k)
 #define HADI_STAMPB_WAIT(n)
 #endif
 
@@ -160,6 +166,70 @@ HADI_DEV HADI_FORCEINLINE void hadi_buf_store(HadiBuf b, unsigned voff_bytes, un
 // A raw buffer store whose VGPR offset is >= num_records is dropped by the hardware (the SGPR offset takes no part
 // in the range check): lanes that must not store get this offset instead of an exec-mask branch per row.
 #define HADI_BUF_DROP 0x80000000u
+// Cache policy of the row pass's LDS-DMA loads: non-temporal, like the column pass's loads (see HADI_AUX_NT).
+// Measured with the strip kernel at 256 instances of 512x256: 1.22e11 -> 1.29e11 point-steps/s.
+#ifndef HADI_DMA_POLICY
+#define HADI_DMA_POLICY " nt"
+#endif
+
+// Value of `v` held by lane `src` of this wavefront, `src` wave-uniform: two v_readlane_b32, result in SGPRs.
+HADI_DEV HADI_FORCEINLINE double hadi_read_lane(double v, int src) {
+#if defined(HADI_EMU)
+    return __shfl(v, src);
+#else
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+#endif
+}
+// The HADI_RCL scalars of one row-table entry through the scalar data cache into SGPRs (the entry is wave-uniform):
+// three s_load_dwordx8.  Inline asm because hipcc would issue per-lane vector loads here (it cannot prove that the
+// kernel's own stores leave the table alone), and those would also drain the LDS-DMA prefetch.
+#if !defined(HADI_EMU)
+typedef int hadi_i32x8 __attribute__((ext_vector_type(8)));
+struct HadiSRow { hadi_i32x8 q0, q1, q2; };
+#else
+struct HadiSRow { const double *p; };
+#endif
+// issue only: the three SGPR octets are NOT valid until hadi_sload_wait()
+HADI_DEV HADI_FORCEINLINE void hadi_sload_issue(const double *__restrict__ entry, HadiSRow &r) {
+#if defined(HADI_EMU)
+    r.p = entry;
+#else
+    asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x20\n\ts_load_dwordx8 %2, %3, 0x40"
+                 : "=&s"(r.q0), "=&s"(r.q1), "=&s"(r.q2)
+                 : "s"(entry)
+                 : "memory");
+#endif
+}
+HADI_DEV HADI_FORCEINLINE void hadi_sload_wait(HadiSRow &r, double (&rt)[HADI_RCL]) {
+#if defined(HADI_EMU)
+    for (int k = 0; k < HADI_RCL; k++) rt[k] = r.p[k];
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.q0), "+s"(r.q1), "+s"(r.q2) : : "memory");
+    rt[0] = __hiloint2double(r.q0[1], r.q0[0]); rt[1] = __hiloint2double(r.q0[3], r.q0[2]);
+    rt[2] = __hiloint2double(r.q0[5], r.q0[4]); rt[3] = __hiloint2double(r.q0[7], r.q0[6]);
+    rt[4] = __hiloint2double(r.q1[1], r.q1[0]); rt[5] = __hiloint2double(r.q1[3], r.q1[2]);
+    rt[6] = __hiloint2double(r.q1[5], r.q1[4]); rt[7] = __hiloint2double(r.q1[7], r.q1[6]);
+    rt[8] = __hiloint2double(r.q2[1], r.q2[0]); rt[9] = __hiloint2double(r.q2[3], r.q2[2]);
+    rt[10] = __hiloint2double(r.q2[5], r.q2[4]); rt[11] = __hiloint2double(r.q2[7], r.q2[6]);
+#endif
+}
+// A wave-uniform double moved to SGPRs (two v_readfirstlane): loop-invariant scalars then cost no VGPRs.
+HADI_DEV HADI_FORCEINLINE double hadi_uniform_d(double x) {
+#if defined(HADI_EMU)
+    return x;
+#else
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+#endif
+}
+// The lanes of a wavefront run in lock step on the GPU; the host-thread emulator needs a rendezvous wherever one
+// lane reads LDS another lane of the same wavefront wrote.
+HADI_DEV HADI_FORCEINLINE void hadi_wave_rendezvous() {
+#if defined(HADI_EMU)
+    pthread_barrier_wait(&emu::t_wave->bar);
+#endif
+}
 
 // ---- LDS row ring helpers ---------------------------------------------------------------------------
 // Asynchronous copy of one state row (rowp doubles, HBM layout == LDS layout) into the ring by LDS-DMA
@@ -183,7 +253,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_to_lds(const double *__restrict__ grow, 
                 const unsigned lds_dst = __builtin_amdgcn_readfirstlane(
                     (unsigned)(size_t)(__attribute__((address_space(3))) char *)(lrow + 2 * v0));
                 unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" HADI_DMA_POLICY "\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep)
                              : "v"(gsrc), "s"(lds_dst)
                              : "memory");
@@ -691,6 +761,326 @@ __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : 4)) hadi_pass_a
 }
 
 // ------------------------------------------------------------------------------------------------
+// Strip row pass (8 nodes per lane, one wavefront per v-row: 256 < m1 <= 512).  Same arithmetic as hadi_row_step,
+// different data movement: every wavefront owns a strip of RS consecutive v-rows and walks down it ALONE -- no
+// barrier in the loop.  The rows j-2, j-1, j of the stencil stay in registers from the previous steps, rows j+1 and
+// j+2 sit in the wavefront's private 4-slot LDS ring, rows j+3 and j+4 are in flight (LDS-DMA issued by this
+// wavefront, retired by its own counted vmcnt wait).  The s-neighbours of a lane's block come from the adjacent
+// lanes (ds_bpermute), the i = 0 column from the row's extra slot, the row's table entry through the scalar cache
+// into SGPRs.  Against the shared-ring kernel:
+// no block-wide barrier (its wait was ~40 % of a wavefront's time there), twice the rows in flight per CU, a quarter
+// of the LDS reads; the price is 4 halo rows per strip read again (mostly L2 hits).
+struct HadiStripCtx {
+    const double *coef;  // LDS: Bm, Bp, Dm, Dp, each 64*B doubles in row layout
+    double *Yi;          // instance base of Y
+    const double *Li;    // instance base of lambda_bar (American)
+    const double *b2r;   // instance b2 row (global)
+    int lane, rowp;
+    double dt, thdt, qd, half_rd, e_nm1, e_n;
+    HADI_STAMP_ACC
+};
+
+template <int B, bool AMER, bool LAST>
+HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtx &c, int j, const double (&rt)[HADI_RCL],
+                                               const double (&um2)[B], const double (&um1)[B], const double (&u0)[B],
+                                               const double (&up1)[B], const double (&up2)[B], double c0m2, double c0m1,
+                                               double c00, double c0p1, double c0p2) {
+    const int lane = c.lane, rowp = c.rowp;
+    constexpr int c0slot = 64 * B;
+    constexpr int NB = B - 1;
+    HADI_STAMP_DECL(c.stamp_acc_)
+    const double dt = c.dt, thdt = c.thdt, qd = c.qd, half_rd = c.half_rd, e_nm1 = c.e_nm1, e_n = c.e_n;
+    const double v = rt[RC_V];
+    const double wm = rt[RC_WM], wz = rt[RC_WZ], wp = rt[RC_WP];
+    const double a2l2 = rt[RC_L2], a2l1 = rt[RC_L1], a2m = rt[RC_M], a2u1 = rt[RC_U1], a2u2 = rt[RC_U2];
+    const double b1val = rt[RC_B1VAL];
+    const int b1col = (int)rt[RC_B1COL];
+    const int b1e = b1col - 1;
+    const int b1lane = (b1col >= 1) ? b1e / B : -1;
+    const int b1r = b1e - (b1e / B) * B;
+
+    // ---- column i = 0 (A0 and A1 rows are zero there; only A2 and the boundary act) ----------------
+    const double a2c0 = a2l2 * c0m2 + a2l1 * c0m1 + a2m * c00 + a2u1 * c0p1 + a2u2 * c0p2;
+    const double b1c0 = (b1col == 0) ? b1val : 0.0;
+    const double b2c0 = LAST ? c.b2r[c0slot] : 0.0;
+    const double lamc0 = AMER ? c.Li[(size_t)j * rowp + c0slot] : 0.0;
+    double y0c0 = c00 + dt * (a2c0 + (b1c0 + b2c0) * e_nm1 + lamc0);
+    y0c0 = y0c0 + thdt * (b1c0 * e_n - (0.0 + b1c0 * e_nm1));
+    const double c2c0 = thdt * (b2c0 * e_n - (a2c0 + b2c0 * e_nm1));
+    const double x0 = y0c0;  // A1 row 0 is the identity (hes_a1_kernels.hpp:56-61)
+    const double yout_c0 = x0 + c2c0;
+
+    // ---- explicit operators (same evaluation order as hadi_row_step) -------------------------------------
+    double tt[B], A2U[B];
+#pragma unroll
+    for (int r = 0; r < B; r++) {
+        tt[r] = wm * um1[r] + wz * u0[r] + wp * up1[r];
+        A2U[r] = a2l1 * um1[r] + a2m * u0[r] + a2u1 * up1[r];
+    }
+#pragma unroll
+    for (int r = 0; r < B; r++) A2U[r] = fma(a2l2, um2[r], A2U[r]);
+#pragma unroll
+    for (int r = 0; r < B; r++) A2U[r] = fma(a2u2, up2[r], A2U[r]);
+    // s-neighbours of the block: last node of lane-1, first node of lane+1; lane 0 borders i = 0, lane 63 the pad (0)
+    const int lp = (lane - 1) & 63, ln = (lane + 1) & 63;
+    double u0L = hadi_lane_get(u0[B - 1], lp), tL = hadi_lane_get(tt[B - 1], lp);
+    double u0R = hadi_lane_get(u0[0], ln), tR = hadi_lane_get(tt[0], ln);
+    if (lane == 0) {
+        u0L = c00;
+        tL = wm * c0m1 + wz * c00 + wp * c0p1;
+    }
+    if (lane == 63) {
+        u0R = 0.0;
+        tR = 0.0;
+    }
+    const double cb1 = dt * e_nm1 + thdt * (e_n - e_nm1);
+
+    double lam[B], b2v[B];
+    if constexpr (AMER) hadi_get_block<B, 1>(c.Li + (size_t)j * rowp, 0, lane, lam);
+    if constexpr (LAST) hadi_get_block<B, 1>(c.b2r, 0, lane, b2v);
+
+    // ---- Y0 (device_solver.hpp:236-250) fused with the forward sweep of the in-lane Thomas ----------
+    // The s-coefficients are read pair by pair inside the sweep (a compiler barrier keeps hipcc from hoisting all 16
+    // LDS reads to the top: 32 live doubles there are what pushed this kernel into scratch).
+    double Bm[B], Bp[B], Dm[B], Dp[B];
+    double ys[B], ps[B], gs[B], iu[B], invt[B];
+    double il_last = 0.0, im_last = 1.0, d_last = 0.0;
+#pragma unroll
+    for (int r = 0; r < B; r++) {
+        if ((r & 1) == 0) {
+#if !defined(HADI_EMU)
+            asm volatile("" ::: "memory");
+#endif
+            const int q = r >> 1;
+            const double2 t0 = *reinterpret_cast<const double2 *>(c.coef + 0 * 64 * B + q * 128 + 2 * lane);
+            const double2 t1 = *reinterpret_cast<const double2 *>(c.coef + 1 * 64 * B + q * 128 + 2 * lane);
+            const double2 t2 = *reinterpret_cast<const double2 *>(c.coef + 2 * 64 * B + q * 128 + 2 * lane);
+            const double2 t3 = *reinterpret_cast<const double2 *>(c.coef + 3 * 64 * B + q * 128 + 2 * lane);
+            Bm[r] = t0.x; Bm[r + 1] = t0.y;
+            Bp[r] = t1.x; Bp[r + 1] = t1.y;
+            Dm[r] = t2.x; Dm[r + 1] = t2.y;
+            Dp[r] = t3.x; Dp[r + 1] = t3.y;
+        }
+        const double uL = (r == 0) ? u0L : u0[r == 0 ? 0 : r - 1];
+        const double uR = (r == B - 1) ? u0R : u0[r == B - 1 ? r : r + 1];
+        const double tl = (r == 0) ? tL : tt[r == 0 ? 0 : r - 1];
+        const double tr = (r == B - 1) ? tR : tt[r == B - 1 ? r : r + 1];
+        const double lo = fma(v, Dm[r], qd * Bm[r]);
+        const double up = fma(v, Dp[r], qd * Bp[r]);
+        const double mn = -(fma(v, Dm[r] + Dp[r], qd * (Bm[r] + Bp[r])) + half_rd);
+        const double A1U = lo * uL + mn * u0[r] + up * uR;
+        const double A0U = Bm[r] * tl - (Bm[r] + Bp[r]) * tt[r] + Bp[r] * tr;
+        const double b1h = (lane == b1lane && r == b1r) ? b1val : 0.0;
+        double S = A0U + A1U + A2U[r];
+        if constexpr (LAST) S += b2v[r] * e_nm1;
+        if constexpr (AMER) S += lam[r];
+        double y = fma(dt, S, u0[r]);
+        y = fma(-thdt, A1U, y);
+        y = fma(b1h, cb1, y);
+        double il = -thdt * lo;
+        const double im = 1.0 - thdt * mn;
+        iu[r] = -thdt * up;
+        if (r == 0 && lane == 0) {  // x_0 is known: move it to the right-hand side
+            y -= il * x0;
+            il = 0.0;
+        }
+        if (r < NB) {
+            if (r == 0) {
+                invt[0] = hadi_rcp(im);
+                ys[0] = y;
+                ps[0] = il;
+            } else {
+                const double w = il * invt[r - 1];
+                invt[r] = hadi_rcp(fma(-w, iu[r - 1], im));
+                ys[r] = fma(-w, ys[r - 1], y);
+                ps[r] = -w * ps[r - 1];
+            }
+        } else {
+            il_last = il;
+            im_last = im;
+            d_last = y;
+        }
+    }
+    HADI_STAMPC(26);  // explicit operators + Y0 + forward Thomas
+    // reduced (interface) row of this lane
+    double ra, rb, rcc, rf;
+    {
+        gs[NB - 1] = iu[NB - 1] * invt[NB - 1];
+        ys[NB - 1] *= invt[NB - 1];
+        ps[NB - 1] *= invt[NB - 1];
+#pragma unroll
+        for (int r = NB - 2; r >= 0; r--) {
+            ys[r] = fma(-iu[r], ys[r + 1], ys[r]) * invt[r];
+            ps[r] = fma(-iu[r], ps[r + 1], ps[r]) * invt[r];
+            gs[r] = -iu[r] * gs[r + 1] * invt[r];
+        }
+        const double p0n = hadi_lane_get(ps[0], ln), g0n = hadi_lane_get(gs[0], ln), y0n = hadi_lane_get(ys[0], ln);
+        ra = -il_last * ps[NB - 1];
+        rb = im_last - il_last * gs[NB - 1] - iu[B - 1] * p0n;
+        rcc = -iu[B - 1] * g0n;
+        rf = d_last - il_last * ys[NB - 1] - iu[B - 1] * y0n;
+    }
+    HADI_STAMPC(27);  // backward Thomas + reduced row
+    // ---- parallel cyclic reduction over the 64 interface unknowns (normalised rows, see hadi_row_step) ----
+    {
+        const double rinv0 = hadi_rcp(rb);
+        ra *= rinv0;
+        rcc *= rinv0;
+        rf *= rinv0;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const int up_lane = (lane - s) & 63, dn_lane = (lane + s) & 63;
+            const double aL = hadi_lane_get(ra, up_lane), cL = hadi_lane_get(rcc, up_lane), fL = hadi_lane_get(rf, up_lane);
+            const double aR = hadi_lane_get(ra, dn_lane), cR = hadi_lane_get(rcc, dn_lane), fR = hadi_lane_get(rf, dn_lane);
+            const double bn = fma(-rcc, aR, fma(-ra, cL, 1.0));
+            const double rn = hadi_rcp(bn);
+            rf = fma(-rcc, fR, fma(-ra, fL, rf)) * rn;
+            if (s < 32) {
+                const double an = -(ra * aL) * rn;
+                const double cn = -(rcc * cR) * rn;
+                ra = an;
+                rcc = cn;
+            }
+        }
+    }
+    HADI_STAMPC(28);  // PCR
+    const double X = rf;
+    double XL = hadi_lane_get(X, lp);
+    if (lane == 0) XL = 0.0;
+    // ---- Y1 -> right-hand side of the A2 solve (device_solver.hpp:254-260) and store ----------
+    double yo[B];
+#pragma unroll
+    for (int r = 0; r < B; r++) {
+        double x;
+        if (r < NB) x = ys[r] - XL * ps[r] - X * gs[r];
+        else x = X;
+        double corr;
+        if constexpr (LAST) corr = thdt * (b2v[r] * e_n - (A2U[r] + b2v[r] * e_nm1));
+        else corr = -thdt * A2U[r];
+        yo[r] = x + corr;
+    }
+    hadi_put_block<B, 1>(c.Yi + (size_t)j * rowp, 0, lane, yo);
+    if (lane == 0) c.Yi[(size_t)j * rowp + c0slot] = yout_c0;
+    HADI_STAMPC(29);  // final correction + store issue
+}
+
+// LDS: [8 wavefronts][4 ring slots][rowp] + the 4 s-coefficient arrays.  Grid = n_inst * sblocks blocks of 8 strips.
+template <int B, bool AMER>
+__global__ void __launch_bounds__(512, 2) hadi_pass_a_strip(HadiSweepArgs a, int n) {
+    HADI_DYN_SMEM(double, smem);
+    constexpr int NS = 4, NWV = 8, c0slot = 64 * B;
+    const int lane = threadIdx.x & 63;
+    const int wave = HADI_UNIFORM((int)(threadIdx.x >> 6));
+    const int total = a.n_inst * a.sblocks;
+    const int logical = hadi_xcd_remap(blockIdx.x, gridDim.x);
+    if (logical >= total) return;
+    const int inst = logical / a.sblocks, sb = logical - inst * a.sblocks;
+    const HadiInstPar ip = a.ipar[inst];
+    if (n > ip.N) return;
+    const int nrows = a.L.nrows, npad = a.L.nrows_pad, rowp = a.L.rowp;
+    double *coef = smem + (size_t)NWV * NS * rowp;
+    {
+        const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B;
+        for (int e = threadIdx.x; e < 4 * 64 * B; e += 64 * NWV) coef[e] = sc[e];
+    }
+    __syncthreads();  // the only block-wide barrier: the coefficient arrays are shared
+    const int j0 = (sb * NWV + wave) * a.RS;
+    if (j0 >= nrows) return;
+    const int j1 = (j0 + a.RS < nrows) ? j0 + a.RS : nrows;
+
+    HadiStripCtx c;
+    c.lane = lane;
+    c.rowp = rowp;
+    c.coef = coef;
+    c.dt = hadi_uniform_d(ip.dt); c.thdt = hadi_uniform_d(ip.thdt); c.qd = hadi_uniform_d(ip.q);
+    c.half_rd = hadi_uniform_d(ip.half_rd);
+    c.e_nm1 = hadi_uniform_d(exp(ip.r_f * ip.dt * (n - 1)));  // device_solver.hpp:238
+    c.e_n = hadi_uniform_d(exp(ip.r_f * ip.dt * n));          // device_solver.hpp:246
+    const double *__restrict__ Ub = a.U + (size_t)inst * a.L.inst_stride;
+    c.Yi = a.Y + (size_t)inst * a.L.inst_stride;
+    c.Li = AMER ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
+    c.b2r = a.b2row + (size_t)inst * rowp;
+
+    double *ring = smem + (size_t)wave * NS * rowp;
+    auto slot = [&](int jj) { return ring + (size_t)(jj & (NS - 1)) * rowp; };
+    // returns the number of vector-memory instructions issued (rows outside the allocation are zero-filled)
+    auto fetch = [&](int jj) -> int {
+        const bool exists = jj >= 0 && jj < npad;
+        hadi_row_to_lds(Ub + (size_t)jj * rowp, slot(jj), rowp, lane, exists);
+        return exists ? (rowp / 2 + 63) / 64 : 0;
+    };
+    // ---- prologue: rows j0+1 .. j0+3 to the ring, rows j0-2 .. j0 and this strip's row table to registers ----
+    fetch(j0 + 1);
+    fetch(j0 + 2);
+    int after0 = fetch(j0 + 3);  // vector-memory instructions issued after the DMA of the row needed next (j+2)
+    int after1 = 0;              // ... after the DMA of row j+3
+    double um2[B], um1[B], u0[B];
+    double c0m2 = 0.0, c0m1 = 0.0, c00, c0p1;
+    hadi_load_row<B>(Ub + (size_t)(j0 - 2) * rowp, lane, j0 - 2 >= 0, um2);
+    hadi_load_row<B>(Ub + (size_t)(j0 - 1) * rowp, lane, j0 - 1 >= 0, um1);
+    hadi_load_row<B>(Ub + (size_t)j0 * rowp, lane, true, u0);
+    if (j0 - 2 >= 0) c0m2 = Ub[(size_t)(j0 - 2) * rowp + c0slot];
+    if (j0 - 1 >= 0) c0m1 = Ub[(size_t)(j0 - 1) * rowp + c0slot];
+    c00 = Ub[(size_t)j0 * rowp + c0slot];
+    c0p1 = (j0 + 1 < npad) ? Ub[(size_t)(j0 + 1) * rowp + c0slot] : 0.0;
+#if !defined(HADI_EMU)
+    // Consume the prologue's register loads HERE: otherwise hipcc parks their s_waitcnt vmcnt(0) at the loop header,
+    // where it would retire the DMA prefetch and the result stores in every iteration.
+#pragma unroll
+    for (int r = 0; r < B; r++) asm volatile("" : "+v"(um2[r]), "+v"(um1[r]), "+v"(u0[r]));
+    asm volatile("" : "+v"(c0m2), "+v"(c0m1), "+v"(c00), "+v"(c0p1));
+#endif
+
+#if defined(HADI_STAMPS) && !defined(HADI_EMU)
+    unsigned long long stamp_store_[32] = {0};
+    c.stamp_acc_ = stamp_store_;
+#endif
+    HADI_STAMP_DECL(c.stamp_acc_)
+    for (int j = j0; j < j1; j++) {
+        HADI_STAMPC(30);  // carry + loop
+        HadiSRow srow;
+        hadi_sload_issue(a.rowc + ((size_t)inst * nrows + j) * HADI_RC, srow);  // flies during the DMA wait
+        hadi_wait_vmcnt(after0);  // row j+2 has landed (row j+1 landed a step earlier)
+        HADI_STAMPC(24);  // wait for the DMA
+        double rt[HADI_RCL];
+        hadi_sload_wait(srow, rt);  // lgkmcnt(0): also retires this wavefront's LDS reads of the previous step, so ...
+        hadi_wave_rendezvous();
+        // ... row j+4 may go to the slot of row j now (row j is in registers; nobody reads that slot any more)
+        int z = 0;
+        if (j + 4 <= j1 + 1) z = fetch(j + 4);
+        after0 = after1 + z;
+        after1 = 0;
+        hadi_wave_rendezvous();
+        double up1[B], up2[B];
+        hadi_lds_row<B>(slot(j + 1), lane, up1);
+        hadi_lds_row<B>(slot(j + 2), lane, up2);
+        const double c0p2 = slot(j + 2)[c0slot];
+        HADI_STAMPC(25);  // LDS reads + table entry + DMA issue
+        if (j == nrows - 1) hadi_strip_step<B, AMER, true>(c, j, rt, um2, um1, u0, up1, up2, c0m2, c0m1, c00, c0p1, c0p2);
+        else hadi_strip_step<B, AMER, false>(c, j, rt, um2, um1, u0, up1, up2, c0m2, c0m1, c00, c0p1, c0p2);
+        after0 += B / 2;  // the row's vector stores (the i = 0 store is not counted: lower bound)
+        after1 += B / 2;
+#pragma unroll
+        for (int r = 0; r < B; r++) {
+            um2[r] = um1[r];
+            um1[r] = u0[r];
+        }
+        hadi_lds_row<B>(slot(j + 1), lane, u0);  // again from its slot (intact until step j+1) rather than held in registers
+        c0m2 = c0m1;
+        c0m1 = c00;
+        c00 = c0p1;
+        c0p1 = c0p2;
+#if defined(HADI_STAMPS) && !defined(HADI_EMU)
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev_) :: "memory");  // the step stamped itself
+#endif
+    }
+#if defined(HADI_STAMPS) && !defined(HADI_EMU)
+    if (HADI_STAMPS == 4 && lane == 0)
+        for (int k = 24; k < 31; k++) atomicAdd(&g_hadi_stamps[k], stamp_store_[k]);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // pass B.  Block = P wavefronts (P*64 threads); wavefront p owns v-rows [p*HADI_LC, (p+1)*HADI_LC) of its
 // instance (rows past nrows are identity padding, so there are no tail branches) and
 // keeps one 64-column tile of them in registers.  A block walks over `btpw` consecutive column tiles
@@ -915,7 +1305,7 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
         if (t + 1 < t1) hadi_pb_solve_store<AMER>(c, t + 1, 1, yb, (t + 2 < t1 ? HADI_LC : 0) + HADI_LC);
     }
 #if defined(HADI_STAMPS) && !defined(HADI_EMU)
-    if (HADI_STAMPS >= 3 && c.lane == 0)
+    if (HADI_STAMPS == 3 && c.lane == 0)
         for (int k = 16; k < 24; k++) atomicAdd(&g_hadi_stamps[k], stamp_store_[k]);
 #endif
 }
@@ -987,7 +1377,7 @@ __global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, in
         else hadi_pb_store<AMER, false>(c, t, y);
     }
 #if defined(HADI_STAMPS) && !defined(HADI_EMU)
-    if (HADI_STAMPS >= 3 && c.lane == 0)
+    if (HADI_STAMPS == 3 && c.lane == 0)
         for (int k = 16; k < 24; k++) atomicAdd(&g_hadi_stamps[k], stamp_store_[k]);
 #endif
 }

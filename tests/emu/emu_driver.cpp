@@ -22,6 +22,11 @@ static void run_pass_a(const HadiPlan &pl, const HadiSweepArgs &a, int n, int mo
 }
 
 static int run_row_pass(const HadiPlan &pl, const HadiSweepArgs &a, int n, int mode) {
+    if (pl.use_strip && mode == 0) {  // same choice as hadi_api.hip
+        if (a.american) emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<8, true>(a, n); }, pl.smem_as);
+        else emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<8, false>(a, n); }, pl.smem_as);
+        return 0;
+    }
     switch (pl.L.B * 10 + pl.L.G) {
         case 11: run_pass_a<1, 1, 1, 2>(pl, a, n, mode); break;
         case 21: run_pass_a<2, 1, 1, 2>(pl, a, n, mode); break;
@@ -90,7 +95,7 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
     a.U = dU.data(); a.Y = dY.data(); a.LAM = american ? dLAM.data() : nullptr; a.U0 = american ? dU0.data() : nullptr;
     a.scoef = scoef.data(); a.b2row = b2row.data(); a.rowc = rowc.data(); a.pb = pb.data(); a.rinv = rinv.data();
     a.ipar = ipar.data(); a.L = L; a.n_inst = n_inst; a.R = pl.R; a.ntiles = pl.ntiles; a.ctiles = pl.ctiles; a.btpw = pl.btpw; a.bgroups = pl.bgroups;
-    a.american = american; a.pos_m1 = pl.pos_m1;
+    a.american = american; a.pos_m1 = pl.pos_m1; a.RS = pl.RS; a.sblocks = pl.sblocks;
     a.R1 = cs ? dR1.data() : nullptr; a.C2 = cs ? dC2.data() : nullptr;
     HadiSweepArgs av = a;
     if (cs) av.U = dV.data();

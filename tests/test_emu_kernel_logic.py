@@ -78,6 +78,16 @@ def test_single_buffer_column_pass_for_more_than_8_chunks(emu):
     _run(emu, 280, 265, 2, [97.0], O.AM, 1, r_f=0.01)
 
 
+def test_strip_row_pass(emu, monkeypatch):
+    # 8 nodes per lane: every wavefront walks a strip of v-rows alone (register window + private LDS ring, no barrier).
+    # 151 rows -> 8 strips of 19; r_f != 0 exercises the boundary terms, the last strip carries the b2 row
+    _run(emu, 300, 150, 2, [100.0], O.EU, 1, r_f=0.01)
+    # forced short strips (6 rows: prologue / halo / ring wrap-around on every strip), American adds lambda_bar
+    monkeypatch.setenv("HADI_TUNE_STRIP", "1")
+    _run(emu, 280, 40, 3, [95.0], O.AM, 1)
+    _run(emu, 512, 20, 2, [104.0], O.EU, 1)
+
+
 def test_two_waves_per_row_split_solve(emu):
     # m1 > 512: the row's tridiagonal system is split over two wavefronts and re-coupled by a 2x2 system
     _run(emu, 600, 12, 2, [100.0, 93.0], O.EU, 8)

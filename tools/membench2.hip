@@ -36,6 +36,7 @@ template<int B,int NT> __global__ void __launch_bounds__(256) rowpat(const doubl
 }
 int main(){
   const int n_inst=256,rowp=520,nrows=264; const long stride=(long)rowp*nrows; size_t tot=(size_t)stride*n_inst;
+  CK(hipFuncSetAttribute((const void*)rowpat<8,1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024)); CK(hipFuncSetAttribute((const void*)colpat<33,1,3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
   double *a,*b; CK(hipMalloc(&a,tot*8)); CK(hipMalloc(&b,tot*8)); CK(hipMemset(a,0,tot*8)); CK(hipMemset(b,0,tot*8));
   hipEvent_t e0,e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); float ms; const int reps=20;
   double gb=2.0*tot*8/1e9;  // per pass
@@ -52,5 +53,10 @@ int main(){
    hipEventRecord(e0); for(int r=0;r<reps;r++){ rowpat<8,1><<<n_inst*8*64/256,256>>>(a,b,rowp,nrows,stride,33,8,n_inst,0); rowpat<8,1><<<n_inst*8*64/256,256>>>(b,a,rowp,nrows,stride,33,8,n_inst,1);} rep("row + row desc, nt");
    hipEventRecord(e0); for(int r=0;r<reps;r++){ colpat<33,1,3><<<n_inst*3,512>>>(a,b,rowp,nrows,stride,3,n_inst,0); colpat<33,1,3><<<n_inst*3,512>>>(b,a,rowp,nrows,stride,3,n_inst,1);} rep("col + col desc, nt");
    hipEventRecord(e0); for(int r=0;r<reps;r++){ colpat<33,0,3><<<n_inst*3,512>>>(a,b,rowp,nrows,stride,3,n_inst,0); colpat<33,0,3><<<n_inst*3,512>>>(b,a,rowp,nrows,stride,3,n_inst,0);} rep("col + col asc");
+   // the same with the occupancy of libhadi's kernels: dynamic LDS limits the row pattern to 8 waves per CU (two
+   // 4-wave blocks) and the column pattern to one 8-wave block per CU
+   hipEventRecord(e0); for(int r=0;r<reps;r++){ rowpat<8,1><<<n_inst*8*64/256,256,72*1024>>>(a,b,rowp,nrows,stride,33,8,n_inst,0); colpat<33,1,3><<<n_inst*3,512,100*1024>>>(b,a,rowp,nrows,stride,3,n_inst,1);} rep("row + col desc, nt, 8 waves/CU each");
+   hipEventRecord(e0); for(int r=0;r<reps;r++){ rowpat<8,1><<<n_inst*8*64/256,256,72*1024>>>(a,b,rowp,nrows,stride,33,8,n_inst,0); colpat<33,1,3><<<n_inst*3,512>>>(b,a,rowp,nrows,stride,3,n_inst,1);} rep("row 8 waves/CU + col 16 waves/CU");
+   hipEventRecord(e0); for(int r=0;r<reps;r++){ rowpat<8,1><<<n_inst*8*64/256,256>>>(a,b,rowp,nrows,stride,33,8,n_inst,0); colpat<33,1,3><<<n_inst*3,512,100*1024>>>(b,a,rowp,nrows,stride,3,n_inst,1);} rep("row full occupancy + col 8 waves/CU");
   }
   return 0; }

@@ -34,6 +34,15 @@ if os.environ.get("STAMP_LEVEL") == "3":
     for k, nm in bn.items():
         print("%-32s %8.0f cycles/tile  %5.1f %%" % (nm, buf[k] / tiles, 100.0 * buf[k] / tb))
     sys.exit(0)
+if os.environ.get("STAMP_LEVEL") == "4":
+    cn = {24: "wait for the DMA (row j+2)", 25: "LDS reads + table entry + DMA issue", 26: "explicit ops + Y0 + fwd Thomas",
+          27: "bwd Thomas + reduced row", 28: "PCR", 29: "final + store issue", 30: "carry + loop"}
+    rows = n * 257 * N
+    tc = sum(buf[k] for k in cn)
+    print("sweep_ms", s.timing()["sweep_ms"])
+    for k, nm in cn.items():
+        print("%-40s %8.0f cycles/row  %5.1f %%" % (nm, buf[k] / rows, 100.0 * buf[k] / tc))
+    sys.exit(0)
 rows = n * 257 * N
 tot = sum(buf[k] for k in (8, 9, 10))
 print("sweep_ms", s.timing()["sweep_ms"])
