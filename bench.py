@@ -124,6 +124,7 @@ def main():
         solver.set_profiling(True)
         step()
         tm = solver.timing()
+        path = solver.describe_last_sweep()
         solver.set_profiling(False)
         pts = float(n_loc) * m
         a_ms = tm["pass_a_ms"] / max(1, tm["pass_a_launches"])
@@ -132,7 +133,7 @@ def main():
         ach_b = B_ALG_PASS * pts / (b_ms * 1e-3) / 1e9
         ach_step = B_ALG_STEP * pts * N / (tm["sweep_ms"] * 1e-3) / 1e9
         roofline = {
-            "bound": "hbm", "kernel": "hadi_pass_a<%d>" % (8 if m1 > 256 else 4 if m1 > 128 else 2 if m1 > 64 else 1),
+            "bound": "hbm", "kernel": path.split(";")[0].replace("row pass ", ""), "kernels": path,
             "achieved": round(ach_a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_a / HBM_PEAK_GBS, 4),
             "traffic": None,
             "avg_launch_ms": round(a_ms, 5), "bytes_per_launch_algorithmic": B_ALG_PASS * pts,

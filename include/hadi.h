@@ -137,6 +137,8 @@ int hadi_get_timing(const hadi_ctx *ctx, hadi_timing *out);
 int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value);
 /* Device the handle runs on: name, CU count, gcn arch string (for bench reports). */
 int hadi_device_info(const hadi_ctx *ctx, char *name, int name_len, int *compute_units, char *arch, int arch_len);
+/* Which kernels the last sweep on this handle ran (kernel names and tile geometry), for bench reports and profiles. */
+int hadi_describe_last_sweep(const hadi_ctx *ctx, char *buf, int len);
 /* Opaque hipStream_t of the handle (void*), so callers can order their own work after it. */
 void *hadi_stream(hadi_ctx *ctx);
 

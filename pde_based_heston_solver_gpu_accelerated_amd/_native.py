@@ -54,7 +54,7 @@ class Timing(C.Structure):
 # every symbol include/hadi.h declares (tests check the library exports all of them)
 EXPORTS = [
     "hadi_create", "hadi_destroy", "hadi_last_error", "hadi_status_string", "hadi_version",
-    "hadi_set_profiling", "hadi_get_timing", "hadi_set_tuning", "hadi_device_info", "hadi_stream",
+    "hadi_set_profiling", "hadi_get_timing", "hadi_set_tuning", "hadi_device_info", "hadi_describe_last_sweep", "hadi_stream",
     "hadi_make_grid", "hadi_rebuild_variance", "hadi_find_s_index", "hadi_find_v_index",
     "hadi_DO_timestepping", "hadi_parallel_DO_solve",
     "hadi_compute_base_prices", "hadi_compute_base_prices_american",
@@ -93,6 +93,7 @@ def lib():
     L.hadi_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
     L.hadi_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.hadi_device_info.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _ip, C.c_char_p, C.c_int]
+    L.hadi_describe_last_sweep.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.hadi_stream.argtypes = [C.c_void_p]
     L.hadi_make_grid.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                                  C.c_int, C.c_double, C.c_double, C.c_double, _dp, _dp, _dp, _dp]

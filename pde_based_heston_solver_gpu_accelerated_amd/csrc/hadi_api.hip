@@ -46,6 +46,7 @@ struct Ctx {
     unsigned long long graph_clock = 0;
     int use_graph = 1;
     int use_small = 1;  // LDS-resident one-launch path for small grids
+    std::string last_path;  // which kernels the last sweep ran (hadi_describe_last_sweep)
     DevBuf div_flag, div_amt, div_pct;
 };
 
@@ -333,6 +334,12 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     // ---- small grids: the whole instance fits in LDS -> one launch runs the entire time loop ----------
     const size_t smem_small = american ? pl.smem_small_am : pl.smem_small_eu;
     if (c->use_small && !prof && !cs && smem_small > 0) {
+        {
+            char buf[160];
+            std::snprintf(buf, sizeof buf, "hadi_small_kernel<%d,4,%s>: whole time loop in one launch, instance resident in LDS (%zu B)", L.B,
+                          american ? "AM" : "EU", smem_small);
+            c->last_path = buf;
+        }
         HadiSmallArgs sm;
         sm.div_flag = nullptr; sm.div_amounts = nullptr; sm.div_pcts = nullptr; sm.vec_s = d.d_vec_s; sm.Nmax = d.Nmax;
         sm.flag_stride = flag_stride;
@@ -352,6 +359,16 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         return HADI_OK;
     }
 
+    {
+        char buf[256];
+        char rowk[96];
+        if (pl.use_strip && !cs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,%s> (strips of %d rows)", american ? "AM" : "EU", pl.RS);
+        else std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,%s%s> (tiles of %d rows)", L.B, L.G, pl.W, pl.NG, pl.PD,
+                           american ? "AM" : "EU", cs ? ",CS" : "", pl.R);
+        std::snprintf(buf, sizeof buf, "row pass %s; column pass %s<%d,%s> (%d chunks of %d rows, %d column tiles per block)", rowk,
+                      L.P <= 8 ? "hadi_pass_b" : "hadi_pass_b1", L.P <= 8 ? 8 : 16, american ? "AM" : "EU", L.P, HADI_LC, pl.btpw);
+        c->last_path = buf;
+    }
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     // Small batches are launch-bound (2*N dependent launches of a few microseconds each): replay the loop
     // from a cached hipGraph.  Every kernel argument is baked into the nodes, so the key is everything they
@@ -793,6 +810,13 @@ int hadi_device_info(const hadi_ctx *ctx, char *name, int name_len, int *compute
     if (name && name_len > 0) std::snprintf(name, name_len, "%s", c->name.c_str());
     if (arch && arch_len > 0) std::snprintf(arch, arch_len, "%s", c->arch.c_str());
     if (compute_units) *compute_units = c->cu_count;
+    return HADI_OK;
+}
+
+int hadi_describe_last_sweep(const hadi_ctx *ctx, char *buf, int len) {
+    const Ctx *c = reinterpret_cast<const Ctx *>(ctx);
+    if (!c || !buf || len <= 0) return HADI_ERR_INVALID;
+    std::snprintf(buf, len, "%s", c->last_path.c_str());
     return HADI_OK;
 }
 

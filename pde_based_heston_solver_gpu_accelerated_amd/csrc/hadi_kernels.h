@@ -1042,10 +1042,9 @@ __global__ void __launch_bounds__(512, 2) hadi_pass_a_strip(HadiSweepArgs a, int
         hadi_sload_issue(a.rowc + ((size_t)inst * nrows + j) * HADI_RC, srow);  // flies during the DMA wait
         hadi_wait_vmcnt(after0);  // row j+2 has landed (row j+1 landed a step earlier)
         HADI_STAMPC(24);  // wait for the DMA
-        double rt[HADI_RCL];
-        hadi_sload_wait(srow, rt);  // lgkmcnt(0): also retires this wavefront's LDS reads of the previous step, so ...
         hadi_wave_rendezvous();
-        // ... row j+4 may go to the slot of row j now (row j is in registers; nobody reads that slot any more)
+        // row j+4 goes to the slot of row j: row j is in registers, and this wavefront's last read of that slot (the
+        // reload at the end of the previous step) has been retired there
         int z = 0;
         if (j + 4 <= j1 + 1) z = fetch(j + 4);
         after0 = after1 + z;
@@ -1055,6 +1054,8 @@ __global__ void __launch_bounds__(512, 2) hadi_pass_a_strip(HadiSweepArgs a, int
         hadi_lds_row<B>(slot(j + 1), lane, up1);
         hadi_lds_row<B>(slot(j + 2), lane, up2);
         const double c0p2 = slot(j + 2)[c0slot];
+        double rt[HADI_RCL];
+        hadi_sload_wait(srow, rt);  // one lgkmcnt(0) for the table entry and the LDS reads above
         HADI_STAMPC(25);  // LDS reads + table entry + DMA issue
         if (j == nrows - 1) hadi_strip_step<B, AMER, true>(c, j, rt, um2, um1, u0, up1, up2, c0m2, c0m1, c00, c0p1, c0p2);
         else hadi_strip_step<B, AMER, false>(c, j, rt, um2, um1, u0, up1, up2, c0m2, c0m1, c00, c0p1, c0p2);
@@ -1066,6 +1067,9 @@ __global__ void __launch_bounds__(512, 2) hadi_pass_a_strip(HadiSweepArgs a, int
             um1[r] = u0[r];
         }
         hadi_lds_row<B>(slot(j + 1), lane, u0);  // again from its slot (intact until step j+1) rather than held in registers
+#if !defined(HADI_EMU)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and retired before the next step reuses that slot
+#endif
         c0m2 = c0m1;
         c0m1 = c00;
         c00 = c0p1;

@@ -121,6 +121,12 @@ class HestonADI:
         self._lib.hadi_device_info(self._h, name, 256, C.byref(cu), arch, 64)
         return {"name": name.value.decode(), "arch": arch.value.decode(), "compute_units": cu.value}
 
+    def describe_last_sweep(self):
+        """Kernel names and tile geometry of the last sweep (for reports)."""
+        buf = C.create_string_buffer(512)
+        self._lib.hadi_describe_last_sweep(self._h, buf, 512)
+        return buf.value.decode()
+
     # ---- problem assembly ---------------------------------------------------------------------
     def _problem(self, variant, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids,
                  U=None, U_0=None, lambda_bar=None, dividends=None, per_instance=None, need_vgrid=True, scheme=0):

@@ -483,6 +483,35 @@ def test_multi_maturity_calibration_drivers_vs_oracle_driven_loop(solver):
               H.calibrate_american_dividends_multi_maturity(Cm.OracleSolver(), *args, max_iter=4))
 
 
+@pytest.mark.parametrize("variant,name", [(H.EU, "EU"), (H.AM, "AM"), (H.AM_DIV, "AM_DIV")])
+@pytest.mark.parametrize("m1,m2,N,n", [(512, 256, 8, 2), (300, 140, 5, 1), (260, 200, 4, 3), (400, 33, 6, 2)])
+def test_strip_row_pass_vs_oracle(solver, monkeypatch, variant, name, m1, m2, N, n):
+    """The barrier-free strip row pass (8 nodes per lane) is only chosen for large batches; force it on small ones so
+    that every strip geometry (short strips, ragged last strip, one block or several per instance) meets the oracle."""
+    monkeypatch.setenv("HADI_TUNE_STRIP", "1")
+    strikes = Cm.strikes_for(n)
+    grids, U0, U, lam = _hadi_solve(solver, m1, m2, N, strikes, variant, r_f=0.01, want_lambda=(variant != H.EU))
+    assert "hadi_pass_a_strip" in solver.describe_last_sweep()
+    p = Cm.oracle_params(m1, m2, N, name, r_f=0.01)
+    Uo, lo, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0, want_lambda=True)
+    _assert_field(U, Uo)
+    if lam is not None:
+        assert np.abs(lam - lo).max() <= 1e-8 * max(1.0, np.abs(lo).max())
+
+
+def test_describe_last_sweep_names_the_kernels(solver):
+    _hadi_solve(solver, 50, 25, 4, [100.0], H.EU)
+    assert "hadi_small_kernel" in solver.describe_last_sweep()
+    _hadi_solve(solver, 128, 64, 2, [100.0], H.AM)
+    d = solver.describe_last_sweep()
+    assert "hadi_pass_a<2,1" in d and "hadi_pass_b<8,AM>" in d
+    _hadi_solve(solver, 512, 256, 2, Cm.strikes_for(256), H.EU)   # enough rows per wavefront for the strip kernel
+    d = solver.describe_last_sweep()
+    assert "hadi_pass_a_strip<8,EU> (strips of 33 rows)" in d and "hadi_pass_b<8,EU>" in d
+    _hadi_solve(solver, 1024, 512, 2, [100.0], H.EU)
+    assert "hadi_pass_b1<16,EU>" in solver.describe_last_sweep()
+
+
 def test_profiling_reports_kernel_times(solver):
     m1, m2, N = 128, 64, 20
     solver.set_profiling(True)
