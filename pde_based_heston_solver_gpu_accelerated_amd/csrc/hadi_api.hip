@@ -164,6 +164,10 @@ hipError_t raise_all_lds_limits() {
     if ((e = raise_pass_a<8, 2, 1, 1>()) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_a_strip<8, false>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_a_strip<8, true>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a_strip<4, false>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a_strip<4, true>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a_strip<2, false>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a_strip<2, true>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_kernel<1, 4, false>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_kernel<1, 4, true>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_kernel<2, 4, false>)) != hipSuccess) return e;
@@ -290,9 +294,16 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
             }
             if (prof) HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 0], q));
             auto row_pass = [&](const HadiSweepArgs &ar, int mode) {
-                if (pl.use_strip && mode == 0) {  // barrier-free strips (Douglas step, 8 nodes per lane)
-                    if (american) hipLaunchKernelGGL((hadi_pass_a_strip<8, true>), dim3(pl.grid_as), dim3(512), pl.smem_as, q, ar, nstep);
-                    else hipLaunchKernelGGL((hadi_pass_a_strip<8, false>), dim3(pl.grid_as), dim3(512), pl.smem_as, q, ar, nstep);
+                if (pl.use_strip && mode == 0) {  // barrier-free strips (Douglas step, one wavefront per row)
+                    const dim3 g(pl.grid_as), b(512);
+                    switch (L.B * 2 + (american ? 1 : 0)) {
+                        case 16: hipLaunchKernelGGL((hadi_pass_a_strip<8, false>), g, b, pl.smem_as, q, ar, nstep); break;
+                        case 17: hipLaunchKernelGGL((hadi_pass_a_strip<8, true>), g, b, pl.smem_as, q, ar, nstep); break;
+                        case 8: hipLaunchKernelGGL((hadi_pass_a_strip<4, false>), g, b, pl.smem_as, q, ar, nstep); break;
+                        case 9: hipLaunchKernelGGL((hadi_pass_a_strip<4, true>), g, b, pl.smem_as, q, ar, nstep); break;
+                        case 4: hipLaunchKernelGGL((hadi_pass_a_strip<2, false>), g, b, pl.smem_as, q, ar, nstep); break;
+                        default: hipLaunchKernelGGL((hadi_pass_a_strip<2, true>), g, b, pl.smem_as, q, ar, nstep); break;
+                    }
                     return;
                 }
                 switch (L.B * 10 + L.G) {
@@ -362,7 +373,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     {
         char buf[256];
         char rowk[96];
-        if (pl.use_strip && !cs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,%s> (strips of %d rows)", american ? "AM" : "EU", pl.RS);
+        if (pl.use_strip && !cs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<%d,%s> (strips of %d rows)", L.B, american ? "AM" : "EU", pl.RS);
         else std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,%s%s> (tiles of %d rows)", L.B, L.G, pl.W, pl.NG, pl.PD,
                            american ? "AM" : "EU", cs ? ",CS" : "", pl.R);
         std::snprintf(buf, sizeof buf, "row pass %s; column pass %s<%d,%s> (%d chunks of %d rows, %d column tiles per block)", rowk,

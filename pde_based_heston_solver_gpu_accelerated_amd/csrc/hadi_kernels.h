@@ -966,7 +966,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtx &c, int j, con
 
 // LDS: [8 wavefronts][4 ring slots][rowp] + the 4 s-coefficient arrays.  Grid = n_inst * sblocks blocks of 8 strips.
 template <int B, bool AMER>
-__global__ void __launch_bounds__(512, 2) hadi_pass_a_strip(HadiSweepArgs a, int n) {
+__global__ void __launch_bounds__(512, (B >= 4 ? 2 : 4)) hadi_pass_a_strip(HadiSweepArgs a, int n) {
     HADI_DYN_SMEM(double, smem);
     constexpr int NS = 4, NWV = 8, c0slot = 64 * B;
     const int lane = threadIdx.x & 63;

@@ -11,7 +11,7 @@ struct HadiPlan {
     int R, ntiles;       // pass A: v-rows per block tile, tiles per instance
     int grid_a;          // pass A grid (64*W-thread blocks), padded to a multiple of 8 for the XCD remap
     size_t smem_a;       // pass A dynamic LDS bytes: NG rings of (PD+1)W+4 rows + the 4 s-coefficient arrays + tables
-    // strip row pass (hadi_pass_a_strip; 8 nodes per lane, one wavefront per row): v-rows per wavefront strip,
+    // strip row pass (hadi_pass_a_strip; 2, 4 or 8 nodes per lane, one wavefront per row): v-rows per wavefront strip,
     // 8-strip blocks per instance, grid, LDS bytes; use_strip = 0 keeps the shared-ring kernel
     int use_strip, RS, sblocks, grid_as;
     size_t smem_as;
@@ -71,7 +71,7 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
     // Strip row pass: every wavefront walks down RS consecutive v-rows alone.  Strips shorter than 16 rows re-read too
     // many halo rows (4 per strip), so small batches stay on the shared-ring kernel.
     p.use_strip = 0; p.RS = 0; p.sblocks = 0; p.grid_as = 0; p.smem_as = 0;
-    if (L.B == 8 && L.G == 1) {
+    if (L.B >= 2 && L.G == 1) {
         long long rs0 = ((long long)L.nrows * n_inst + target_waves - 1) / target_waves;
         if (rs0 < 16) rs0 = 16;
         if (rs0 > 64) rs0 = 64;
@@ -80,7 +80,10 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
         p.RS = (L.nrows + 8 * p.sblocks - 1) / (8 * p.sblocks);
         p.grid_as = (int)(((long long)n_inst * p.sblocks + 7) / 8 * 8);
         p.smem_as = ((size_t)8 * 4 * L.rowp + (size_t)4 * 64 * L.B) * sizeof(double);
-        p.use_strip = (p.RS >= 16 && p.RS <= 64) ? 1 : 0;
+        // Chosen automatically at 8 nodes per lane only: measured on MI355X, 512x256 x256: 0.156 -> 0.141 ms/launch; at 4
+        // nodes per lane (256x128 x1024) the shared-ring kernel, which fits four wavefronts per SIMD there, stays
+        // ahead (0.190 vs 0.203 ms).  HADI_TUNE_STRIP=1 forces strips for 2 and 4 nodes per lane too (tests).
+        p.use_strip = (L.B == 8 && p.RS >= 16 && p.RS <= 64) ? 1 : 0;
         if (const char *e = getenv("HADI_TUNE_STRIP")) p.use_strip = (atoi(e) && p.RS >= 1 && p.RS <= 64) ? 1 : 0;
     }
     p.ctiles = (L.rowp + 63) / 64;

@@ -23,8 +23,14 @@ static void run_pass_a(const HadiPlan &pl, const HadiSweepArgs &a, int n, int mo
 
 static int run_row_pass(const HadiPlan &pl, const HadiSweepArgs &a, int n, int mode) {
     if (pl.use_strip && mode == 0) {  // same choice as hadi_api.hip
-        if (a.american) emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<8, true>(a, n); }, pl.smem_as);
-        else emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<8, false>(a, n); }, pl.smem_as);
+        switch (pl.L.B * 2 + (a.american ? 1 : 0)) {
+            case 16: emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<8, false>(a, n); }, pl.smem_as); break;
+            case 17: emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<8, true>(a, n); }, pl.smem_as); break;
+            case 8: emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<4, false>(a, n); }, pl.smem_as); break;
+            case 9: emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<4, true>(a, n); }, pl.smem_as); break;
+            case 4: emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<2, false>(a, n); }, pl.smem_as); break;
+            default: emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<2, true>(a, n); }, pl.smem_as); break;
+        }
         return 0;
     }
     switch (pl.L.B * 10 + pl.L.G) {

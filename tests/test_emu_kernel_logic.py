@@ -86,6 +86,9 @@ def test_strip_row_pass(emu, monkeypatch):
     monkeypatch.setenv("HADI_TUNE_STRIP", "1")
     _run(emu, 280, 40, 3, [95.0], O.AM, 1)
     _run(emu, 512, 20, 2, [104.0], O.EU, 1)
+    # 4 and 2 nodes per lane
+    _run(emu, 200, 60, 3, [100.0], O.AM_DIV, 1, r_f=0.01)
+    _run(emu, 100, 70, 2, [100.0, 92.0], O.EU, 1)
 
 
 def test_two_waves_per_row_split_solve(emu):

@@ -484,9 +484,10 @@ def test_multi_maturity_calibration_drivers_vs_oracle_driven_loop(solver):
 
 
 @pytest.mark.parametrize("variant,name", [(H.EU, "EU"), (H.AM, "AM"), (H.AM_DIV, "AM_DIV")])
-@pytest.mark.parametrize("m1,m2,N,n", [(512, 256, 8, 2), (300, 140, 5, 1), (260, 200, 4, 3), (400, 33, 6, 2)])
+@pytest.mark.parametrize("m1,m2,N,n", [(512, 256, 8, 2), (300, 140, 5, 1), (260, 200, 4, 3), (400, 33, 6, 2),
+                                      (256, 128, 6, 2), (200, 100, 5, 2), (100, 50, 4, 3)])
 def test_strip_row_pass_vs_oracle(solver, monkeypatch, variant, name, m1, m2, N, n):
-    """The barrier-free strip row pass (8 nodes per lane) is only chosen for large batches; force it on small ones so
+    """The barrier-free strip row pass (2, 4 or 8 nodes per lane) is only chosen for large batches; force it on small ones so
     that every strip geometry (short strips, ragged last strip, one block or several per instance) meets the oracle."""
     monkeypatch.setenv("HADI_TUNE_STRIP", "1")
     strikes = Cm.strikes_for(n)
