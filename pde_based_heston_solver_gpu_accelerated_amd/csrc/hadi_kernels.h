@@ -1096,7 +1096,7 @@ struct HadiPassBCtx {
     HadiBuf Yb, Ub;     // the same two as buffer resources (uniform)
     double *Li;         // instance base of lambda_bar (American)
     const double *P0i;  // instance base of the payoff (American)
-    const double *pb;   // this chunk's table in LDS
+    double tab[5];      // this chunk's table (33 rows x 9 scalars) spread over the lanes: lane l holds entries l + 64 q
     const double *Ri;   // this wavefront's four rows of the reduced inverse in LDS, [4P][4]: for column m the
                         // coefficients of (left-neighbour last two, right-neighbour first two)
     double *zsh;        // LDS exchange, 2 buffers of P*4*64
@@ -1104,6 +1104,31 @@ struct HadiPassBCtx {
     double dt;
     HADI_STAMP_ACC
 };
+
+// Scalar m of chunk row k of the column-pass table.  The table is identical for all 64 columns; reading it from LDS costs
+// a full-width LDS return per row and phase (a broadcast ds_read_b128 still moves 1 KiB to the VGPRs): ~280 reads per
+// tile and wavefront, which kept the LDS pipe of the CU busy for a third of the tile time.  Spread over the lanes of 5
+// register pairs and fetched with v_readlane (static lane index, result in SGPRs, used as an FMA operand) it costs
+// only VALU slots, of which this kernel has plenty.
+#if defined(HADI_EMU)  // same register / lane mapping, read from the image the lanes published after loading the table
+#define HADI_PB_T(c, k, m) (emu::t_wave->pub[((k) * 9 + (m)) >> 6][((k) * 9 + (m)) & 63])
+#else
+#define HADI_PB_T(c, k, m) hadi_read_lane((c).tab[((k) * 9 + (m)) >> 6], ((k) * 9 + (m)) & 63)
+#endif
+
+HADI_DEV HADI_FORCEINLINE void hadi_pb_load_table(HadiPassBCtx &c, const double *__restrict__ pbg) {
+    static_assert(HADI_LC * 9 <= 5 * 64, "table does not fit 5 registers per lane");
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        const int e = c.lane + 64 * q;
+        const int k = e / 9, m = e - k * 9;
+        c.tab[q] = (k < HADI_LC) ? pbg[(size_t)k * HADI_PBW + m] : 0.0;
+#if defined(HADI_EMU)
+        emu::t_wave->pub[q][c.lane] = c.tab[q];
+#endif
+    }
+    hadi_wave_rendezvous();
+}
 
 HADI_DEV HADI_FORCEINLINE void hadi_pb_load(const HadiPassBCtx &c, int ctile, double (&y)[HADI_LC]) {
     const int col = ctile * 64 + c.lane;
@@ -1116,7 +1141,6 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_load(const HadiPassBCtx &c, int ctile, do
 
 // Chunk-local solve + interface exchange + spike correction of one 64-column tile held in y (no memory traffic).
 HADI_DEV HADI_FORCEINLINE void hadi_pb_solve(const HadiPassBCtx &c, int parity, double (&y)[HADI_LC], int younger = 0) {
-    const double *__restrict__ pb = c.pb;
     HADI_STAMP_DECL(c.stamp_acc_)
     HADI_STAMPB_WAIT(younger);
     HADI_STAMPB(16);  // this tile's loads have landed
@@ -1125,8 +1149,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve(const HadiPassBCtx &c, int parity, 
         double ym1 = 0.0, ym2 = 0.0;
 #pragma unroll
         for (int k = 0; k < HADI_LC; k++) {
-            const double *__restrict__ t = pb + (size_t)k * HADI_PBW;
-            const double yk = (y[k] - t[PB_L] * ym1 - t[PB_L2] * ym2) * t[PB_Q];
+            const double yk = (y[k] - HADI_PB_T(c, k, PB_L) * ym1 - HADI_PB_T(c, k, PB_L2) * ym2) * HADI_PB_T(c, k, PB_Q);
             y[k] = yk;
             ym2 = ym1;
             ym1 = yk;
@@ -1138,8 +1161,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve(const HadiPassBCtx &c, int parity, 
         double xp1 = 0.0, xp2 = 0.0;
 #pragma unroll
         for (int k = HADI_LC - 1; k >= 0; k--) {
-            const double *__restrict__ t = pb + (size_t)k * HADI_PBW;
-            const double xk = y[k] - t[PB_C] * xp1 - t[PB_C2] * xp2;
+            const double xk = y[k] - HADI_PB_T(c, k, PB_C) * xp1 - HADI_PB_T(c, k, PB_C2) * xp2;
             y[k] = xk;
             xp2 = xp1;
             xp1 = xk;
@@ -1174,8 +1196,8 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve(const HadiPassBCtx &c, int parity, 
         // spikes are zero where there is no neighbour (first chunk: V = 0, last chunk: W = 0)
 #pragma unroll
         for (int k = 0; k < HADI_LC; k++) {
-            const double *__restrict__ t = pb + (size_t)k * HADI_PBW;
-            y[k] = y[k] - t[PB_V0] * tl0 - t[PB_V1] * tl1 - t[PB_W0] * tr0 - t[PB_W1] * tr1;
+            y[k] = y[k] - HADI_PB_T(c, k, PB_V0) * tl0 - HADI_PB_T(c, k, PB_V1) * tl1 - HADI_PB_T(c, k, PB_W0) * tr0 -
+                   HADI_PB_T(c, k, PB_W1) * tr1;
         }
     }
     HADI_STAMPB(21);  // spike correction
@@ -1241,8 +1263,8 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ct
     hadi_pb_store<AMER, false>(c, ctile, y);
 }
 
-// Dynamic LDS: P * (2*4*64 + HADI_LC*HADI_PBW + 16*P) doubles (two interface-exchange buffers, the chunk tables,
-// each wavefront's four rows of the reduced inverse).
+// Dynamic LDS: P * (2*4*64 + 16*P) doubles (two interface-exchange buffers, each wavefront's four rows of the reduced
+// inverse); the chunk tables live in registers (HADI_PB_T).
 // MAXP only sets the launch bound (register budget): 8 -> 512 threads, 16 -> 1024 threads.
 template <int MAXP, bool AMER>
 __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n) {
@@ -1280,18 +1302,14 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
 #endif
     double ya[HADI_LC], yb[HADI_LC];
     hadi_pb_load(c, t0, ya);
-    // the chunk's table (HADI_LC x HADI_PBW doubles, identical for every column) goes through LDS once per
-    // block: coalesced load, then every use is a conflict-free broadcast read with a compile-time offset
+    // the chunk's table (identical for every column) is spread over the lanes' registers once per block
     {
-        const double *__restrict__ pbg = a.pb + ((size_t)inst * nrows + c.ja) * HADI_PBW;
-        double *__restrict__ tw = tsh + c.wave * (HADI_LC * HADI_PBW);
-        for (int e = c.lane; e < HADI_LC * HADI_PBW; e += 64) tw[e] = pbg[e];
-        c.pb = tw;
+        hadi_pb_load_table(c, a.pb + ((size_t)inst * nrows + c.ja) * HADI_PBW);
         // t = Rinv z needs, for this chunk, the rows of the previous chunk's last two and the next chunk's first two
         // unknowns (spikes are zero where there is no neighbour, so any row will do there)
         const int n4 = 4 * c.P;
         const double *__restrict__ Rg = a.rinv + (size_t)inst * 16 * c.P * c.P;
-        double *__restrict__ rw = tsh + (size_t)c.P * (HADI_LC * HADI_PBW) + (size_t)c.wave * 4 * n4;
+        double *__restrict__ rw = tsh + (size_t)c.wave * 4 * n4;
         const int rl0 = (c.wave > 0) ? 4 * (c.wave - 1) + 2 : 0, rr0 = (c.wave < c.P - 1) ? 4 * (c.wave + 1) : 0;
         for (int e = c.lane; e < 4 * n4; e += 64) {
             const int m = e >> 2, q = e & 3;
@@ -1354,18 +1372,14 @@ __global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, in
 #endif
     double y[HADI_LC];
     hadi_pb_load(c, t0, y);
-    // the chunk's table (HADI_LC x HADI_PBW doubles, identical for every column) goes through LDS once per
-    // block: coalesced load, then every use is a conflict-free broadcast read with a compile-time offset
+    // the chunk's table (identical for every column) is spread over the lanes' registers once per block
     {
-        const double *__restrict__ pbg = a.pb + ((size_t)inst * nrows + c.ja) * HADI_PBW;
-        double *__restrict__ tw = tsh + c.wave * (HADI_LC * HADI_PBW);
-        for (int e = c.lane; e < HADI_LC * HADI_PBW; e += 64) tw[e] = pbg[e];
-        c.pb = tw;
+        hadi_pb_load_table(c, a.pb + ((size_t)inst * nrows + c.ja) * HADI_PBW);
         // t = Rinv z needs, for this chunk, the rows of the previous chunk's last two and the next chunk's first two
         // unknowns (spikes are zero where there is no neighbour, so any row will do there)
         const int n4 = 4 * c.P;
         const double *__restrict__ Rg = a.rinv + (size_t)inst * 16 * c.P * c.P;
-        double *__restrict__ rw = tsh + (size_t)c.P * (HADI_LC * HADI_PBW) + (size_t)c.wave * 4 * n4;
+        double *__restrict__ rw = tsh + (size_t)c.wave * 4 * n4;
         const int rl0 = (c.wave > 0) ? 4 * (c.wave - 1) + 2 : 0, rr0 = (c.wave < c.P - 1) ? 4 * (c.wave + 1) : 0;
         for (int e = c.lane; e < 4 * n4; e += 64) {
             const int m = e >> 2, q = e & 3;

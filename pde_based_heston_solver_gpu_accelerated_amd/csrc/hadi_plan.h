@@ -101,8 +101,8 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
     }
     p.grid_b = n_inst * p.bgroups;
     p.block_b = 64 * L.P;
-    // two interface-exchange buffers + the chunk tables + each wavefront's four rows of the reduced inverse
-    p.smem_b = (size_t)L.P * (2 * 4 * 64 + HADI_LC * HADI_PBW + 16 * L.P) * sizeof(double);
+    // two interface-exchange buffers + each wavefront's four rows of the reduced inverse
+    p.smem_b = (size_t)L.P * (2 * 4 * 64 + 16 * L.P) * sizeof(double);
     p.pos_m1 = hadi_pos(L, m1);
     p.n_scoef = (size_t)4 * 64 * L.B * L.G;
     p.n_b2row = (size_t)L.rowp;

@@ -38,6 +38,7 @@ namespace emu {
 struct WaveState {
     pthread_barrier_t bar;
     double slot[64];
+    double pub[8][64];  // register images published once (hadi_pb_load_table) so that static readlanes need no rendezvous
 };
 struct BlockState {
     pthread_barrier_t bar;
