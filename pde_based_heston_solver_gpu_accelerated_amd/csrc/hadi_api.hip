@@ -48,6 +48,7 @@ struct Ctx {
     int use_small = 1;  // LDS-resident one-launch path for small grids
     std::string last_path;  // which kernels the last sweep ran (hadi_describe_last_sweep)
     DevBuf div_flag, div_amt, div_pct;
+    DevBuf pay_mis;  // American: per-instance payoff-shape flags (hadi_payoff_shape_kernel)
 };
 
 int fail(Ctx *c, int code, const char *fmt, ...) {
@@ -255,6 +256,9 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         hipLaunchKernelGGL(hadi_pack_kernel, dim3(grid1d(tot)), dim3(256), 0, s, L, d.n, d.n_src,
                            d.d_natU0 ? d.d_natU0 : d.d_natU, ptr<double>(c->U0));
         HIP_TRY(c, hipMemsetAsync(c->LAM.p, 0, st, s));  // lambda_bar <- 0, device_solver.hpp:310-313
+        if ((rc = ensure(c, c->pay_mis, sizeof(int) * n))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->pay_mis.p, 0, sizeof(int) * n, s));
+        hipLaunchKernelGGL(hadi_payoff_shape_kernel, dim3(grid1d(tot)), dim3(256), 0, s, L, d.n, ptr<double>(c->U0), ptr<int>(c->pay_mis));
     }
     HIP_TRY(c, hipGetLastError());
 
@@ -262,6 +266,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     a.U = ptr<double>(c->U); a.Y = ptr<double>(c->Y);
     a.LAM = american ? ptr<double>(c->LAM) : nullptr;
     a.U0 = american ? ptr<double>(c->U0) : nullptr;
+    a.pay_mis = american ? ptr<int>(c->pay_mis) : nullptr;
     a.scoef = ptr<double>(c->scoef); a.b2row = ptr<double>(c->b2row); a.rowc = ptr<double>(c->rowc);
     a.pb = ptr<double>(c->pb); a.rinv = ptr<double>(c->rinv); a.ipar = ptr<HadiInstPar>(c->ipar);
     a.L = L; a.n_inst = d.n; a.R = pl.R; a.ntiles = pl.ntiles; a.ctiles = pl.ctiles; a.btpw = pl.btpw; a.bgroups = pl.bgroups;
@@ -389,7 +394,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         std::string key;
         auto put = [&](const void *p_, size_t nbytes) { key.append(static_cast<const char *>(p_), nbytes); };
         {  // field by field: struct padding is not initialised
-            const void *ptrs[] = {a.U, a.Y, a.LAM, a.U0, a.scoef, a.b2row, a.rowc, a.pb, a.rinv, a.ipar, a.R1, a.C2, av.U};
+            const void *ptrs[] = {a.pay_mis, a.U, a.Y, a.LAM, a.U0, a.scoef, a.b2row, a.rowc, a.pb, a.rinv, a.ipar, a.R1, a.C2, av.U};
             const int ints[] = {a.L.m1, a.L.m2, a.L.B, a.L.G, a.L.P, a.n_inst, a.R, a.ntiles, a.ctiles, a.btpw, a.bgroups,
                                 a.american, a.pos_m1, d.scheme, pl.use_strip, pl.RS, pl.sblocks, pl.grid_as, pl.grid_a, pl.grid_b, pl.block_b, pl.W, (int)pl.smem_a, (int)pl.smem_b};
             put(ptrs, sizeof(ptrs));

@@ -31,6 +31,7 @@ struct HadiSweepArgs {
     double *LAM;       // lambda_bar (American) or nullptr
     double *R1, *C2;   // Craig-Sneyd only: predictor quantities reused by the corrector (see hadi_row_step)
     const double *U0;  // payoff (American) or nullptr
+    const int *pay_mis;  // American: per instance, != 0 if the payoff differs between v-rows (0 = it depends on s only)
     // tables
     const double *scoef, *b2row, *rowc, *pb, *rinv;
     const HadiInstPar *ipar;
@@ -1096,6 +1097,7 @@ struct HadiPassBCtx {
     HadiBuf Yb, Ub;     // the same two as buffer resources (uniform)
     double *Li;         // instance base of lambda_bar (American)
     const double *P0i;  // instance base of the payoff (American)
+    int pay1d;          // the payoff does not depend on v: one load per column instead of one per node
     double tab[5];      // this chunk's table (33 rows x 9 scalars) spread over the lanes: lane l holds entries l + 64 q
     const double *Ri;   // this wavefront's four rows of the reduced inverse in LDS, [4P][4]: for column m the
                         // coefficients of (left-neighbour last two, right-neighbour first two)
@@ -1231,18 +1233,26 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_store(const HadiPassBCtx &c, int ctile, d
         }
     } else {
         const unsigned row0 = (unsigned)c.ja * (unsigned)c.rowp * 8u, rstride = (unsigned)c.rowp * 8u;
-        // Ikonen-Toivanen projection, device_solver.hpp:358-372
+        // Ikonen-Toivanen projection, device_solver.hpp:358-372.  Plain pointer accesses on purpose: with raw buffer
+        // operations hipcc cannot tell that the lambda_bar load of row k+1 does not alias the store of row k, keeps them in
+        // program order and exposes one memory latency per row (measured 0.204 vs 0.179 ms/launch at 256x128 x512).
         double *__restrict__ dst = c.Ui + base;
         double *__restrict__ Lb = c.Li + base;
         const double *__restrict__ P0 = c.P0i + base;
         const double dt = c.dt;
         const bool is_smax = (col == c.pos_m1);
+        // A call / put payoff depends on s only (every driver of the reference builds U_0 that way,
+        // heston_calibration.cpp:183-192): then one load per column replaces 33 (8 of the 40 B per node of this pass).
+        // Identity padding rows then see the payoff instead of 0: their results are never read.
+        const bool pay1d = c.pay1d != 0;
+        const double pay_col = pay1d ? c.P0i[colc] : 0.0;
 #pragma unroll
         for (int k = 0; k < HADI_LC; k++) {
             const size_t off = (size_t)k * c.rowp;
             const double U_bar = y[k];
             const double lamv = Lb[off];
-            const double pay = P0[off];
+            double pay = pay_col;
+            if (!pay1d) pay = P0[off];
             const double un = fmax(U_bar - dt * lamv, pay);
             double ln = fmax(0.0, lamv + (pay - U_bar) / dt);
             if (is_smax) ln = 0.0;
@@ -1290,6 +1300,7 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
     c.Ub = hadi_make_buf(c.Ui, (size_t)a.L.inst_stride * sizeof(double));
     c.Li = AMER ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
     c.P0i = AMER ? a.U0 + (size_t)inst * a.L.inst_stride : nullptr;
+    c.pay1d = AMER ? (a.pay_mis[inst] == 0) : 0;
     c.american = a.american;
     c.pos_m1 = a.pos_m1;
     c.dt = ip.dt;
@@ -1360,6 +1371,7 @@ __global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, in
     c.Ub = hadi_make_buf(c.Ui, (size_t)a.L.inst_stride * sizeof(double));
     c.Li = AMER ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
     c.P0i = AMER ? a.U0 + (size_t)inst * a.L.inst_stride : nullptr;
+    c.pay1d = AMER ? (a.pay_mis[inst] == 0) : 0;
     c.american = a.american;
     c.pos_m1 = a.pos_m1;
     c.dt = ip.dt;
@@ -1696,6 +1708,17 @@ __global__ void __launch_bounds__(256) hadi_dividend_kernel(HadiLayout L, int n_
             }
         }
         U[inst * L.inst_stride + (size_t)j * L.rowp + hadi_pos(L, i)] = out;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// American payoff shape: mis[inst] != 0 if any v-row of the packed payoff differs from its row 0 (mis is zeroed first).
+__global__ void __launch_bounds__(256) hadi_payoff_shape_kernel(HadiLayout L, int n_inst, const double *__restrict__ P0, int *__restrict__ mis) {
+    const size_t per = (size_t)L.nrows * L.rowp, total = (size_t)n_inst * per;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t inst = e / per, r = e - inst * per;
+        const size_t x = r % L.rowp;
+        if (P0[inst * L.inst_stride + r] != P0[inst * L.inst_stride + x]) mis[inst] = 1;
     }
 }
 

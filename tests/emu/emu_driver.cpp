@@ -102,6 +102,9 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
     a.scoef = scoef.data(); a.b2row = b2row.data(); a.rowc = rowc.data(); a.pb = pb.data(); a.rinv = rinv.data();
     a.ipar = ipar.data(); a.L = L; a.n_inst = n_inst; a.R = pl.R; a.ntiles = pl.ntiles; a.ctiles = pl.ctiles; a.btpw = pl.btpw; a.bgroups = pl.bgroups;
     a.american = american; a.pos_m1 = pl.pos_m1; a.RS = pl.RS; a.sblocks = pl.sblocks;
+    std::vector<int> pay_mis(n_inst, 0);
+    a.pay_mis = american ? pay_mis.data() : nullptr;
+    if (american) emu::launch(8, 64, [&]() { hadi_payoff_shape_kernel(L, n_inst, dU0.data(), pay_mis.data()); });
     a.R1 = cs ? dR1.data() : nullptr; a.C2 = cs ? dC2.data() : nullptr;
     HadiSweepArgs av = a;
     if (cs) av.U = dV.data();

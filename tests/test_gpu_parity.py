@@ -91,6 +91,24 @@ def test_american_dividend_variants_vs_oracle(solver, variant, name, m1, m2, N, 
         assert np.abs(lam - lamo).max() <= 1e-8 * max(1.0, np.abs(lamo).max())
 
 
+@pytest.mark.parametrize("m1,m2,N,n", [(256, 128, 10, 3), (512, 256, 5, 2), (1024, 512, 3, 1), (50, 25, 10, 2)])
+def test_american_with_a_payoff_that_depends_on_v(solver, m1, m2, N, n):
+    """The column pass loads a payoff that depends on s only (every driver of the reference) once per column; a general
+    U_0 must take the per-node path and still match the oracle.  The same batch mixes both kinds of instance."""
+    strikes = Cm.strikes_for(n)
+    grids, U0 = _batch(m1, m2, strikes)
+    U0 = U0.reshape(n, m2 + 1, m1 + 1).copy()
+    U0[0] += 0.5 * grids.Vec_v[0][:, None] * (grids.Vec_s[0][None, :] > strikes[0])  # instance 0: v-dependent payoff
+    U0 = np.ascontiguousarray(U0.reshape(n, -1))
+    U, lam = U0.copy(), np.zeros_like(U0)
+    solver.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U,
+                           variant=H.AM, U_0=U0, lambda_bar=lam)
+    p = Cm.oracle_params(m1, m2, N, "AM")
+    Uo, lo, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0, want_lambda=True)
+    _assert_field(U, Uo)
+    assert np.abs(lam - lo).max() <= 1e-8 * max(1.0, np.abs(lo).max())
+
+
 @pytest.mark.parametrize("variant,name", [(H.EU, "EU"), (H.AM, "AM"), (H.DIV, "DIV"), (H.AM_DIV, "AM_DIV")])
 def test_small_grid_kernel_and_streaming_kernels_agree(solver, variant, name):
     """Grids that fit in LDS run through the one-launch LDS-resident kernel by default; the two-pass
