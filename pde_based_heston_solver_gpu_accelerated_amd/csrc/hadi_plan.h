@@ -83,7 +83,13 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
         // Chosen automatically at 8 nodes per lane only: measured on MI355X, 512x256 x256: 0.156 -> 0.141 ms/launch; at 4
         // nodes per lane (256x128 x1024) the shared-ring kernel, which fits four wavefronts per SIMD there, stays
         // ahead (0.190 vs 0.203 ms).  HADI_TUNE_STRIP=1 forces strips for 2 and 4 nodes per lane too (tests).
-        p.use_strip = (L.B == 8 && p.RS >= 16 && p.RS <= 64) ? 1 : 0;
+        // One strip block occupies a CU: the launch runs in ceil(blocks / CUs) rounds.  When the last round is mostly
+        // empty (e.g. 160 instances -> 320 blocks on 256 CUs) the shared-ring kernel, whose small blocks fill the tail,
+        // is faster (measured: 160 instances 0.142 ms with strips, ~0.127 ms with the ring).
+        const int cus = target_waves / 8 > 0 ? target_waves / 8 : 1;
+        const long long sblk = (long long)n_inst * p.sblocks;
+        const double fill = (double)sblk / (double)(((sblk + cus - 1) / cus) * cus);
+        p.use_strip = (L.B == 8 && p.RS >= 16 && p.RS <= 64 && fill >= 0.7) ? 1 : 0;
         if (const char *e = getenv("HADI_TUNE_STRIP")) p.use_strip = (atoi(e) && p.RS >= 1 && p.RS <= 64) ? 1 : 0;
     }
     p.ctiles = (L.rowp + 63) / 64;
@@ -93,6 +99,23 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
         const int want_blocks = (3 * target_waves) / 8;  // target_waves = 8 per CU
         int groups = (want_blocks + n_inst - 1) / n_inst;
         if (groups < 1) groups = 1;
+        if (groups > p.ctiles) groups = p.ctiles;
+        // One block per CU (two register buffers): the launch takes ceil(blocks / CUs) rounds of btpw tiles each.
+        // Keep the "about three blocks per CU" choice unless another split needs fewer tile-rounds (batch sizes that
+        // are not a multiple of the CU count); blocks of a single tile lose the double buffering (+30 % measured).
+        {
+            const int cus = target_waves / 8 > 0 ? target_waves / 8 : 1;
+            auto cost = [&](int g) {
+                const int tiles = (p.ctiles + g - 1) / g;
+                const int gg = (p.ctiles + tiles - 1) / tiles;
+                const long long rounds = ((long long)n_inst * gg + cus - 1) / cus;
+                return (double)rounds * (tiles + (tiles < 2 ? 0.6 : 0.0));
+            };
+            int best = groups;
+            for (int g = p.ctiles; g >= 1; g--)
+                if (cost(g) < cost(best) - 1e-9) best = g;
+            groups = best;
+        }
         if (const char *e = getenv("HADI_TUNE_BG")) groups = atoi(e);
         if (groups < 1) groups = 1;
         if (groups > p.ctiles) groups = p.ctiles;
