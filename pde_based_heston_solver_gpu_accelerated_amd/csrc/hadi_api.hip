@@ -780,7 +780,7 @@ int hadi_destroy(hadi_ctx *ctx) {
     DevBuf *bufs[] = {&c->U, &c->Y, &c->LAM, &c->U0, &c->UT, &c->scoef, &c->b2row, &c->rowc, &c->a2i, &c->pb,
                       &c->rinv, &c->rwork, &c->ipar, &c->par8, &c->g_s, &c->g_v, &c->g_ds, &c->g_dv, &c->src_v,
                       &c->src_dv, &c->sel_a, &c->sel_b, &c->v0_i, &c->natU, &c->natU0, &c->natOut, &c->prices,
-                      &c->status, &c->div_flag, &c->div_amt, &c->div_pct, &c->V, &c->R1, &c->C2};
+                      &c->status, &c->div_flag, &c->div_amt, &c->div_pct, &c->V, &c->R1, &c->C2, &c->pay_mis};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto &g : c->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
