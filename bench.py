@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--m1", type=int, default=512)
     ap.add_argument("--m2", type=int, default=256)
     ap.add_argument("--timesteps", type=int, default=1000)
+    ap.add_argument("--state", default="fp64", choices=["fp64", "fp32"],
+                    help="precision of the state between the two passes (fp32 = BASELINE config 5: half the traffic, fp64 arithmetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-single", action="store_true", help="skip the 1-instance latency run (profiling)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
@@ -56,6 +58,10 @@ def main():
     import __graft_entry__ as G
     G.build()
     import pde_based_heston_solver_gpu_accelerated_amd as H
+    global B_ALG_PASS, B_ALG_STEP
+    STATE = H.STATE_FP32 if args.state == "fp32" else H.STATE_FP64
+    if args.state == "fp32":  # 16 B per point-step with fp32 state
+        B_ALG_PASS, B_ALG_STEP = 8.0, 16.0
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -92,7 +98,8 @@ def main():
     def step():
         U.copy_(U0)  # workspace.U <- U_0 before every call (heston_calibration.cpp:216); D2D, part of the pass
         torch.cuda.synchronize()
-        solver.DO_timestepping(m1, m2, N, T / N, theta, r_d, r_f, rho, sigma, kappa, eta, grids, U)
+        solver.DO_timestepping(m1, m2, N, T / N, theta, r_d, r_f, rho, sigma, kappa, eta, grids, U,
+                               state_precision=STATE)
 
     def barrier():
         torch.cuda.synchronize()
@@ -202,7 +209,7 @@ def main():
             "metric": "grid-points x timesteps/sec (ADI sweep), %dx%d grid" % (m1, m2),
             "value": value, "unit": "point-steps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64" if args.state == "fp64" else "f32 state, f64 arithmetic", "data": "synthetic",
             "config": {"workload": "C2: European calls, Heston Douglas ADI, %dx%d grid, %d time steps, %d strikes per GPU "
                                    "(85..115), HBM-resident inputs" % (m1, m2, N, n_loc),
                        "m1": m1, "m2": m2, "timesteps": N, "instances_per_gpu": n_loc, "instances_total": n_glob,

@@ -68,6 +68,12 @@ enum hadi_memspace { HADI_MEM_HOST = 0, HADI_MEM_DEVICE = 1 };
  * exists in its host family (CS_scheme_shuffled, src/solver.hpp:781-907, European) and is offered here on the
  * device for the European variant. */
 enum hadi_scheme { HADI_SCHEME_DOUGLAS = 0, HADI_SCHEME_CRAIG_SNEYD = 1 };
+/* Precision of the state arrays BETWEEN the two directional passes.  FP64 is what the reference computes in.  FP32
+ * ("mixed-precision fp32 ADI sweep with fp64 tridiag pivots", BASELINE.json config 5): U and the A2 right-hand side are
+ * stored as fp32 in HBM (half the traffic: 16 B per point-step), every operator, pivot and line solve is still
+ * evaluated in fp64 in registers.  European Douglas sweeps only; the caller's arrays stay fp64.  Not a reference
+ * feature: parity is against the oracle run with the same two roundings per step (tests), ~1e-6 relative to fp64. */
+enum hadi_state_precision { HADI_STATE_FP64 = 0, HADI_STATE_FP32 = 1 };
 
 /* One batch of independent option instances = one league of teams in the reference
  * (TeamPolicy(nInstances, AUTO), device_solver.hpp:83-88). */
@@ -110,6 +116,8 @@ typedef struct hadi_problem {
     double *lambda_bar;
     /* enum hadi_scheme; 0 (Douglas) is what every reference launcher runs */
     int scheme;
+    /* enum hadi_state_precision; 0 (fp64) is what every reference launcher runs */
+    int state_precision;
 } hadi_problem;
 
 /* Timing of the last sweep on this handle, measured with HIP events on the handle's

@@ -479,6 +479,13 @@ static void timestepping(ho_ws *w, const ho_params *p, const double *vec_s,
     if (american)
         for (int i = 0; i < m; i++) lambda_bar[i] = 0;
 
+    /* fp32-state sweep (libhadi's HADI_STATE_FP32; not a reference feature): the state is rounded to float where the
+     * GPU stores it -- the initial U, the A2 right-hand side after the row pass, U after the column pass.  All
+     * arithmetic stays fp64. */
+    const int f32 = p->state_fp32;
+    if (f32)
+        for (int i = 0; i < m; i++) U[i] = (double)(float)U[i];
+
     for (int n = 1; n <= N; n++) {
         if (dividend) { /* device_solver.hpp:426-517 */
             const double t = n * delta_t;
@@ -516,7 +523,11 @@ static void timestepping(ho_ws *w, const ho_params *p, const double *vec_s,
         for (int i = 0; i < m; i++)
             w->Y1[i] = w->Y1[i] + theta * delta_t * (w->b2[i] * exp_factor_n - (w->A2U[i] + w->b2[i] * exp_factor_nm1));
         if (dump && dump->step == n && dump->Y1rhs) memcpy(dump->Y1rhs, w->Y1, sizeof(double) * m);
+        if (f32)
+            for (int i = 0; i < m; i++) w->Y1[i] = (double)(float)w->Y1[i];
         a2_solve(w, U, w->Y1);
+        if (f32)
+            for (int i = 0; i < m; i++) U[i] = (double)(float)U[i];
         if (american) { /* device_solver.hpp:358-372 */
             for (int i = 0; i < m; i++) {
                 const double U_bar = U[i];
@@ -536,6 +547,7 @@ int ho_solve(const ho_params *p, const double *vec_s, const double *vec_v,
              double *U, const double *U_0, double *lambda_bar, ho_dump *dump) {
     if (p->m1 < 2 || p->m2 < 3) return -1;
     if (p->scheme == 1 && p->variant != HO_EU) return -4; /* the reference has CS for European only */
+    if (p->state_fp32 && (p->variant != HO_EU || p->scheme != 0)) return -5;
     double *lam_own = NULL;
     if (variant_needs_payoff(p->variant)) {
         if (!U_0) return -2;

@@ -29,6 +29,8 @@ typedef struct ho_params {
     int num_dividends;
     const double *div_dates, *div_amounts, *div_percentages;
     int scheme; /* 0 = Douglas (device_solver.hpp), 1 = Craig-Sneyd (solver.hpp:781-907, European only) */
+    int state_fp32; /* 1 = round the state to float between the directional passes (checker for libhadi's fp32-state
+                     * sweep; NOT a reference feature, European Douglas only) */
 } ho_params;
 
 /* Optional capture of the intermediates of time step `step` (1-based); every

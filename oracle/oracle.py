@@ -25,6 +25,7 @@ class _Params(C.Structure):
         ("num_dividends", C.c_int),
         ("div_dates", _dp), ("div_amounts", _dp), ("div_percentages", _dp),
         ("scheme", C.c_int),
+        ("state_fp32", C.c_int),
     ]
 
 
@@ -62,12 +63,13 @@ def _f64(a):
 
 
 def make_params(m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, variant=EU,
-                dividends=None, scheme=0):
+                dividends=None, scheme=0, state_fp32=0):
     p = _Params()
     p.m1, p.m2, p.N, p.variant = m1, m2, N, variant
     p.delta_t, p.theta, p.r_d, p.r_f = delta_t, theta, r_d, r_f
     p.rho, p.sigma, p.kappa, p.eta = rho, sigma, kappa, eta
     p.scheme = scheme
+    p.state_fp32 = state_fp32
     keep = []
     if dividends is not None:
         dates, amounts, pcts = (_f64(x) for x in dividends)

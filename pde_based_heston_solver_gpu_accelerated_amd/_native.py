@@ -13,6 +13,7 @@ HADI_OK = 0
 EU, AM, DIV, AM_DIV = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
 SCHEME_DOUGLAS, SCHEME_CRAIG_SNEYD = 0, 1
+STATE_FP64, STATE_FP32 = 0, 1
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -38,6 +39,7 @@ class Problem(C.Structure):
         ("dividend_dates", _dp), ("dividend_amounts", _dp), ("dividend_percentages", _dp),
         ("U", _dp), ("U_0", _dp), ("lambda_bar", _dp),
         ("scheme", C.c_int),
+        ("state_precision", C.c_int),
     ]
 
 

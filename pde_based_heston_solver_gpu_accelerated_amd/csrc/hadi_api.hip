@@ -36,6 +36,7 @@ struct Ctx {
     // grow-only device buffers
     DevBuf U, Y, LAM, U0, UT;
     DevBuf V, R1, C2;                 // Craig-Sneyd: predictor result and carry-over arrays
+    DevBuf Uf, Yf;                    // fp32-state sweep: the two state arrays as float
     DevBuf scoef, b2row, rowc, a2i, pb, rinv, rwork, ipar, par8;
     DevBuf g_s, g_v, g_ds, g_dv;      // grids owned by the library (staged / broadcast)
     DevBuf src_v, src_dv, sel_a, sel_b, v0_i;
@@ -118,7 +119,7 @@ void build_v(int m2, double V_0, double V, double d, double *vec_v, double *delt
 // ---- one batched sweep ----------------------------------------------------------------------------
 struct SweepDesc {
     int n = 0;               // instances actually solved (6x the caller's for a Jacobian)
-    int m1 = 0, m2 = 0, variant = 0, scheme = 0;
+    int m1 = 0, m2 = 0, variant = 0, scheme = 0, prec = 0;
     double theta = 0, r_d = 0, r_f = 0;
     std::vector<double> par8;  // [n][8] rho sigma kappa eta dt N . .
     int Nmax = 0;
@@ -142,6 +143,14 @@ void launch_pass_a(const HadiPlan &pl, const HadiSweepArgs &a, int n, hipStream_
         hipLaunchKernelGGL((hadi_pass_a<B, G, 4, NG, PD, true>), dim3(pl.grid_a), dim3(64 * pl.W * G * NG), pl.smem_a, s, a, n);
     else
         hipLaunchKernelGGL((hadi_pass_a<B, G, 4, NG, PD, false>), dim3(pl.grid_a), dim3(64 * pl.W * G * NG), pl.smem_a, s, a, n);
+}
+
+// fp32-state row pass: same geometry, the LDS ring holds floats (the coefficient arrays and tables stay double)
+template <int B, int G, int NG, int PD>
+void launch_pass_a_f32(const HadiPlan &pl, const HadiSweepArgs &a, int n, hipStream_t s) {
+    const size_t ring_elems = (size_t)NG * ((PD + 1) * pl.W + 4) * pl.L.rowp;
+    const size_t smem = pl.smem_a - ring_elems * (sizeof(double) - sizeof(float));
+    hipLaunchKernelGGL((hadi_pass_a<B, G, 4, NG, PD, false, 0, float>), dim3(pl.grid_a), dim3(64 * pl.W * G * NG), smem, s, a, n);
 }
 
 // Kernels whose dynamic LDS can exceed the 64 KiB default need the limit raised once.
@@ -176,6 +185,13 @@ hipError_t raise_all_lds_limits() {
     if ((e = raise_lds_limit(hadi_pass_b<8, false>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b<8, true>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b1<16, false>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_b<8, false, float>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_b1<16, false, float>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<1, 1, 4, 1, 2, false, 0, float>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<2, 1, 4, 1, 2, false, 0, float>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<4, 1, 4, 1, 2, false, 0, float>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<8, 1, 4, 1, 1, false, 0, float>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<8, 2, 4, 1, 1, false, 0, float>)) != hipSuccess) return e;
     return raise_lds_limit(hadi_pass_b1<16, true>);
 }
 
@@ -197,6 +213,8 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     }
     if (dividend && (rc = ensure(c, c->UT, st))) return rc;
     const bool cs = d.scheme == HADI_SCHEME_CRAIG_SNEYD;
+    const bool f32 = d.prec == HADI_STATE_FP32;  // European Douglas only (validated)
+    if (f32 && ((rc = ensure(c, c->Uf, st / 2)) || (rc = ensure(c, c->Yf, st / 2)))) return rc;
     if (cs && ((rc = ensure(c, c->V, st)) || (rc = ensure(c, c->R1, st)) || (rc = ensure(c, c->C2, st)))) return rc;
     const size_t n = d.n;
     if ((rc = ensure(c, c->scoef, pl.n_scoef * n * 8))) return rc;
@@ -262,8 +280,16 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     }
     HIP_TRY(c, hipGetLastError());
 
+    if (f32) {  // round the packed state to fp32; Y's identity padding rows must read as zeros
+        hipLaunchKernelGGL(hadi_narrow_kernel, dim3(grid1d(tot)), dim3(256), 0, s, ptr<double>(c->U), ptr<float>(c->Uf), tot);
+        HIP_TRY(c, hipMemsetAsync(c->Yf.p, 0, st / 2, s));
+    }
     HadiSweepArgs a;
     a.U = ptr<double>(c->U); a.Y = ptr<double>(c->Y);
+    if (f32) {  // the kernels instantiated for float reinterpret these two
+        a.U = reinterpret_cast<double *>(c->Uf.p);
+        a.Y = reinterpret_cast<double *>(c->Yf.p);
+    }
     a.LAM = american ? ptr<double>(c->LAM) : nullptr;
     a.U0 = american ? ptr<double>(c->U0) : nullptr;
     a.pay_mis = american ? ptr<int>(c->pay_mis) : nullptr;
@@ -299,6 +325,16 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
             }
             if (prof) HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 0], q));
             auto row_pass = [&](const HadiSweepArgs &ar, int mode) {
+                if (f32) {  // fp32 state: shared-ring kernel for every shape
+                    switch (L.B * 10 + L.G) {
+                        case 11: launch_pass_a_f32<1, 1, 1, 2>(pl, ar, nstep, q); break;
+                        case 21: launch_pass_a_f32<2, 1, 1, 2>(pl, ar, nstep, q); break;
+                        case 41: launch_pass_a_f32<4, 1, 1, 2>(pl, ar, nstep, q); break;
+                        case 81: launch_pass_a_f32<8, 1, 1, 1>(pl, ar, nstep, q); break;
+                        default: launch_pass_a_f32<8, 2, 1, 1>(pl, ar, nstep, q); break;
+                    }
+                    return;
+                }
                 if (pl.use_strip && mode == 0) {  // barrier-free strips (Douglas step, one wavefront per row)
                     const dim3 g(pl.grid_as), b(512);
                     switch (L.B * 2 + (american ? 1 : 0)) {
@@ -324,6 +360,11 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                 // 1024-thread block leaves 128 VGPRs per lane, which only the single-buffer kernel fits
                 // (measured at 1024x512: 0.250 vs 0.382 ms/launch for the double-buffered code, which spills)
                 const dim3 g(pl.grid_b), b(pl.block_b);
+                if (f32) {
+                    if (L.P <= 8) hipLaunchKernelGGL((hadi_pass_b<8, false, float>), g, b, pl.smem_b, q, ar, nstep);
+                    else hipLaunchKernelGGL((hadi_pass_b1<16, false, float>), g, b, pl.smem_b, q, ar, nstep);
+                    return;
+                }
                 if (L.P <= 8) {
                     if (american) hipLaunchKernelGGL((hadi_pass_b<8, true>), g, b, pl.smem_b, q, ar, nstep);
                     else hipLaunchKernelGGL((hadi_pass_b<8, false>), g, b, pl.smem_b, q, ar, nstep);
@@ -349,7 +390,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
 
     // ---- small grids: the whole instance fits in LDS -> one launch runs the entire time loop ----------
     const size_t smem_small = american ? pl.smem_small_am : pl.smem_small_eu;
-    if (c->use_small && !prof && !cs && smem_small > 0) {
+    if (c->use_small && !prof && !cs && !f32 && smem_small > 0) {
         {
             char buf[160];
             std::snprintf(buf, sizeof buf, "hadi_small_kernel<%d,4,%s>: whole time loop in one launch, instance resident in LDS (%zu B)", L.B,
@@ -378,7 +419,8 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     {
         char buf[256];
         char rowk[96];
-        if (pl.use_strip && !cs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<%d,%s> (strips of %d rows)", L.B, american ? "AM" : "EU", pl.RS);
+        if (f32) std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,EU,float> (tiles of %d rows, fp32 state)", L.B, L.G, pl.W, pl.NG, pl.PD, pl.R);
+        else if (pl.use_strip && !cs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<%d,%s> (strips of %d rows)", L.B, american ? "AM" : "EU", pl.RS);
         else std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,%s%s> (tiles of %d rows)", L.B, L.G, pl.W, pl.NG, pl.PD,
                            american ? "AM" : "EU", cs ? ",CS" : "", pl.R);
         std::snprintf(buf, sizeof buf, "row pass %s; column pass %s<%d,%s> (%d chunks of %d rows, %d column tiles per block)", rowk,
@@ -396,7 +438,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         {  // field by field: struct padding is not initialised
             const void *ptrs[] = {a.pay_mis, a.U, a.Y, a.LAM, a.U0, a.scoef, a.b2row, a.rowc, a.pb, a.rinv, a.ipar, a.R1, a.C2, av.U};
             const int ints[] = {a.L.m1, a.L.m2, a.L.B, a.L.G, a.L.P, a.n_inst, a.R, a.ntiles, a.ctiles, a.btpw, a.bgroups,
-                                a.american, a.pos_m1, d.scheme, pl.use_strip, pl.RS, pl.sblocks, pl.grid_as, pl.grid_a, pl.grid_b, pl.block_b, pl.W, (int)pl.smem_a, (int)pl.smem_b};
+                                a.american, a.pos_m1, d.scheme, d.prec, pl.use_strip, pl.RS, pl.sblocks, pl.grid_as, pl.grid_a, pl.grid_b, pl.block_b, pl.W, (int)pl.smem_a, (int)pl.smem_b};
             put(ptrs, sizeof(ptrs));
             put(ints, sizeof(ints));
         }
@@ -441,6 +483,8 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
+    if (f32)  // back to the fp64 packed array the unpack / price-pick kernels read
+        hipLaunchKernelGGL(hadi_widen_kernel, dim3(grid1d(tot)), dim3(256), 0, s, ptr<float>(c->Uf), ptr<double>(c->U), tot);
     return HADI_OK;
 }
 
@@ -508,6 +552,10 @@ int check_problem(Ctx *c, const hadi_problem *p, bool need_U, bool need_vgrid) {
         return fail(c, HADI_ERR_INVALID, "bad scheme %d", p->scheme);
     if (p->scheme == HADI_SCHEME_CRAIG_SNEYD && p->variant != HADI_EU)
         return fail(c, HADI_ERR_UNSUPPORTED, "Craig-Sneyd is available for the European variant only (as in the reference)");
+    if (p->state_precision != HADI_STATE_FP64 && p->state_precision != HADI_STATE_FP32)
+        return fail(c, HADI_ERR_INVALID, "bad state_precision %d", p->state_precision);
+    if (p->state_precision == HADI_STATE_FP32 && (p->variant != HADI_EU || p->scheme != HADI_SCHEME_DOUGLAS))
+        return fail(c, HADI_ERR_UNSUPPORTED, "the fp32-state sweep covers European Douglas steps only");
     return HADI_OK;
 }
 
@@ -533,7 +581,7 @@ void fill_par(const hadi_problem *p, SweepDesc &d, int groups) {
 }
 
 void fill_common(const hadi_problem *p, SweepDesc &d) {
-    d.m1 = p->m1; d.m2 = p->m2; d.variant = p->variant; d.scheme = p->scheme;
+    d.m1 = p->m1; d.m2 = p->m2; d.variant = p->variant; d.scheme = p->scheme; d.prec = p->state_precision;
     d.theta = p->theta; d.r_d = p->r_d; d.r_f = p->r_f;
     const bool dividend = p->variant == HADI_DIV || p->variant == HADI_AM_DIV;
     d.num_div = dividend ? p->num_dividends : 0;
@@ -780,7 +828,7 @@ int hadi_destroy(hadi_ctx *ctx) {
     DevBuf *bufs[] = {&c->U, &c->Y, &c->LAM, &c->U0, &c->UT, &c->scoef, &c->b2row, &c->rowc, &c->a2i, &c->pb,
                       &c->rinv, &c->rwork, &c->ipar, &c->par8, &c->g_s, &c->g_v, &c->g_ds, &c->g_dv, &c->src_v,
                       &c->src_dv, &c->sel_a, &c->sel_b, &c->v0_i, &c->natU, &c->natU0, &c->natOut, &c->prices,
-                      &c->status, &c->div_flag, &c->div_amt, &c->div_pct, &c->V, &c->R1, &c->C2, &c->pay_mis};
+                      &c->status, &c->div_flag, &c->div_amt, &c->div_pct, &c->V, &c->R1, &c->C2, &c->pay_mis, &c->Uf, &c->Yf};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto &g : c->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }

@@ -131,14 +131,23 @@ __device__ unsigned long long g_hadi_stamps[32];
 // (raw buffer loads/stores take the row offset in an SGPR, so walking down a column costs no VALU
 // address arithmetic and no address VGPR pairs: cdna_hip_programming.md T8)
 #if defined(HADI_EMU)
-struct HadiBuf { const double *p; };
-HADI_DEV HADI_FORCEINLINE HadiBuf hadi_make_buf(const double *base, size_t) { return HadiBuf{base}; }
+struct HadiBuf { const void *p; };
+HADI_DEV HADI_FORCEINLINE HadiBuf hadi_make_buf(const void *base, size_t) { return HadiBuf{base}; }
 HADI_DEV HADI_FORCEINLINE double hadi_buf_load(HadiBuf b, unsigned voff_bytes, unsigned soff_bytes) {
-    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(b.p) + voff_bytes + soff_bytes);
+    return *reinterpret_cast<const double *>(static_cast<const char *>(b.p) + voff_bytes + soff_bytes);
 }
 HADI_DEV HADI_FORCEINLINE void hadi_buf_store(HadiBuf b, unsigned voff_bytes, unsigned soff_bytes, double v) {
     if (voff_bytes >= 0x80000000u) return;  // HADI_BUF_DROP: the hardware range check discards the lane's store
-    *reinterpret_cast<double *>(const_cast<char *>(reinterpret_cast<const char *>(b.p)) + voff_bytes + soff_bytes) = v;
+    *reinterpret_cast<double *>(const_cast<char *>(static_cast<const char *>(b.p)) + voff_bytes + soff_bytes) = v;
+}
+template <class T>
+HADI_DEV HADI_FORCEINLINE double hadi_buf_load_t(HadiBuf b, unsigned voff_bytes, unsigned soff_bytes) {
+    return (double)*reinterpret_cast<const T *>(static_cast<const char *>(b.p) + voff_bytes + soff_bytes);
+}
+template <class T>
+HADI_DEV HADI_FORCEINLINE void hadi_buf_store_t(HadiBuf b, unsigned voff_bytes, unsigned soff_bytes, double v) {
+    if (voff_bytes >= 0x80000000u) return;
+    *reinterpret_cast<T *>(const_cast<char *>(static_cast<const char *>(b.p)) + voff_bytes + soff_bytes) = (T)v;
 }
 #else
 typedef unsigned hadi_u32x2 __attribute__((ext_vector_type(2)));
@@ -149,8 +158,8 @@ typedef unsigned hadi_u32x2 __attribute__((ext_vector_type(2)));
 // plain ping-pong copy (512 MB working set: 5.4 -> 7.3 TB/s).
 #define HADI_AUX_NT 2
 struct HadiBuf { __amdgpu_buffer_rsrc_t r; };
-HADI_DEV HADI_FORCEINLINE HadiBuf hadi_make_buf(const double *base, size_t bytes) {
-    return HadiBuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base), 0, (int)bytes, 0x00020000)};
+HADI_DEV HADI_FORCEINLINE HadiBuf hadi_make_buf(const void *base, size_t bytes) {
+    return HadiBuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000)};
 }
 HADI_DEV HADI_FORCEINLINE double hadi_buf_load(HadiBuf b, unsigned voff_bytes, unsigned soff_bytes) {
     const hadi_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(b.r, voff_bytes, soff_bytes, HADI_AUX_NT);
@@ -161,6 +170,26 @@ HADI_DEV HADI_FORCEINLINE void hadi_buf_store(HadiBuf b, unsigned voff_bytes, un
     d.x = (unsigned)__double2loint(v);
     d.y = (unsigned)__double2hiint(v);
     __builtin_amdgcn_raw_buffer_store_b64(d, b.r, voff_bytes, soff_bytes, HADI_AUX_NT);
+}
+#endif
+
+#if !defined(HADI_EMU)
+// element type T of the state: double, or float for the fp32-state sweep (widened on load, rounded on store)
+template <class T>
+HADI_DEV HADI_FORCEINLINE double hadi_buf_load_t(HadiBuf b, unsigned voff_bytes, unsigned soff_bytes) {
+    if constexpr (sizeof(T) == 8) {
+        return hadi_buf_load(b, voff_bytes, soff_bytes);
+    } else {
+        return (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, voff_bytes, soff_bytes, HADI_AUX_NT));
+    }
+}
+template <class T>
+HADI_DEV HADI_FORCEINLINE void hadi_buf_store_t(HadiBuf b, unsigned voff_bytes, unsigned soff_bytes, double v) {
+    if constexpr (sizeof(T) == 8) {
+        hadi_buf_store(b, voff_bytes, soff_bytes, v);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), b.r, voff_bytes, soff_bytes, HADI_AUX_NT);
+    }
 }
 #endif
 
@@ -239,20 +268,22 @@ HADI_DEV HADI_FORCEINLINE void hadi_wave_rendezvous() {
 // (it cannot know the ring slots differ), which serialises the prefetch with the row it should overlap.
 // The asm form is invisible to that bookkeeping, so completion is OUR job: hadi_dma_wait() + barrier
 // before anyone reads the rows (cdna_hip_programming.md 5.7).  Rows outside the allocation are zeros.
-HADI_DEV HADI_FORCEINLINE void hadi_row_to_lds(const double *__restrict__ grow, double *lrow, int rowp, int lane,
-                                               bool exists) {
-    const int nvec = rowp >> 1;  // 16-byte vectors per row
+// T = double, or float for the fp32-state sweep (state stored as fp32, all arithmetic fp64): the row is copied as raw
+// bytes either way, rowp * sizeof(T) is a multiple of 32.
+template <class T>
+HADI_DEV HADI_FORCEINLINE void hadi_row_to_lds(const T *__restrict__ grow, T *lrow, int rowp, int lane, bool exists) {
+    constexpr int EPV = 16 / (int)sizeof(T);  // elements per 16-byte vector
+    const int nvec = rowp / EPV;
     if (exists) {
         for (int v0 = 0; v0 < nvec; v0 += 64) {
             if (v0 + lane < nvec) {
 #if defined(HADI_EMU)
-                lrow[2 * (v0 + lane)] = grow[2 * (v0 + lane)];
-                lrow[2 * (v0 + lane) + 1] = grow[2 * (v0 + lane) + 1];
+                for (int e = 0; e < EPV; e++) lrow[EPV * (v0 + lane) + e] = grow[EPV * (v0 + lane) + e];
 #else
-                const double *gsrc = grow + 2 * (v0 + lane);
+                const T *gsrc = grow + EPV * (v0 + lane);
                 // wave-uniform LDS byte address of this 1 KiB piece; the hardware adds lane*16
                 const unsigned lds_dst = __builtin_amdgcn_readfirstlane(
-                    (unsigned)(size_t)(__attribute__((address_space(3))) char *)(lrow + 2 * v0));
+                    (unsigned)(size_t)(__attribute__((address_space(3))) char *)(lrow + EPV * v0));
                 unsigned keep;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" HADI_DMA_POLICY "\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep)
@@ -262,11 +293,14 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_to_lds(const double *__restrict__ grow, 
             }
         }
     } else {
-        for (int v = lane; v < nvec; v += 64) {
-            lrow[2 * v] = 0.0;
-            lrow[2 * v + 1] = 0.0;
-        }
+        for (int v = lane; v < nvec; v += 64)
+            for (int e = 0; e < EPV; e++) lrow[EPV * v + e] = (T)0;
     }
+}
+// number of vector-memory instructions hadi_row_to_lds issues for an existing row
+template <class T>
+HADI_DEV HADI_FORCEINLINE int hadi_row_dma_count(int rowp) {
+    return (rowp / (16 / (int)sizeof(T)) + 63) / 64;
 }
 
 template <int B>
@@ -291,10 +325,11 @@ HADI_DEV HADI_FORCEINLINE void hadi_lds_row(const double *lrow, int lane, double
 // unknown boundary value (a second right-hand side carried through the cyclic reduction) and the two
 // boundary values follow from a 2x2 system exchanged through LDS -- small per-lane state (B = 4 at
 // m1 = 512) is what lets four wavefronts share a SIMD.
-struct HadiRowCtx {
+template <class T>
+struct HadiRowCtxT {
     const double *coef;  // LDS: Bm, Bp, Dm, Dp, each 64*B*G doubles in row layout
     double *xch;         // LDS: [W][4] boundary exchange between the two waves of a row (G = 2)
-    double *Yi;          // instance base of Y
+    T *Yi;               // instance base of Y (T = float: fp32-state sweep)
     const double *Li;    // instance base of lambda_bar (American)
     const double *rowc;  // LDS copy of the row table of this block's tile: entry (j - j0)
     int j0;              // first v-row of the tile
@@ -304,32 +339,38 @@ struct HadiRowCtx {
     double dt, thdt, qd, half_rd, e_nm1, e_n;
     HADI_STAMP_ACC
 };
+typedef HadiRowCtxT<double> HadiRowCtx;
 
 // Loads this lane's B values of a row-layout array (LDS or global): pair q at q*128*G + 128*half + 2*lane.
-template <int B, int G>
-HADI_DEV HADI_FORCEINLINE void hadi_get_block(const double *row, int half, int lane, double (&u)[B]) {
+// T = double (16-byte pairs) or float (fp32 state: 8-byte pairs, widened on load / rounded on store).
+template <class T> struct HadiPair;
+template <> struct HadiPair<double> { typedef double2 type; };
+template <> struct HadiPair<float> { typedef float2 type; };
+template <int B, int G, class T = double>
+HADI_DEV HADI_FORCEINLINE void hadi_get_block(const T *row, int half, int lane, double (&u)[B]) {
     if constexpr (B == 1) {
-        u[0] = row[64 * half + lane];
+        u[0] = (double)row[64 * half + lane];
     } else {
 #pragma unroll
         for (int q = 0; q < B / 2; q++) {
-            const double2 t = *reinterpret_cast<const double2 *>(row + q * 128 * G + 128 * half + 2 * lane);
-            u[2 * q] = t.x;
-            u[2 * q + 1] = t.y;
+            const typename HadiPair<T>::type t =
+                *reinterpret_cast<const typename HadiPair<T>::type *>(row + q * 128 * G + 128 * half + 2 * lane);
+            u[2 * q] = (double)t.x;
+            u[2 * q + 1] = (double)t.y;
         }
     }
 }
-template <int B, int G>
-HADI_DEV HADI_FORCEINLINE void hadi_put_block(double *row, int half, int lane, const double (&u)[B]) {
+template <int B, int G, class T = double>
+HADI_DEV HADI_FORCEINLINE void hadi_put_block(T *row, int half, int lane, const double (&u)[B]) {
     if constexpr (B == 1) {
-        row[64 * half + lane] = u[0];
+        row[64 * half + lane] = (T)u[0];
     } else {
 #pragma unroll
         for (int q = 0; q < B / 2; q++) {
-            double2 t;
-            t.x = u[2 * q];
-            t.y = u[2 * q + 1];
-            *reinterpret_cast<double2 *>(row + q * 128 * G + 128 * half + 2 * lane) = t;
+            typename HadiPair<T>::type t;
+            t.x = (T)u[2 * q];
+            t.y = (T)u[2 * q + 1];
+            *reinterpret_cast<typename HadiPair<T>::type *>(row + q * 128 * G + 128 * half + 2 * lane) = t;
         }
     }
 }
@@ -342,10 +383,9 @@ HADI_DEV HADI_FORCEINLINE void hadi_put_block(double *row, int half, int lane, c
 // the corrector's A1 right-hand side is Y0~ + theta dt (...) = Y1rhs + dt/2 (A0 Y2 - A0 U): MODE 1 is a
 // Douglas row step that also stores R1 = Y1rhs - dt/2 A0U and C2; MODE 2 takes its rows from Y2, forms
 // R1 + dt/2 A0 Y2, runs the same A1 solve and adds C2 -- it never needs U, A1U or A2U again.
-template <int B, int G, bool AMER, bool LAST, int MODE = 0>
-HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtx &c, bool active, int j, const double *rm2,
-                                             const double *rm1, const double *r0, const double *rp1,
-                                             const double *rp2) {
+template <int B, int G, bool AMER, bool LAST, int MODE = 0, class T = double>
+HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool active, int j, const T *rm2, const T *rm1,
+                                             const T *r0, const T *rp1, const T *rp2) {
     const int lane = c.lane, rowp = c.rowp, half = c.half;
     constexpr int c0slot = 64 * B * G;
     constexpr int NB = B - 1;
@@ -373,8 +413,9 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtx &c, bool active, i
         const int b1r = b1el - (b1el / B) * B;
 
         // ---- column i = 0 (A0 and A1 rows are zero there; only A2 and the boundary act) ------------
-        const double c0 = r0[c0slot];
-        const double a2c0 = a2l2 * rm2[c0slot] + a2l1 * rm1[c0slot] + a2m * c0 + a2u1 * rp1[c0slot] + a2u2 * rp2[c0slot];
+        const double c0 = (double)r0[c0slot];
+        const double a2c0 = a2l2 * (double)rm2[c0slot] + a2l1 * (double)rm1[c0slot] + a2m * c0 + a2u1 * (double)rp1[c0slot] +
+                            a2u2 * (double)rp2[c0slot];
         const double b1c0 = (b1col == 0) ? b1val : 0.0;
         const double b2c0 = LAST ? c.b2r[c0slot] : 0.0;
         const double lamc0 = AMER ? c.Li[(size_t)j * rowp + c0slot] : 0.0;
@@ -400,25 +441,25 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtx &c, bool active, i
         double u0[B], tt[B];
         {
             double um[B], up[B], u2[B];
-            hadi_get_block<B, G>(r0, half, lane, u0);
-            hadi_get_block<B, G>(rm1, half, lane, um);
-            hadi_get_block<B, G>(rp1, half, lane, up);
+            hadi_get_block<B, G, T>(r0, half, lane, u0);
+            hadi_get_block<B, G, T>(rm1, half, lane, um);
+            hadi_get_block<B, G, T>(rp1, half, lane, up);
 #pragma unroll
             for (int r = 0; r < B; r++) {
                 tt[r] = wm * um[r] + wz * u0[r] + wp * up[r];
                 A2U[r] = a2l1 * um[r] + a2m * u0[r] + a2u1 * up[r];
             }
-            hadi_get_block<B, G>(rm2, half, lane, u2);
+            hadi_get_block<B, G, T>(rm2, half, lane, u2);
 #pragma unroll
             for (int r = 0; r < B; r++) A2U[r] = fma(a2l2, u2[r], A2U[r]);
-            hadi_get_block<B, G>(rp2, half, lane, u2);
+            hadi_get_block<B, G, T>(rp2, half, lane, u2);
 #pragma unroll
             for (int r = 0; r < B; r++) A2U[r] = fma(a2u2, u2[r], A2U[r]);
         }
         const double cb1 = dt * e_nm1 + thdt * (e_n - e_nm1);
-        const double u0L = r0[c.posL], u0R = r0[c.posR];
-        const double tL = wm * rm1[c.posL] + wz * u0L + wp * rp1[c.posL];
-        const double tR = wm * rm1[c.posR] + wz * u0R + wp * rp1[c.posR];
+        const double u0L = (double)r0[c.posL], u0R = (double)r0[c.posR];
+        const double tL = wm * (double)rm1[c.posL] + wz * u0L + wp * (double)rp1[c.posL];
+        const double tR = wm * (double)rm1[c.posR] + wz * u0R + wp * (double)rp1[c.posR];
 
         HADI_STAMP(1);  // LDS rows -> tt, A2U
         double lam[B];
@@ -602,8 +643,8 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtx &c, bool active, i
             hadi_put_block<B, G>(c.R1i + (size_t)j * rowp, half, lane, r1v);
             hadi_put_block<B, G>(c.C2i + (size_t)j * rowp, half, lane, c2v);
         }
-        hadi_put_block<B, G>(c.Yi + (size_t)j * rowp, half, lane, yo);
-        if (lane == 0 && first_half) c.Yi[(size_t)j * rowp + c0slot] = yout_c0;
+        hadi_put_block<B, G, T>(c.Yi + (size_t)j * rowp, half, lane, yo);
+        if (lane == 0 && first_half) c.Yi[(size_t)j * rowp + c0slot] = (T)yout_c0;
         HADI_STAMP(5);  // final correction + store
     }
 }
@@ -642,8 +683,10 @@ HADI_DEV HADI_FORCEINLINE void hadi_wait_vmcnt(int n) {
 // s-coefficient arrays are shared), PD = prefetch depth in iterations: the ring holds (PD+1)*W + 4 rows.
 // (B, G) = (8, 1) runs NG = 2, PD = 2: one 8-wave block per CU whose 158 KB of LDS keep two iterations of
 // rows in flight per wavefront -- the latency-bandwidth product of a CU needs more than one.
-template <int B, int G, int W, int NG, int PD, bool AMER, int MODE = 0>
+// T = float: fp32-state sweep (a.U / a.Y then point to float arrays of the same element layout; European Douglas only).
+template <int B, int G, int W, int NG, int PD, bool AMER, int MODE = 0, class T = double>
 __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : 4)) hadi_pass_a(HadiSweepArgs a, int n) {
+    static_assert(sizeof(T) == 8 || (!AMER && MODE == 0), "the fp32-state sweep covers the European Douglas step only");
     HADI_DYN_SMEM(double, smem);
     constexpr int RING = (PD + 1) * W + 4;
     constexpr int NT = 64 * W * G * NG;
@@ -663,7 +706,7 @@ __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : 4)) hadi_pass_a
     const int j0 = tile * a.R;  // may be >= nrows for the last block's spare group: that group only joins barriers
     const int j1 = (j0 + a.R < nrows) ? j0 + a.R : nrows;
 
-    HadiRowCtx c;
+    HadiRowCtxT<T> c;
     c.lane = lane;
     c.half = half;
     c.wrow = wrow;
@@ -671,8 +714,8 @@ __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : 4)) hadi_pass_a
     c.dt = ip.dt; c.thdt = ip.thdt; c.qd = ip.q; c.half_rd = ip.half_rd;
     c.e_nm1 = exp(ip.r_f * ip.dt * (n - 1));  // device_solver.hpp:238
     c.e_n = exp(ip.r_f * ip.dt * n);          // device_solver.hpp:246
-    const double *__restrict__ Ub = a.U + (size_t)inst * a.L.inst_stride;
-    c.Yi = a.Y + (size_t)inst * a.L.inst_stride;
+    const T *__restrict__ Ub = reinterpret_cast<const T *>(a.U) + (size_t)inst * a.L.inst_stride;
+    c.Yi = reinterpret_cast<T *>(a.Y) + (size_t)inst * a.L.inst_stride;
     c.Li = AMER ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
     c.b2r = a.b2row + (size_t)inst * rowp;
     c.R1i = MODE ? a.R1 + (size_t)inst * a.L.inst_stride : nullptr;
@@ -687,9 +730,9 @@ __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : 4)) hadi_pass_a
         c.posR = (ifirst + B <= 64 * B * G) ? hadi_pos(B, G, ifirst + B) : c0slot + 1;
     }
 
-    // LDS: [NG rings of RING rows] [4 coefficient arrays of 64*B*G] [NG*W*4 exchange] [NG compact row tables]
-    double *ring = smem + (size_t)grp * RING * rowp;
-    double *coef = smem + (size_t)NG * RING * rowp;
+    // LDS: [NG rings of RING rows of T] [4 coefficient arrays of 64*B*G] [NG*W*4 exchange] [NG compact row tables]
+    T *ring = reinterpret_cast<T *>(smem) + (size_t)grp * RING * rowp;
+    double *coef = reinterpret_cast<double *>(reinterpret_cast<T *>(smem) + (size_t)NG * RING * rowp);
     {
         const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B * G;
         for (int e = threadIdx.x; e < 4 * 64 * B * G; e += NT) coef[e] = sc[e];
@@ -711,7 +754,7 @@ __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : 4)) hadi_pass_a
     auto fetch = [&](int jj) -> int {
         const bool exists = jj >= 0 && jj < npad;
         hadi_row_to_lds(Ub + (size_t)jj * rowp, slot(jj), rowp, lane, exists);
-        return exists ? (rowp / 2 + 63) / 64 : 0;
+        return exists ? hadi_row_dma_count<T>(rowp) : 0;
     };
     // prologue: rows of iterations 0 .. PD-1
     if (iters > 0)
@@ -746,9 +789,9 @@ __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : 4)) hadi_pass_a
             if (!active) continue;
         }
         if (j == nrows - 1)
-            hadi_row_step<B, G, AMER, true, MODE>(c, active, j, slot(j - 2), slot(j - 1), slot(j), slot(j + 1), slot(j + 2));
+            hadi_row_step<B, G, AMER, true, MODE, T>(c, active, j, slot(j - 2), slot(j - 1), slot(j), slot(j + 1), slot(j + 2));
         else
-            hadi_row_step<B, G, AMER, false, MODE>(c, active, j, slot(j - 2), slot(j - 1), slot(j), slot(j + 1), slot(j + 2));
+            hadi_row_step<B, G, AMER, false, MODE, T>(c, active, j, slot(j - 2), slot(j - 1), slot(j), slot(j + 1), slot(j + 2));
         if (active) {  // B/2 (one for B = 1) vector stores of the block; the i = 0 store is not counted (lower bound)
 #pragma unroll
             for (int k = 0; k < PD; k++) ya[k] += (B == 1 ? 1 : B / 2);
@@ -1132,13 +1175,15 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_load_table(HadiPassBCtx &c, const double 
     hadi_wave_rendezvous();
 }
 
+template <class T = double>
 HADI_DEV HADI_FORCEINLINE void hadi_pb_load(const HadiPassBCtx &c, int ctile, double (&y)[HADI_LC]) {
+    constexpr unsigned ES = (unsigned)sizeof(T);
     const int col = ctile * 64 + c.lane;
     const int colc = col < c.rowp ? col : c.rowp - 1;  // lanes past the pitch read a valid address, never store
-    const unsigned voff = (unsigned)colc * 8u;
-    const unsigned row0 = (unsigned)c.ja * (unsigned)c.rowp * 8u, rstride = (unsigned)c.rowp * 8u;
+    const unsigned voff = (unsigned)colc * ES;
+    const unsigned row0 = (unsigned)c.ja * (unsigned)c.rowp * ES, rstride = (unsigned)c.rowp * ES;
 #pragma unroll
-    for (int k = 0; k < HADI_LC; k++) y[k] = hadi_buf_load(c.Yb, voff, row0 + (unsigned)k * rstride);
+    for (int k = 0; k < HADI_LC; k++) y[k] = hadi_buf_load_t<T>(c.Yb, voff, row0 + (unsigned)k * rstride);
 }
 
 // Chunk-local solve + interface exchange + spike correction of one 64-column tile held in y (no memory traffic).
@@ -1208,28 +1253,30 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve(const HadiPassBCtx &c, int parity, 
 // Stores the solved tile `ctile` (with the Ikonen-Toivanen projection for American).  RELOAD: every row's register
 // is refilled with the same row of tile `ctile + 1` right behind its store, so one register buffer serves both
 // tiles and the loads of the next tile are in flight as soon as the stores have been issued.
-template <bool AMER, bool RELOAD>
+template <bool AMER, bool RELOAD, class T = double>
 HADI_DEV HADI_FORCEINLINE void hadi_pb_store(const HadiPassBCtx &c, int ctile, double (&y)[HADI_LC]) {
+    static_assert(sizeof(T) == 8 || !AMER, "the fp32-state sweep is European only");
+    constexpr unsigned ES = (unsigned)sizeof(T);
     HADI_STAMP_DECL(c.stamp_acc_)
     const int coln = (ctile + 1) * 64 + c.lane;
-    const unsigned voffn = (unsigned)(coln < c.rowp ? coln : c.rowp - 1) * 8u;
+    const unsigned voffn = (unsigned)(coln < c.rowp ? coln : c.rowp - 1) * ES;
     const int col = ctile * 64 + c.lane;
     const bool valid = col < c.rowp;
     const int colc = valid ? col : c.rowp - 1;
     const size_t base = (size_t)c.ja * c.rowp + colc;
     if constexpr (!AMER) {
-        const unsigned voff = (unsigned)colc * 8u;
-        const unsigned row0 = (unsigned)c.ja * (unsigned)c.rowp * 8u, rstride = (unsigned)c.rowp * 8u;
+        const unsigned voff = (unsigned)colc * ES;
+        const unsigned row0 = (unsigned)c.ja * (unsigned)c.rowp * ES, rstride = (unsigned)c.rowp * ES;
         if constexpr (RELOAD) {
             const unsigned voffs = valid ? voff : HADI_BUF_DROP;
 #pragma unroll
             for (int k = 0; k < HADI_LC; k++) {
-                hadi_buf_store(c.Ub, voffs, row0 + (unsigned)k * rstride, y[k]);
-                y[k] = hadi_buf_load(c.Yb, voffn, row0 + (unsigned)k * rstride);
+                hadi_buf_store_t<T>(c.Ub, voffs, row0 + (unsigned)k * rstride, y[k]);
+                y[k] = hadi_buf_load_t<T>(c.Yb, voffn, row0 + (unsigned)k * rstride);
             }
         } else if (valid) {
 #pragma unroll
-            for (int k = 0; k < HADI_LC; k++) hadi_buf_store(c.Ub, voff, row0 + (unsigned)k * rstride, y[k]);
+            for (int k = 0; k < HADI_LC; k++) hadi_buf_store_t<T>(c.Ub, voff, row0 + (unsigned)k * rstride, y[k]);
         }
     } else {
         const unsigned row0 = (unsigned)c.ja * (unsigned)c.rowp * 8u, rstride = (unsigned)c.rowp * 8u;
@@ -1266,17 +1313,17 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_store(const HadiPassBCtx &c, int ctile, d
     HADI_STAMPB(22);  // projection + store issue
 }
 
-template <bool AMER>
+template <bool AMER, class T = double>
 HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ctile, int parity, double (&y)[HADI_LC],
                                                    int younger = 0) {
     hadi_pb_solve(c, parity, y, younger);
-    hadi_pb_store<AMER, false>(c, ctile, y);
+    hadi_pb_store<AMER, false, T>(c, ctile, y);
 }
 
 // Dynamic LDS: P * (2*4*64 + 16*P) doubles (two interface-exchange buffers, each wavefront's four rows of the reduced
 // inverse); the chunk tables live in registers (HADI_PB_T).
 // MAXP only sets the launch bound (register budget): 8 -> 512 threads, 16 -> 1024 threads.
-template <int MAXP, bool AMER>
+template <int MAXP, bool AMER, class T = double>
 __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n) {
     HADI_DYN_SMEM(double, smem);
     HadiPassBCtx c;
@@ -1294,10 +1341,10 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
     const int nrows = a.L.nrows_pad;
     c.rowp = a.L.rowp;
     c.ja = c.wave * HADI_LC;
-    c.Yi = a.Y + (size_t)inst * a.L.inst_stride;
+    c.Yi = a.Y + (size_t)inst * a.L.inst_stride;  // (pointer-based accesses: American, T = double only)
     c.Ui = a.U + (size_t)inst * a.L.inst_stride;
-    c.Yb = hadi_make_buf(c.Yi, (size_t)a.L.inst_stride * sizeof(double));
-    c.Ub = hadi_make_buf(c.Ui, (size_t)a.L.inst_stride * sizeof(double));
+    c.Yb = hadi_make_buf(reinterpret_cast<const T *>(a.Y) + (size_t)inst * a.L.inst_stride, (size_t)a.L.inst_stride * sizeof(T));
+    c.Ub = hadi_make_buf(reinterpret_cast<const T *>(a.U) + (size_t)inst * a.L.inst_stride, (size_t)a.L.inst_stride * sizeof(T));
     c.Li = AMER ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
     c.P0i = AMER ? a.U0 + (size_t)inst * a.L.inst_stride : nullptr;
     c.pay1d = AMER ? (a.pay_mis[inst] == 0) : 0;
@@ -1312,7 +1359,7 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
     c.stamp_acc_ = stamp_store_;
 #endif
     double ya[HADI_LC], yb[HADI_LC];
-    hadi_pb_load(c, t0, ya);
+    hadi_pb_load<T>(c, t0, ya);
     // the chunk's table (identical for every column) is spread over the lanes' registers once per block
     {
         hadi_pb_load_table(c, a.pb + ((size_t)inst * nrows + c.ja) * HADI_PBW);
@@ -1332,10 +1379,10 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
     __syncthreads();
     for (int t = t0; t < t1; t += 2) {
         // `younger` = vector-memory operations issued after the loads of the tile being solved (diagnostic build only)
-        if (t + 1 < t1) hadi_pb_load(c, t + 1, yb);
-        hadi_pb_solve_store<AMER>(c, t, 0, ya, (t + 1 < t1 ? HADI_LC : 0) + (t > t0 ? HADI_LC : 0));
-        if (t + 2 < t1) hadi_pb_load(c, t + 2, ya);
-        if (t + 1 < t1) hadi_pb_solve_store<AMER>(c, t + 1, 1, yb, (t + 2 < t1 ? HADI_LC : 0) + HADI_LC);
+        if (t + 1 < t1) hadi_pb_load<T>(c, t + 1, yb);
+        hadi_pb_solve_store<AMER, T>(c, t, 0, ya, (t + 1 < t1 ? HADI_LC : 0) + (t > t0 ? HADI_LC : 0));
+        if (t + 2 < t1) hadi_pb_load<T>(c, t + 2, ya);
+        if (t + 1 < t1) hadi_pb_solve_store<AMER, T>(c, t + 1, 1, yb, (t + 2 < t1 ? HADI_LC : 0) + HADI_LC);
     }
 #if defined(HADI_STAMPS) && !defined(HADI_EMU)
     if (HADI_STAMPS == 3 && c.lane == 0)
@@ -1347,7 +1394,7 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
 // 33-row register buffers (the double-buffered code spills 650 B per lane there).  The next tile is loaded into the
 // registers of the current one row by row, right behind the stores.  Measured on MI355X: 1024x512 grid 0.250 ms per
 // launch against 0.382; at 512x256 (P = 8) the double-buffered kernel above wins, 0.144 against 0.206.
-template <int MAXP, bool AMER>
+template <int MAXP, bool AMER, class T = double>
 __global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, int n) {
     HADI_DYN_SMEM(double, smem);
     HadiPassBCtx c;
@@ -1365,10 +1412,10 @@ __global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, in
     const int nrows = a.L.nrows_pad;
     c.rowp = a.L.rowp;
     c.ja = c.wave * HADI_LC;
-    c.Yi = a.Y + (size_t)inst * a.L.inst_stride;
+    c.Yi = a.Y + (size_t)inst * a.L.inst_stride;  // (pointer-based accesses: American, T = double only)
     c.Ui = a.U + (size_t)inst * a.L.inst_stride;
-    c.Yb = hadi_make_buf(c.Yi, (size_t)a.L.inst_stride * sizeof(double));
-    c.Ub = hadi_make_buf(c.Ui, (size_t)a.L.inst_stride * sizeof(double));
+    c.Yb = hadi_make_buf(reinterpret_cast<const T *>(a.Y) + (size_t)inst * a.L.inst_stride, (size_t)a.L.inst_stride * sizeof(T));
+    c.Ub = hadi_make_buf(reinterpret_cast<const T *>(a.U) + (size_t)inst * a.L.inst_stride, (size_t)a.L.inst_stride * sizeof(T));
     c.Li = AMER ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
     c.P0i = AMER ? a.U0 + (size_t)inst * a.L.inst_stride : nullptr;
     c.pay1d = AMER ? (a.pay_mis[inst] == 0) : 0;
@@ -1383,7 +1430,7 @@ __global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, in
     c.stamp_acc_ = stamp_store_;
 #endif
     double y[HADI_LC];
-    hadi_pb_load(c, t0, y);
+    hadi_pb_load<T>(c, t0, y);
     // the chunk's table (identical for every column) is spread over the lanes' registers once per block
     {
         hadi_pb_load_table(c, a.pb + ((size_t)inst * nrows + c.ja) * HADI_PBW);
@@ -1403,8 +1450,8 @@ __global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, in
     __syncthreads();
     for (int t = t0; t < t1; t++) {
         hadi_pb_solve(c, (t - t0) & 1, y, 0);
-        if (t + 1 < t1) hadi_pb_store<AMER, true>(c, t, y);
-        else hadi_pb_store<AMER, false>(c, t, y);
+        if (t + 1 < t1) hadi_pb_store<AMER, true, T>(c, t, y);
+        else hadi_pb_store<AMER, false, T>(c, t, y);
     }
 #if defined(HADI_STAMPS) && !defined(HADI_EMU)
     if (HADI_STAMPS == 3 && c.lane == 0)
@@ -1709,6 +1756,15 @@ __global__ void __launch_bounds__(256) hadi_dividend_kernel(HadiLayout L, int n_
         }
         U[inst * L.inst_stride + (size_t)j * L.rowp + hadi_pos(L, i)] = out;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32-state sweep: the packed state is rounded to fp32 before the time loop and widened after it (same element layout).
+__global__ void __launch_bounds__(256) hadi_narrow_kernel(const double *__restrict__ src, float *__restrict__ dst, size_t n) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) dst[e] = (float)src[e];
+}
+__global__ void __launch_bounds__(256) hadi_widen_kernel(const float *__restrict__ src, double *__restrict__ dst, size_t n) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) dst[e] = (double)src[e];
 }
 
 // ------------------------------------------------------------------------------------------------

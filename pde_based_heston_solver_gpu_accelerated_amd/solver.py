@@ -129,7 +129,8 @@ class HestonADI:
 
     # ---- problem assembly ---------------------------------------------------------------------
     def _problem(self, variant, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids,
-                 U=None, U_0=None, lambda_bar=None, dividends=None, per_instance=None, need_vgrid=True, scheme=0):
+                 U=None, U_0=None, lambda_bar=None, dividends=None, per_instance=None, need_vgrid=True, scheme=0,
+                 state_precision=0):
         n = grids.Vec_s.shape[0]
         m = (m1 + 1) * (m2 + 1)
         p = nat.Problem()
@@ -144,6 +145,7 @@ class HestonADI:
 
         p.n_instances, p.m1, p.m2, p.variant = n, m1, m2, variant
         p.scheme = int(scheme)
+        p.state_precision = int(state_precision)
         p.N, p.delta_t, p.theta = int(N), float(delta_t), float(theta)
         p.r_d, p.r_f = float(r_d), float(r_f)
         p.rho, p.sigma, p.kappa, p.eta = float(rho), float(sigma), float(kappa), float(eta)
@@ -195,12 +197,14 @@ class HestonADI:
 
     # ---- device_DO_timestepping* (src/device_solver.hpp:194-942) -------------------------------
     def DO_timestepping(self, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids, U,
-                        variant=EU, U_0=None, lambda_bar=None, dividends=None, per_instance=None, scheme=0):
+                        variant=EU, U_0=None, lambda_bar=None, dividends=None, per_instance=None, scheme=0,
+                        state_precision=0):
         """Boundary init + operator build + N Douglas steps on the caller's grids; U is updated in
-        place (initial condition in, solution at T out).  scheme=1 runs Craig-Sneyd (European only)."""
+        place (initial condition in, solution at T out).  scheme=1 runs Craig-Sneyd (European only);
+        state_precision=1 keeps the state between the two passes in fp32 (European Douglas only, arithmetic stays fp64)."""
         p = self._problem(variant, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids,
                           U=U, U_0=U_0, lambda_bar=lambda_bar, dividends=dividends, per_instance=per_instance,
-                          scheme=scheme)
+                          scheme=scheme, state_precision=state_precision)
         rc = self._lib.hadi_DO_timestepping(self._h, C.byref(p))
         if rc != nat.HADI_OK:
             self._raise(rc)

@@ -44,6 +44,27 @@ static int run_row_pass(const HadiPlan &pl, const HadiSweepArgs &a, int n, int m
     return 0;
 }
 
+// fp32-state sweep (scheme == 2 in emu_solve): same choices as hadi_api.hip
+template <int B, int G, int NG, int PD>
+static void run_pass_a_f32(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
+    const size_t ring_elems = (size_t)NG * ((PD + 1) * pl.W + 4) * pl.L.rowp;
+    emu::launch(pl.grid_a, 64 * pl.W * G * NG, [&]() { hadi_pass_a<B, G, 4, NG, PD, false, 0, float>(a, n); },
+                pl.smem_a - ring_elems * (sizeof(double) - sizeof(float)));
+}
+static int run_sweep_f32(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
+    switch (pl.L.B * 10 + pl.L.G) {
+        case 11: run_pass_a_f32<1, 1, 1, 2>(pl, a, n); break;
+        case 21: run_pass_a_f32<2, 1, 1, 2>(pl, a, n); break;
+        case 41: run_pass_a_f32<4, 1, 1, 2>(pl, a, n); break;
+        case 81: run_pass_a_f32<8, 1, 1, 1>(pl, a, n); break;
+        case 82: run_pass_a_f32<8, 2, 1, 1>(pl, a, n); break;
+        default: return 2;
+    }
+    if (pl.L.P <= 8) emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b<8, false, float>(a, n); }, pl.smem_b);
+    else emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b1<16, false, float>(a, n); }, pl.smem_b);
+    return 0;
+}
+
 static void run_col_pass(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
     if (pl.L.P <= 8) {  // same choice as hadi_api.hip
         if (a.american) emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b<8, true>(a, n); }, pl.smem_b);
@@ -72,7 +93,8 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
     const HadiLayout &L = pl.L;
     const int american = variant & 1, dividend = (variant >> 1) & 1;
     const size_t st = (size_t)L.inst_stride * n_inst;
-    const bool cs = scheme == 1;
+    const bool cs = scheme == 1, f32 = scheme == 2;
+    if (f32 && (american || dividend)) return 3;
     std::vector<double> dV(cs ? st : 0), dR1(cs ? st : 0), dC2(cs ? st : 0);
     std::vector<double> dU(st), dY(st, 0.0), dLAM(american ? st : 0), dU0(american ? st : 0), dUT(dividend ? st : 0);
     std::vector<double> scoef(pl.n_scoef * n_inst), b2row(pl.n_b2row * n_inst), rowc(pl.n_rowc * n_inst),
@@ -112,7 +134,7 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
     std::vector<int> flags(N, -1);
     if (dividend) hadi_dividend_steps(N, dt, ndiv, ddates, flags.data(), N);
     const size_t smem_small = american ? pl.smem_small_am : pl.smem_small_eu;
-    if (use_small && !cs && smem_small > 0) {
+    if (use_small && !cs && !f32 && smem_small > 0) {
         HadiSmallArgs sm;
         sm.div_flag = dividend ? flags.data() : nullptr; sm.flag_stride = 0; sm.div_amounts = damounts; sm.div_pcts = dpcts;
         sm.vec_s = vec_s; sm.Nmax = N;
@@ -125,6 +147,18 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
         }
         emu::launch(8, 64, [&]() { hadi_unpack_kernel(L, n_inst, dU.data(), U); });
         if (american && lam_out) emu::launch(8, 64, [&]() { hadi_unpack_kernel(L, n_inst, dLAM.data(), lam_out); });
+        return 0;
+    }
+    if (f32) {  // round the packed state to float, sweep on float arrays, widen again
+        std::vector<float> fU(st), fY(st, 0.0f);
+        emu::launch(8, 64, [&]() { hadi_narrow_kernel(dU.data(), fU.data(), st); });
+        HadiSweepArgs af = a;
+        af.U = reinterpret_cast<double *>(fU.data());
+        af.Y = reinterpret_cast<double *>(fY.data());
+        for (int n = 1; n <= N; n++)
+            if (run_sweep_f32(pl, af, n)) return 2;
+        emu::launch(8, 64, [&]() { hadi_widen_kernel(fU.data(), dU.data(), st); });
+        emu::launch(8, 64, [&]() { hadi_unpack_kernel(L, n_inst, dU.data(), U); });
         return 0;
     }
     for (int n = 1; n <= N; n++) {

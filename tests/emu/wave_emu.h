@@ -33,6 +33,9 @@ struct emu_dim3 {
 struct double2 {
     double x, y;
 };
+struct float2 {
+    float x, y;
+};
 
 namespace emu {
 struct WaveState {

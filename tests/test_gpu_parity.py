@@ -518,6 +518,38 @@ def test_strip_row_pass_vs_oracle(solver, monkeypatch, variant, name, m1, m2, N,
         assert np.abs(lam - lo).max() <= 1e-8 * max(1.0, np.abs(lo).max())
 
 
+@pytest.mark.parametrize("m1,m2,N,n", [(50, 25, 20, 3), (128, 64, 10, 2), (256, 128, 12, 3), (512, 256, 8, 2),
+                                      (1024, 512, 4, 1), (700, 300, 4, 2)])
+def test_fp32_state_sweep_vs_oracle(solver, m1, m2, N, n):
+    """BASELINE config 5 ("mixed-precision fp32 ADI sweep with fp64 tridiag pivots"): U and the A2 right-hand side are
+    stored as fp32 between the passes, all arithmetic is fp64.  Not a reference feature -- the checker is the oracle
+    with the same two roundings per step; an fp64 last-bit difference before a store can flip a float rounding
+    (6e-8 relative), hence 2e-7 per step.  Against the fp64 sweep the price moves by a few 1e-6 relative."""
+    strikes = Cm.strikes_for(n)
+    grids, U0 = _batch(m1, m2, strikes)
+    U = U0.copy()
+    solver.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U,
+                           state_precision=H.STATE_FP32)
+    assert "float" in solver.describe_last_sweep()
+    p = Cm.oracle_params(m1, m2, N, "EU", r_f=0.01)
+    p.state_fp32 = 1
+    Uo, _, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0)
+    _assert_field(U, Uo, rtol=2e-7 * N)
+    p.state_fp32 = 0
+    U64, _, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0)
+    _assert_field(U, U64, rtol=2e-6)
+
+
+def test_fp32_state_restrictions(solver):
+    m1, m2, N = 64, 32, 4
+    grids, U0 = _batch(m1, m2, [100.0])
+    for kw in ({"variant": H.AM, "U_0": U0}, {"scheme": 1}):
+        with pytest.raises(H.HadiError) as e:
+            solver.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids,
+                                   U0.copy(), state_precision=H.STATE_FP32, **kw)
+        assert e.value.status == 2  # HADI_ERR_UNSUPPORTED
+
+
 def test_describe_last_sweep_names_the_kernels(solver):
     _hadi_solve(solver, 50, 25, 4, [100.0], H.EU)
     assert "hadi_small_kernel" in solver.describe_last_sweep()

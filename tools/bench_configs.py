@@ -3,7 +3,8 @@
    C3  batch of 512 American calls with discrete dividends, 256x128 grid, 500 steps
    C4  Heston LM calibration pieces on a 500-option surface (50 strikes x 10 maturities), 50x25 grid:
        one flattened Jacobian (3000 instances) + one trial pricing (500 instances), per-instance maturities
-   C5g the config-5 grid (1024x512, 2000 steps) in fp64, 32 instances
+   C5  the config-5 grid (1024x512, 2000 steps), 64 instances: fp64, and with the state kept in fp32 between the passes
+       (fp64 arithmetic) -- price difference reported
    REF the reference's own perf-harness shape: 50x25, N=20, 500 instances (perfomance_test.cpp:46-57)
 Prints one JSON object; `python tools/bench_configs.py > profiles/<tag>_configs.json` on the GPU box."""
 import json, os, sys, time
@@ -91,14 +92,26 @@ def ref_amdiv():
 t = timed(ref_amdiv, 5)
 out["REF_harness_50x25x20_x500_american_dividend"] = {"seconds": t, "point_steps_per_s": n * ts * N / t}
 
-# ---- C5 grid in fp64
-m1, m2, N, n = 1024, 512, 2000, 32
+# ---- C5 grid: fp64 and fp32 state
+m1, m2, N, n = 1024, 512, 2000, 64
 ks = ladder(n); g = H.GridViewsBatch.for_strikes(m1, m2, S_0, V_0, ks); U0h = g.call_payoff(ks)
 gd = g.to(dev); U0 = torch.from_numpy(U0h).to(dev); U = torch.empty_like(U0)
+prec = H.STATE_FP64
 def c5():
     U.copy_(U0)
-    solver.DO_timestepping(m1, m2, N, T / N, theta, r_d, r_f, rho, sigma, kappa, eta, gd, U)
+    solver.DO_timestepping(m1, m2, N, T / N, theta, r_d, r_f, rho, sigma, kappa, eta, gd, U, state_precision=prec)
+kmid = min(range(n), key=lambda k: abs(ks[k] - 100.0))
+gk = H.Grid(m1, 8 * ks[kmid], S_0, ks[kmid], ks[kmid] / 5, m2, 5.0, V_0, 5.0 / 500)
+node = gk.find_s_index(S_0) + gk.find_v0_index(V_0) * (m1 + 1)
 t = timed(c5, 1)
-out["C5grid_european_1024x512x2000_x32_fp64"] = {"seconds": t, "point_steps_per_s": n * (m1 + 1) * (m2 + 1) * N / t}
+p64 = float(U[kmid, node].item())
+prec = H.STATE_FP32
+t32 = timed(c5, 1)
+p32 = float(U[kmid, node].item())
+out["C5_european_1024x512x2000_x64_fp32_state"] = {"seconds": t32, "point_steps_per_s": n * (m1 + 1) * (m2 + 1) * N / t32,
+                                                   "effective_GBps_at_16B": n * (m1 + 1) * (m2 + 1) * N / t32 * 16 / 1e9,
+                                                   "price_fp32_state": p32, "price_fp64": p64, "price_abs_diff": abs(p32 - p64),
+                                                   "kernels": solver.describe_last_sweep()}
+out["C5grid_european_1024x512x2000_x64_fp64"] = {"seconds": t, "point_steps_per_s": n * (m1 + 1) * (m2 + 1) * N / t}
 out["device"] = solver.device_info()
 print(json.dumps(out, indent=1))
