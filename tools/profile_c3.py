@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 import pde_based_heston_solver_gpu_accelerated_amd as H
 variant = {"EU": H.EU, "AM": H.AM, "DIV": H.DIV, "AM_DIV": H.AM_DIV}[sys.argv[1] if len(sys.argv) > 1 else "AM_DIV"]
-m1, m2, N, n = 256, 128, 500, 512
+m1, m2, N, n = [int(x) for x in os.environ.get("C3_SHAPE", "256,128,500,512").split(",")]
 ks = [85.0 + 30.0 * k / (n - 1) for k in range(n)]
 g = H.GridViewsBatch.for_strikes(m1, m2, 100.0, 0.04, ks); U0h = g.call_payoff(ks)
 dev = torch.device("cuda:0"); gd = g.to(dev); U0 = torch.from_numpy(U0h).to(dev); U = torch.empty_like(U0)
