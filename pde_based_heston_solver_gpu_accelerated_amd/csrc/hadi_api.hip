@@ -50,6 +50,7 @@ struct Ctx {
     std::string last_path;  // which kernels the last sweep ran (hadi_describe_last_sweep)
     DevBuf div_flag, div_amt, div_pct;
     DevBuf pay_mis;  // American: per-instance payoff-shape flags (hadi_payoff_shape_kernel)
+    DevBuf order;    // small-grid path: dispatch order of the instances (multi-maturity batches)
 };
 
 int fail(Ctx *c, int code, const char *fmt, ...) {
@@ -399,6 +400,18 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         }
         HadiSmallArgs sm;
         sm.div_flag = nullptr; sm.div_amounts = nullptr; sm.div_pcts = nullptr; sm.vec_s = d.d_vec_s; sm.Nmax = d.Nmax;
+        sm.order = nullptr;
+        if (!d.uniform_steps) {  // longest-processing-time-first dispatch order
+            std::vector<int> order(d.n);
+            for (int k = 0; k < d.n; k++) order[k] = k;
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+                return d.par8[(size_t)x * 8 + 5] > d.par8[(size_t)y * 8 + 5];
+            });
+            if ((rc = ensure(c, c->order, sizeof(int) * n))) return rc;
+            HIP_TRY(c, hipMemcpyAsync(c->order.p, order.data(), sizeof(int) * n, hipMemcpyHostToDevice, s));
+            HIP_TRY(c, hipStreamSynchronize(s));  // pageable staging vector leaves scope
+            sm.order = ptr<int>(c->order);
+        }
         sm.flag_stride = flag_stride;
         if (have_div) {
             sm.div_flag = ptr<int>(c->div_flag); sm.div_amounts = ptr<double>(c->div_amt); sm.div_pcts = ptr<double>(c->div_pct);
@@ -828,7 +841,7 @@ int hadi_destroy(hadi_ctx *ctx) {
     DevBuf *bufs[] = {&c->U, &c->Y, &c->LAM, &c->U0, &c->UT, &c->scoef, &c->b2row, &c->rowc, &c->a2i, &c->pb,
                       &c->rinv, &c->rwork, &c->ipar, &c->par8, &c->g_s, &c->g_v, &c->g_ds, &c->g_dv, &c->src_v,
                       &c->src_dv, &c->sel_a, &c->sel_b, &c->v0_i, &c->natU, &c->natU0, &c->natOut, &c->prices,
-                      &c->status, &c->div_flag, &c->div_amt, &c->div_pct, &c->V, &c->R1, &c->C2, &c->pay_mis, &c->Uf, &c->Yf};
+                      &c->status, &c->div_flag, &c->div_amt, &c->div_pct, &c->V, &c->R1, &c->C2, &c->pay_mis, &c->Uf, &c->Yf, &c->order};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto &g : c->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }

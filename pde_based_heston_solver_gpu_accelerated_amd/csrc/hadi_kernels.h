@@ -1496,6 +1496,7 @@ struct HadiSmallArgs {
     const double *div_pcts;
     const double *vec_s;        // [n_inst][m1+1] (dividend interpolation)
     int Nmax;
+    const int *order;           // block b solves instance order[b] (longest time loops first), nullptr = identity
 };
 
 template <int B, int W, bool AMER>
@@ -1504,8 +1505,9 @@ __global__ void __launch_bounds__(64 * W) hadi_small_kernel(HadiSweepArgs a, Had
     constexpr int G = 1, NT = 64 * W;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = HADI_UNIFORM((int)(threadIdx.x >> 6));
-    const int inst = blockIdx.x;
-    if (inst >= a.n_inst) return;
+    if ((int)blockIdx.x >= a.n_inst) return;
+    // multi-maturity batches: instances with many time steps are dispatched first, short ones fill the tail
+    const int inst = sm.order ? sm.order[blockIdx.x] : (int)blockIdx.x;
     const HadiInstPar ip = a.ipar[inst];
     const int nrows = a.L.nrows, rowp = a.L.rowp, m1 = a.L.m1;
     constexpr int c0slot = 64 * B;

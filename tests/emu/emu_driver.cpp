@@ -137,7 +137,7 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
     if (use_small && !cs && !f32 && smem_small > 0) {
         HadiSmallArgs sm;
         sm.div_flag = dividend ? flags.data() : nullptr; sm.flag_stride = 0; sm.div_amounts = damounts; sm.div_pcts = dpcts;
-        sm.vec_s = vec_s; sm.Nmax = N;
+        sm.vec_s = vec_s; sm.Nmax = N; sm.order = nullptr;
         if (L.B == 1) {
             if (american) emu::launch(n_inst, 256, [&]() { hadi_small_kernel<1, 4, true>(a, sm); }, smem_small);
             else emu::launch(n_inst, 256, [&]() { hadi_small_kernel<1, 4, false>(a, sm); }, smem_small);
