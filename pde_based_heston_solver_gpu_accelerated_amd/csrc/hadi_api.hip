@@ -183,6 +183,10 @@ hipError_t raise_all_lds_limits() {
     if ((e = raise_lds_limit(hadi_small_kernel<1, 4, true>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_kernel<2, 4, false>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_kernel<2, 4, true>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_small_kernel<1, 8, false>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_small_kernel<1, 8, true>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_small_kernel<2, 8, false>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_small_kernel<2, 8, true>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b<8, false>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b<8, true>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b1<16, false>)) != hipSuccess) return e;
@@ -394,8 +398,8 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     if (c->use_small && !prof && !cs && !f32 && smem_small > 0) {
         {
             char buf[160];
-            std::snprintf(buf, sizeof buf, "hadi_small_kernel<%d,4,%s>: whole time loop in one launch, instance resident in LDS (%zu B)", L.B,
-                          american ? "AM" : "EU", smem_small);
+            std::snprintf(buf, sizeof buf, "hadi_small_kernel<%d,%d,%s>: whole time loop in one launch, instance resident in LDS (%zu B)", L.B,
+                          d.n <= 2 * c->cu_count ? 8 : 4, american ? "AM" : "EU", smem_small);
             c->last_path = buf;
         }
         HadiSmallArgs sm;
@@ -417,7 +421,20 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
             sm.div_flag = ptr<int>(c->div_flag); sm.div_amounts = ptr<double>(c->div_amt); sm.div_pcts = ptr<double>(c->div_pct);
         }
         HIP_TRY(c, hipEventRecord(c->ev[1], s));
-        if (L.B == 1) {
+        // wavefronts per instance: 4 when the batch fills the GPU (throughput), 8 for small batches (latency of the
+        // dependent per-step phases; more waves share the rows of the row pass)
+        // (measured, 50x25 grid: 1 instance x 100 steps 1.27 -> 1.04 ms with 8; 3000 instances x 50 steps 4.19 -> 4.58 ms)
+        const int sw = std::getenv("HADI_TUNE_SMALLW") ? std::atoi(std::getenv("HADI_TUNE_SMALLW"))
+                                                       : (d.n <= 2 * c->cu_count ? 8 : 4);
+        if (sw == 8) {
+            if (L.B == 1) {
+                if (american) hipLaunchKernelGGL((hadi_small_kernel<1, 8, true>), dim3(d.n), dim3(512), smem_small, s, a, sm);
+                else hipLaunchKernelGGL((hadi_small_kernel<1, 8, false>), dim3(d.n), dim3(512), smem_small, s, a, sm);
+            } else {
+                if (american) hipLaunchKernelGGL((hadi_small_kernel<2, 8, true>), dim3(d.n), dim3(512), smem_small, s, a, sm);
+                else hipLaunchKernelGGL((hadi_small_kernel<2, 8, false>), dim3(d.n), dim3(512), smem_small, s, a, sm);
+            }
+        } else if (L.B == 1) {
             if (american) hipLaunchKernelGGL((hadi_small_kernel<1, 4, true>), dim3(d.n), dim3(256), smem_small, s, a, sm);
             else hipLaunchKernelGGL((hadi_small_kernel<1, 4, false>), dim3(d.n), dim3(256), smem_small, s, a, sm);
         } else {
