@@ -138,7 +138,15 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
         HadiSmallArgs sm;
         sm.div_flag = dividend ? flags.data() : nullptr; sm.flag_stride = 0; sm.div_amounts = damounts; sm.div_pcts = dpcts;
         sm.vec_s = vec_s; sm.Nmax = N; sm.order = nullptr;
-        if (L.B == 1) {
+        if (use_small == 2) {  // 8 wavefronts per instance (what hadi_api.hip picks for small batches)
+            if (L.B == 1) {
+                if (american) emu::launch(n_inst, 512, [&]() { hadi_small_kernel<1, 8, true>(a, sm); }, smem_small);
+                else emu::launch(n_inst, 512, [&]() { hadi_small_kernel<1, 8, false>(a, sm); }, smem_small);
+            } else {
+                if (american) emu::launch(n_inst, 512, [&]() { hadi_small_kernel<2, 8, true>(a, sm); }, smem_small);
+                else emu::launch(n_inst, 512, [&]() { hadi_small_kernel<2, 8, false>(a, sm); }, smem_small);
+            }
+        } else if (L.B == 1) {
             if (american) emu::launch(n_inst, 256, [&]() { hadi_small_kernel<1, 4, true>(a, sm); }, smem_small);
             else emu::launch(n_inst, 256, [&]() { hadi_small_kernel<1, 4, false>(a, sm); }, smem_small);
         } else {

@@ -121,6 +121,9 @@ def test_small_grid_lds_resident_kernel(emu):
     _run(emu, 50, 25, 20, [100.0], O.AM_DIV, 8, small=1)
     _run(emu, 100, 30, 4, [100.0], O.AM, 8, r_f=0.01, small=1)
     _run(emu, 40, 12, 12, [100.0], O.DIV, 8, small=1)
+    # 8 wavefronts per instance (small batches)
+    _run(emu, 50, 25, 6, [100.0], O.AM_DIV, 8, small=2)
+    _run(emu, 100, 30, 3, [96.0], O.EU, 8, r_f=0.01, small=2)
 
 
 def test_setup_tables_against_oracle_operators(emu):

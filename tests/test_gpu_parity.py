@@ -550,6 +550,25 @@ def test_fp32_state_restrictions(solver):
         assert e.value.status == 2  # HADI_ERR_UNSUPPORTED
 
 
+def test_small_grid_kernel_on_a_batch_larger_than_two_per_cu(solver):
+    """More than 2 instances per CU -> 4 wavefronts per instance (throughput shape of the LDS-resident kernel); small
+    batches (every other small-grid test) run 8 per instance.  Per-instance maturities exercise the dispatch order."""
+    m1, m2, n = 50, 25, 640
+    strikes = Cm.strikes_for(n)
+    Ns = [4 + (k % 5) for k in range(n)]
+    per = {"N_i": Ns, "delta_t_i": [0.5 / N for N in Ns]}
+    grids, U0 = _batch(m1, m2, strikes)
+    U = U0.copy()
+    solver.DO_timestepping(m1, m2, 1, 1.0, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U,
+                           per_instance=per)
+    assert "hadi_small_kernel<1,4,EU>" in solver.describe_last_sweep()
+    for N in sorted(set(Ns)):
+        rows = np.array([k for k in range(n) if Ns[k] == N])
+        p = O.make_params(m1, m2, N, 0.5 / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA)
+        Uo, _, _ = O.solve_batch(p, grids.Vec_s[rows], grids.Vec_v[rows], grids.Delta_s[rows], grids.Delta_v[rows], U0[rows])
+        _assert_field(U[rows], Uo)
+
+
 def test_describe_last_sweep_names_the_kernels(solver):
     _hadi_solve(solver, 50, 25, 4, [100.0], H.EU)
     assert "hadi_small_kernel" in solver.describe_last_sweep()
