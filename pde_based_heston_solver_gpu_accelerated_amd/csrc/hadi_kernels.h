@@ -281,7 +281,8 @@ HADI_DEV HADI_FORCEINLINE void hadi_wave_rendezvous() {
 // (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPRs).  Issued through inline asm on purpose:
 // with the builtin hipcc sees an LDS write and puts s_waitcnt vmcnt(0) in front of the very next ds_read
 // (it cannot know the ring slots differ), which serialises the prefetch with the row it should overlap.
-// The asm form is invisible to that bookkeeping, so completion is OUR job: hadi_dma_wait() + barrier
+// The asm form is invisible to that bookkeeping, so completion is OUR job: hadi_wait_vmcnt() (+ the barrier, where
+// other wavefronts read the row)
 // before anyone reads the rows (cdna_hip_programming.md 5.7).  Rows outside the allocation are zeros.
 // T = double, or float for the fp32-state sweep (state stored as fp32, all arithmetic fp64): the row is copied as raw
 // bytes either way, rowp * sizeof(T) is a multiple of 32.
@@ -699,8 +700,8 @@ HADI_DEV HADI_FORCEINLINE void hadi_wait_vmcnt(int n) {
 
 // NG = row tiles handled by one block (each by its own group of W*G wavefronts with its own LDS ring; the
 // s-coefficient arrays are shared), PD = prefetch depth in iterations: the ring holds (PD+1)*W + 4 rows.
-// (B, G) = (8, 1) runs NG = 2, PD = 2: one 8-wave block per CU whose 158 KB of LDS keep two iterations of
-// rows in flight per wavefront -- the latency-bandwidth product of a CU needs more than one.
+// Every shape runs NG = 1 (hadi_plan.h: two groups behind one barrier measured slower); PD = 1 at 8 nodes per lane
+// (two 4-wave blocks per CU), 2 below.  Large batches at 8 nodes per lane use hadi_pass_a_strip instead.
 // T = float: fp32-state sweep (a.U / a.Y then point to float arrays of the same element layout; European Douglas only).
 template <int B, int G, int W, int NG, int PD, bool AMER, int MODE = 0, class T = double>
 __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : 4)) hadi_pass_a(HadiSweepArgs a, int n) {
