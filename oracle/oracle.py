@@ -36,9 +36,16 @@ class _Dump(C.Structure):
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    if force or not os.path.exists(_LIB_PATH) or \
-            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "heston_oracle.c")):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    import fcntl
+    fd = os.open(os.path.join(_HERE, ".build.lock"), os.O_CREAT | os.O_RDWR, 0o644)
+    try:  # several test ranks may get here at once
+        fcntl.flock(fd, fcntl.LOCK_EX)
+        if force or not os.path.exists(_LIB_PATH) or \
+                os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "heston_oracle.c")):
+            subprocess.check_call(["make", "-C", _HERE, "-s"])
+    finally:
+        fcntl.flock(fd, fcntl.LOCK_UN)
+        os.close(fd)
     return _LIB_PATH
 
 
