@@ -53,6 +53,20 @@ struct Ctx {
     DevBuf order;    // small-grid path: dispatch order of the instances (multi-maturity batches)
 };
 
+// Every GPU entry point runs on the handle's device whatever the caller's current device is (a torch rank that
+// never called set_device sits on device 0), and leaves the caller's choice as it found it.
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
 int fail(Ctx *c, int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
@@ -622,6 +636,7 @@ void fill_common(const hadi_problem *p, SweepDesc &d) {
 int solve_common(Ctx *c, const hadi_problem *p, bool rebuild_v, bool pick, double S_0, double V_0, double *prices_out) {
     int rc = check_problem(c, p, true, !rebuild_v);
     if (rc) return rc;
+    DeviceGuard guard(c->device);
     const int n = p->n_instances, m1 = p->m1, m2 = p->m2;
     if (m1 < 2 || m2 < 3) return fail(c, HADI_ERR_UNSUPPORTED, "grid %dx%d too small", m1, m2);
     const size_t m = (size_t)(m1 + 1) * (m2 + 1);
@@ -699,6 +714,7 @@ int solve_common(Ctx *c, const hadi_problem *p, bool rebuild_v, bool pick, doubl
 int jacobian_common(Ctx *c, const hadi_problem *p, double S_0, double V_0, double eps, double *J, double *base_prices) {
     int rc = check_problem(c, p, false, false);
     if (rc) return rc;
+    DeviceGuard guard(c->device);
     if (!p->U_0) return fail(c, HADI_ERR_INVALID, "U_0 (initial condition) is required for the Jacobian");
     if (!J || !base_prices) return fail(c, HADI_ERR_INVALID, "J / base_prices missing");
     const int n0 = p->n_instances, m1 = p->m1, m2 = p->m2, G = 6;
