@@ -1075,20 +1075,29 @@ __global__ void __launch_bounds__(512, (B >= 4 ? 2 : 4)) hadi_pass_a_strip(HadiS
         hadi_row_to_lds(Ub + (size_t)jj * rowp, slot(jj), rowp, lane, exists);
         return exists ? (rowp / 2 + 63) / 64 : 0;
     };
-    // ---- prologue: rows j0+1 .. j0+3 to the ring, rows j0-2 .. j0 and this strip's row table to registers ----
-    fetch(j0 + 1);
-    fetch(j0 + 2);
-    int after0 = fetch(j0 + 3);  // vector-memory instructions issued after the DMA of the row needed next (j+2)
-    int after1 = 0;              // ... after the DMA of row j+3
-    double um2[B], um1[B], u0[B];
+    // Direction of the walk: even strips go up (j0 -> j1-1), odd strips come down (j1-1 -> j0).  Neighbouring strips
+    // then touch their shared halo rows at the same time -- both start there or both end there -- so the second reader
+    // finds them in L2 instead of fetching them again ~100 us later (HBM reads of this pass 9.8 -> ~9 B per node).
+    // Below, "behind" = rows already passed (registers), "ahead" = rows still to come (LDS ring / in flight); for a
+    // descending strip the row-table scalars of the +1/+2 and -1/-2 neighbours simply swap roles.
+    const int dir = (((sb * NWV + wave) & 1) == 0) ? 1 : -1;
+    const int cnt = j1 - j0;
+    const int js = dir > 0 ? j0 : j1 - 1;
+    auto row_ok = [&](int jj) { return jj >= 0 && jj < npad; };
+    // ---- prologue: the next three rows ahead to the ring, the two rows behind and the first row to registers ----
+    fetch(js + dir);
+    fetch(js + 2 * dir);
+    int after0 = fetch(js + 3 * dir);  // vector-memory instructions issued after the DMA of the row needed next
+    int after1 = 0;                    // ... after the DMA of the row after that
+    double um2[B], um1[B], u0[B];      // rows behind by 2, behind by 1, current
     double c0m2 = 0.0, c0m1 = 0.0, c00, c0p1;
-    hadi_load_row<B>(Ub + (size_t)(j0 - 2) * rowp, lane, j0 - 2 >= 0, um2);
-    hadi_load_row<B>(Ub + (size_t)(j0 - 1) * rowp, lane, j0 - 1 >= 0, um1);
-    hadi_load_row<B>(Ub + (size_t)j0 * rowp, lane, true, u0);
-    if (j0 - 2 >= 0) c0m2 = Ub[(size_t)(j0 - 2) * rowp + c0slot];
-    if (j0 - 1 >= 0) c0m1 = Ub[(size_t)(j0 - 1) * rowp + c0slot];
-    c00 = Ub[(size_t)j0 * rowp + c0slot];
-    c0p1 = (j0 + 1 < npad) ? Ub[(size_t)(j0 + 1) * rowp + c0slot] : 0.0;
+    hadi_load_row<B>(Ub + (ptrdiff_t)(js - 2 * dir) * rowp, lane, row_ok(js - 2 * dir), um2);
+    hadi_load_row<B>(Ub + (ptrdiff_t)(js - dir) * rowp, lane, row_ok(js - dir), um1);
+    hadi_load_row<B>(Ub + (size_t)js * rowp, lane, true, u0);
+    if (row_ok(js - 2 * dir)) c0m2 = Ub[(ptrdiff_t)(js - 2 * dir) * rowp + c0slot];
+    if (row_ok(js - dir)) c0m1 = Ub[(ptrdiff_t)(js - dir) * rowp + c0slot];
+    c00 = Ub[(size_t)js * rowp + c0slot];
+    c0p1 = row_ok(js + dir) ? Ub[(ptrdiff_t)(js + dir) * rowp + c0slot] : 0.0;
 #if !defined(HADI_EMU)
     // Consume the prologue's register loads HERE: otherwise hipcc parks their s_waitcnt vmcnt(0) at the loop header,
     // where it would retire the DMA prefetch and the result stores in every iteration.
@@ -1102,26 +1111,33 @@ __global__ void __launch_bounds__(512, (B >= 4 ? 2 : 4)) hadi_pass_a_strip(HadiS
     c.stamp_acc_ = stamp_store_;
 #endif
     HADI_STAMP_DECL(c.stamp_acc_)
-    for (int j = j0; j < j1; j++) {
+    for (int t = 0; t < cnt; t++) {
+        const int j = js + dir * t;
         HADI_STAMPC(30);  // carry + loop
         HadiSRow srow;
         hadi_sload_issue(a.rowc + ((size_t)inst * nrows + j) * HADI_RC, srow);  // flies during the DMA wait
-        hadi_wait_vmcnt(after0);  // row j+2 has landed (row j+1 landed a step earlier)
+        hadi_wait_vmcnt(after0);  // the row two ahead has landed (the row one ahead landed a step earlier)
         HADI_STAMPC(24);  // wait for the DMA
         hadi_wave_rendezvous();
-        // row j+4 goes to the slot of row j: row j is in registers, and this wavefront's last read of that slot (the
-        // reload at the end of the previous step) has been retired there
+        // the row four ahead goes to the slot of row j: row j is in registers, and this wavefront's last read of that
+        // slot (the reload at the end of the previous step) has been retired there
         int z = 0;
-        if (j + 4 <= j1 + 1) z = fetch(j + 4);
+        if (t + 4 <= cnt + 1) z = fetch(j + 4 * dir);
         after0 = after1 + z;
         after1 = 0;
         hadi_wave_rendezvous();
         double up1[B], up2[B];
-        hadi_lds_row<B>(slot(j + 1), lane, up1);
-        hadi_lds_row<B>(slot(j + 2), lane, up2);
-        const double c0p2 = slot(j + 2)[c0slot];
+        hadi_lds_row<B>(slot(j + dir), lane, up1);
+        hadi_lds_row<B>(slot(j + 2 * dir), lane, up2);
+        const double c0p2 = slot(j + 2 * dir)[c0slot];
         double rt[HADI_RCL];
         hadi_sload_wait(srow, rt);  // one lgkmcnt(0) for the table entry and the LDS reads above
+        if (dir < 0) {  // descending: "behind" rows are j+1, j+2 -- swap the neighbour weights instead of the arrays
+            double w;
+            w = rt[RC_WM]; rt[RC_WM] = rt[RC_WP]; rt[RC_WP] = w;
+            w = rt[RC_L2]; rt[RC_L2] = rt[RC_U2]; rt[RC_U2] = w;
+            w = rt[RC_L1]; rt[RC_L1] = rt[RC_U1]; rt[RC_U1] = w;
+        }
         HADI_STAMPC(25);  // LDS reads + table entry + DMA issue
         if (j == nrows - 1) hadi_strip_step<B, AMER, true>(c, j, rt, um2, um1, u0, up1, up2, c0m2, c0m1, c00, c0p1, c0p2);
         else hadi_strip_step<B, AMER, false>(c, j, rt, um2, um1, u0, up1, up2, c0m2, c0m1, c00, c0p1, c0p2);
@@ -1132,7 +1148,7 @@ __global__ void __launch_bounds__(512, (B >= 4 ? 2 : 4)) hadi_pass_a_strip(HadiS
             um2[r] = um1[r];
             um1[r] = u0[r];
         }
-        hadi_lds_row<B>(slot(j + 1), lane, u0);  // again from its slot (intact until step j+1) rather than held in registers
+        hadi_lds_row<B>(slot(j + dir), lane, u0);  // again from its slot (intact until the next step) rather than held in registers
 #if !defined(HADI_EMU)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and retired before the next step reuses that slot
 #endif
