@@ -47,6 +47,7 @@ struct Ctx {
     unsigned long long graph_clock = 0;
     int use_graph = 1;
     int use_small = 1;  // LDS-resident one-launch path for small grids
+    int use_amp = 1;    // American sweeps without the lambda_bar array when the payoff depends on s only
     std::string last_path;  // which kernels the last sweep ran (hadi_describe_last_sweep)
     DevBuf div_flag, div_amt, div_pct;
     DevBuf pay_mis;  // American: per-instance payoff-shape flags (hadi_payoff_shape_kernel)
@@ -168,6 +169,13 @@ void launch_pass_a_f32(const HadiPlan &pl, const HadiSweepArgs &a, int n, hipStr
     hipLaunchKernelGGL((hadi_pass_a<B, G, 4, NG, PD, false, 0, float>), dim3(pl.grid_a), dim3(64 * pl.W * G * NG), smem, s, a, n);
 }
 
+// American, P representation (no lambda_bar array): shared-ring kernel with the payoff row behind the tables in LDS
+template <int B, int G, int NG, int PD>
+void launch_pass_a_amp(const HadiPlan &pl, const HadiSweepArgs &a, int n, hipStream_t s) {
+    hipLaunchKernelGGL((hadi_pass_a<B, G, 4, NG, PD, 2>), dim3(pl.grid_a), dim3(64 * pl.W * G * NG),
+                       pl.smem_a + (size_t)pl.L.rowp * sizeof(double), s, a, n);
+}
+
 // Kernels whose dynamic LDS can exceed the 64 KiB default need the limit raised once.
 template <class K>
 hipError_t raise_lds_limit(K kernel) {
@@ -204,6 +212,13 @@ hipError_t raise_all_lds_limits() {
     if ((e = raise_lds_limit(hadi_pass_b<8, false>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b<8, true>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b1<16, false>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_b<8, 2>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_b1<16, 2>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<1, 1, 4, 1, 2, 2>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<2, 1, 4, 1, 2, 2>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<4, 1, 4, 1, 2, 2>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<8, 1, 4, 1, 1, 2>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a<8, 2, 4, 1, 1, 2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b<8, false, float>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b1<16, false, float>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_a<1, 1, 4, 1, 2, false, 0, float>)) != hipSuccess) return e;
@@ -297,6 +312,17 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         HIP_TRY(c, hipMemsetAsync(c->pay_mis.p, 0, sizeof(int) * n, s));
         hipLaunchKernelGGL(hadi_payoff_shape_kernel, dim3(grid1d(tot)), dim3(256), 0, s, L, d.n, ptr<double>(c->U0), ptr<int>(c->pay_mis));
     }
+    // American in the P representation (hadi_row_step, AMER == 2): every payoff of the batch must depend on s only.
+    // One small device-to-host copy per solve decides it.
+    bool amp = false;
+    const bool takes_small_path = c->use_small && !c->profiling && !cs && !f32 && (american ? pl.smem_small_am : pl.smem_small_eu) > 0;
+    if (american && c->use_amp && !cs && !takes_small_path) {
+        std::vector<int> mis(d.n);
+        HIP_TRY(c, hipMemcpyAsync(mis.data(), c->pay_mis.p, sizeof(int) * n, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        amp = true;
+        for (int k = 0; k < d.n; k++) amp = amp && mis[k] == 0;
+    }
     HIP_TRY(c, hipGetLastError());
 
     if (f32) {  // round the packed state to fp32; Y's identity padding rows must read as zeros
@@ -335,6 +361,12 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     // The whole time loop as a function of the stream, so it can be enqueued directly or captured.
     auto enqueue_loop = [&](hipStream_t q) -> int {
         for (int nstep = 1; nstep <= d.Nmax; nstep++) {
+            // P representation: the first step (the caller's initial U need not dominate the payoff) and dividend steps
+            // (the jump acts on U alone) run on the explicit (U, lambda_bar) pair, converted on the way in and out
+            const bool xstep = amp && (nstep == 1 || (have_div && div_step[nstep]));
+            if (xstep && nstep > 1)
+                hipLaunchKernelGGL(hadi_am_materialise_kernel, dim3(grid1d(tot)), dim3(256), 0, q, L, d.n, ptr<HadiInstPar>(c->ipar),
+                                   ptr<double>(c->U0), ptr<double>(c->U), ptr<double>(c->LAM), pl.pos_m1);
             if (have_div && div_step[nstep]) {  // device_solver.hpp:426-517: U_temp <- U, U <- interpolated jump
                 HIP_TRY(c, hipMemcpyAsync(c->UT.p, c->U.p, st, hipMemcpyDeviceToDevice, q));
                 const size_t npts = (size_t)d.n * L.nrows * (L.m1 + 1);
@@ -344,6 +376,16 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
             }
             if (prof) HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 0], q));
             auto row_pass = [&](const HadiSweepArgs &ar, int mode) {
+                if (amp && !xstep) {
+                    switch (L.B * 10 + L.G) {
+                        case 11: launch_pass_a_amp<1, 1, 1, 2>(pl, ar, nstep, q); break;
+                        case 21: launch_pass_a_amp<2, 1, 1, 2>(pl, ar, nstep, q); break;
+                        case 41: launch_pass_a_amp<4, 1, 1, 2>(pl, ar, nstep, q); break;
+                        case 81: launch_pass_a_amp<8, 1, 1, 1>(pl, ar, nstep, q); break;
+                        default: launch_pass_a_amp<8, 2, 1, 1>(pl, ar, nstep, q); break;
+                    }
+                    return;
+                }
                 if (f32) {  // fp32 state: shared-ring kernel for every shape
                     switch (L.B * 10 + L.G) {
                         case 11: launch_pass_a_f32<1, 1, 1, 2>(pl, ar, nstep, q); break;
@@ -379,6 +421,11 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                 // 1024-thread block leaves 128 VGPRs per lane, which only the single-buffer kernel fits
                 // (measured at 1024x512: 0.250 vs 0.382 ms/launch for the double-buffered code, which spills)
                 const dim3 g(pl.grid_b), b(pl.block_b);
+                if (amp && !xstep) {
+                    if (L.P <= 8) hipLaunchKernelGGL((hadi_pass_b<8, 2>), g, b, pl.smem_b, q, ar, nstep);
+                    else hipLaunchKernelGGL((hadi_pass_b1<16, 2>), g, b, pl.smem_b, q, ar, nstep);
+                    return;
+                }
                 if (f32) {
                     if (L.P <= 8) hipLaunchKernelGGL((hadi_pass_b<8, false, float>), g, b, pl.smem_b, q, ar, nstep);
                     else hipLaunchKernelGGL((hadi_pass_b1<16, false, float>), g, b, pl.smem_b, q, ar, nstep);
@@ -403,7 +450,13 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                 row_pass(av, 2);
                 col_pass(a);
             }
+            if (xstep)
+                hipLaunchKernelGGL(hadi_am_dematerialise_kernel, dim3(grid1d(tot)), dim3(256), 0, q, L, d.n, ptr<HadiInstPar>(c->ipar),
+                                   ptr<double>(c->U0), ptr<double>(c->U), ptr<double>(c->LAM));
         }
+        if (amp)  // explicit U and lambda_bar for the outputs
+            hipLaunchKernelGGL(hadi_am_materialise_kernel, dim3(grid1d(tot)), dim3(256), 0, q, L, d.n, ptr<HadiInstPar>(c->ipar),
+                               ptr<double>(c->U0), ptr<double>(c->U), ptr<double>(c->LAM), pl.pos_m1);
         return HADI_OK;
     };
 
@@ -463,12 +516,13 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     {
         char buf[256];
         char rowk[96];
-        if (f32) std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,EU,float> (tiles of %d rows, fp32 state)", L.B, L.G, pl.W, pl.NG, pl.PD, pl.R);
+        if (amp) std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,AM-P> (tiles of %d rows, no lambda_bar array)", L.B, L.G, pl.W, pl.NG, pl.PD, pl.R);
+        else if (f32) std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,EU,float> (tiles of %d rows, fp32 state)", L.B, L.G, pl.W, pl.NG, pl.PD, pl.R);
         else if (pl.use_strip && !cs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<%d,%s> (strips of %d rows)", L.B, american ? "AM" : "EU", pl.RS);
         else std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,%s%s> (tiles of %d rows)", L.B, L.G, pl.W, pl.NG, pl.PD,
                            american ? "AM" : "EU", cs ? ",CS" : "", pl.R);
         std::snprintf(buf, sizeof buf, "row pass %s; column pass %s<%d,%s> (%d chunks of %d rows, %d column tiles per block)", rowk,
-                      L.P <= 8 ? "hadi_pass_b" : "hadi_pass_b1", L.P <= 8 ? 8 : 16, american ? "AM" : "EU", L.P, HADI_LC, pl.btpw);
+                      L.P <= 8 ? "hadi_pass_b" : "hadi_pass_b1", L.P <= 8 ? 8 : 16, amp ? "AM-P" : american ? "AM" : "EU", L.P, HADI_LC, pl.btpw);
         c->last_path = buf;
     }
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
@@ -482,7 +536,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         {  // field by field: struct padding is not initialised
             const void *ptrs[] = {a.pay_mis, a.U, a.Y, a.LAM, a.U0, a.scoef, a.b2row, a.rowc, a.pb, a.rinv, a.ipar, a.R1, a.C2, av.U};
             const int ints[] = {a.L.m1, a.L.m2, a.L.B, a.L.G, a.L.P, a.n_inst, a.R, a.ntiles, a.ctiles, a.btpw, a.bgroups,
-                                a.american, a.pos_m1, d.scheme, d.prec, pl.use_strip, pl.RS, pl.sblocks, pl.grid_as, pl.grid_a, pl.grid_b, pl.block_b, pl.W, (int)pl.smem_a, (int)pl.smem_b};
+                                a.american, a.pos_m1, d.scheme, d.prec, (int)amp, pl.use_strip, pl.RS, pl.sblocks, pl.grid_as, pl.grid_a, pl.grid_b, pl.block_b, pl.W, (int)pl.smem_a, (int)pl.smem_b};
             put(ptrs, sizeof(ptrs));
             put(ints, sizeof(ints));
         }
@@ -860,6 +914,7 @@ int hadi_create(hadi_ctx **out, int device_id) {
     if (raise_all_lds_limits() != hipSuccess) { delete c; return HADI_ERR_HIP; }
     if (const char *e = std::getenv("HADI_NO_GRAPH")) c->use_graph = std::atoi(e) ? 0 : 1;
     if (const char *e = std::getenv("HADI_NO_SMALL")) c->use_small = std::atoi(e) ? 0 : 1;
+    if (const char *e = std::getenv("HADI_NO_AMP")) c->use_amp = std::atoi(e) ? 0 : 1;
     for (auto &e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete c; return HADI_ERR_HIP; }
     *out = reinterpret_cast<hadi_ctx *>(c);
@@ -903,6 +958,7 @@ int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value) {
     if (!c || !key) return HADI_ERR_INVALID;
     if (!std::strcmp(key, "graph")) c->use_graph = value ? 1 : 0;
     else if (!std::strcmp(key, "small_grid")) c->use_small = value ? 1 : 0;
+    else if (!std::strcmp(key, "american_p")) c->use_amp = value ? 1 : 0;
     else return fail(c, HADI_ERR_INVALID, "unknown tuning key '%s'", key);
     return HADI_OK;
 }

@@ -353,6 +353,11 @@ struct HadiRowCtxT {
     double *R1i, *C2i;   // instance bases of the Craig-Sneyd carry-over arrays (MODE 1 writes, MODE 2 reads)
     int lane, half, wrow, posL, posR, rowp;
     double dt, thdt, qd, half_rd, e_nm1, e_n;
+    // American without the lambda_bar array (AMER == 2, see hadi_row_step): LDS copy of the payoff row (it depends on s
+    // only), 1/dt, and which (lane, node) of this wavefront is i = m1 (lambda_bar is forced to 0 there), -1 if none
+    const double *payrow;
+    double inv_dt;
+    int m1_lane, m1_r;
     HADI_STAMP_ACC
 };
 typedef HadiRowCtxT<double> HadiRowCtx;
@@ -399,7 +404,11 @@ HADI_DEV HADI_FORCEINLINE void hadi_put_block(T *row, int half, int lane, const 
 // the corrector's A1 right-hand side is Y0~ + theta dt (...) = Y1rhs + dt/2 (A0 Y2 - A0 U): MODE 1 is a
 // Douglas row step that also stores R1 = Y1rhs - dt/2 A0U and C2; MODE 2 takes its rows from Y2, forms
 // R1 + dt/2 A0 Y2, runs the same A1 solve and adds C2 -- it never needs U, A1U or A2U again.
-template <int B, int G, bool AMER, bool LAST, int MODE = 0, class T = double>
+// AMER == 2: American in the P representation.  After the projection  U = max(P, U0),  lambda_bar = max(0, (U0 - P)/dt)
+// with  P = U_bar - dt lambda_bar_old  (device_solver.hpp:358-372 rewritten), so ONE array -- P, stored where U is --
+// carries both, provided the payoff U0 depends on s only (then it is a per-lane constant here).  The row pass rebuilds U on
+// the five stencil rows and lambda_bar on row j from P; no lambda_bar array is read or written by the sweep.
+template <int B, int G, int AMER, bool LAST, int MODE = 0, class T = double>
 HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool active, int j, const T *rm2, const T *rm1,
                                              const T *r0, const T *rp1, const T *rp2) {
     const int lane = c.lane, rowp = c.rowp, half = c.half;
@@ -429,12 +438,18 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
         const int b1r = b1el - (b1el / B) * B;
 
         // ---- column i = 0 (A0 and A1 rows are zero there; only A2 and the boundary act) ------------
-        const double c0 = (double)r0[c0slot];
-        const double a2c0 = a2l2 * (double)rm2[c0slot] + a2l1 * (double)rm1[c0slot] + a2m * c0 + a2u1 * (double)rp1[c0slot] +
-                            a2u2 * (double)rp2[c0slot];
+        double c0 = (double)r0[c0slot];
+        double c0m2 = (double)rm2[c0slot], c0m1 = (double)rm1[c0slot], c0p1 = (double)rp1[c0slot], c0p2 = (double)rp2[c0slot];
+        double lamc0 = 0.0;
+        if constexpr (AMER == 1) lamc0 = c.Li[(size_t)j * rowp + c0slot];
+        if constexpr (AMER == 2) {
+            const double pay0 = c.payrow[c0slot];
+            lamc0 = fmax(0.0, (pay0 - c0) * c.inv_dt);
+            c0 = fmax(c0, pay0); c0m2 = fmax(c0m2, pay0); c0m1 = fmax(c0m1, pay0); c0p1 = fmax(c0p1, pay0); c0p2 = fmax(c0p2, pay0);
+        }
+        const double a2c0 = a2l2 * c0m2 + a2l1 * c0m1 + a2m * c0 + a2u1 * c0p1 + a2u2 * c0p2;
         const double b1c0 = (b1col == 0) ? b1val : 0.0;
         const double b2c0 = LAST ? c.b2r[c0slot] : 0.0;
-        const double lamc0 = AMER ? c.Li[(size_t)j * rowp + c0slot] : 0.0;
         double y0c0 = c0 + dt * (a2c0 + (b1c0 + b2c0) * e_nm1 + lamc0);
         y0c0 = y0c0 + thdt * (b1c0 * e_n - (0.0 + b1c0 * e_nm1));
         double c2c0 = thdt * (b2c0 * e_n - (a2c0 + b2c0 * e_nm1));
@@ -455,31 +470,56 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
         // ---- explicit operators.  A0 = (s-derivative) o (v-derivative): first the v-combination
         // t = wm u(j-1) + wz u(j) + wp u(j+1) on the block and its two s-neighbours, then the B-weights.
         double u0[B], tt[B];
+        double lam[B], pay[B];
+        if constexpr (AMER == 2) hadi_get_block<B, G>(c.payrow, half, lane, pay);
         {
             double um[B], up[B], u2[B];
             hadi_get_block<B, G, T>(r0, half, lane, u0);
             hadi_get_block<B, G, T>(rm1, half, lane, um);
             hadi_get_block<B, G, T>(rp1, half, lane, up);
+            if constexpr (AMER == 2) {
+#pragma unroll
+                for (int r = 0; r < B; r++) {
+                    lam[r] = fmax(0.0, (pay[r] - u0[r]) * c.inv_dt);  // from the raw P of row j
+                    if (lane == c.m1_lane && r == c.m1_r) lam[r] = 0.0;
+                    u0[r] = fmax(u0[r], pay[r]);
+                    um[r] = fmax(um[r], pay[r]);
+                    up[r] = fmax(up[r], pay[r]);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < B; r++) {
                 tt[r] = wm * um[r] + wz * u0[r] + wp * up[r];
                 A2U[r] = a2l1 * um[r] + a2m * u0[r] + a2u1 * up[r];
             }
             hadi_get_block<B, G, T>(rm2, half, lane, u2);
+            if constexpr (AMER == 2) {
+#pragma unroll
+                for (int r = 0; r < B; r++) u2[r] = fmax(u2[r], pay[r]);
+            }
 #pragma unroll
             for (int r = 0; r < B; r++) A2U[r] = fma(a2l2, u2[r], A2U[r]);
             hadi_get_block<B, G, T>(rp2, half, lane, u2);
+            if constexpr (AMER == 2) {
+#pragma unroll
+                for (int r = 0; r < B; r++) u2[r] = fmax(u2[r], pay[r]);
+            }
 #pragma unroll
             for (int r = 0; r < B; r++) A2U[r] = fma(a2u2, u2[r], A2U[r]);
         }
         const double cb1 = dt * e_nm1 + thdt * (e_n - e_nm1);
-        const double u0L = (double)r0[c.posL], u0R = (double)r0[c.posR];
-        const double tL = wm * (double)rm1[c.posL] + wz * u0L + wp * (double)rp1[c.posL];
-        const double tR = wm * (double)rm1[c.posR] + wz * u0R + wp * (double)rp1[c.posR];
+        double u0L = (double)r0[c.posL], u0R = (double)r0[c.posR];
+        double m1L = (double)rm1[c.posL], m1R = (double)rm1[c.posR], p1L = (double)rp1[c.posL], p1R = (double)rp1[c.posR];
+        if constexpr (AMER == 2) {
+            const double payL = c.payrow[c.posL], payR = c.payrow[c.posR];
+            u0L = fmax(u0L, payL); m1L = fmax(m1L, payL); p1L = fmax(p1L, payL);
+            u0R = fmax(u0R, payR); m1R = fmax(m1R, payR); p1R = fmax(p1R, payR);
+        }
+        const double tL = wm * m1L + wz * u0L + wp * p1L;
+        const double tR = wm * m1R + wz * u0R + wp * p1R;
 
         HADI_STAMP(1);  // LDS rows -> tt, A2U
-        double lam[B];
-        if constexpr (AMER) hadi_get_block<B, G>(c.Li + (size_t)j * rowp, half, lane, lam);
+        if constexpr (AMER == 1) hadi_get_block<B, G>(c.Li + (size_t)j * rowp, half, lane, lam);
         if constexpr (LAST) hadi_get_block<B, G>(c.b2r, half, lane, b2v);
         if constexpr (MODE == 2) {
             hadi_get_block<B, G>(c.R1i + (size_t)j * rowp, half, lane, r1v);
@@ -513,7 +553,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
             // entry of this v-row (a single node) contributes b1 * cb1, cb1 = dt e_{n-1} + theta dt (e_n - e_{n-1})
             double S = A0U + A1U + A2U[r];
             if constexpr (LAST) S += b2v[r] * e_nm1;
-            if constexpr (AMER) S += lam[r];
+            if constexpr (AMER != 0) S += lam[r];
             double y = fma(dt, S, u0[r]);
             y = fma(-thdt, A1U, y);
             y = fma(b1h, cb1, y);
@@ -703,7 +743,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_wait_vmcnt(int n) {
 // Every shape runs NG = 1 (hadi_plan.h: two groups behind one barrier measured slower); PD = 1 at 8 nodes per lane
 // (two 4-wave blocks per CU), 2 below.  Large batches at 8 nodes per lane use hadi_pass_a_strip instead.
 // T = float: fp32-state sweep (a.U / a.Y then point to float arrays of the same element layout; European Douglas only).
-template <int B, int G, int W, int NG, int PD, bool AMER, int MODE = 0, class T = double>
+template <int B, int G, int W, int NG, int PD, int AMER, int MODE = 0, class T = double>
 __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : 4)) hadi_pass_a(HadiSweepArgs a, int n) {
     static_assert(sizeof(T) == 8 || (!AMER && MODE == 0), "the fp32-state sweep covers the European Douglas step only");
     HADI_DYN_SMEM(double, smem);
@@ -735,7 +775,7 @@ __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : 4)) hadi_pass_a
     c.e_n = exp(ip.r_f * ip.dt * n);          // device_solver.hpp:246
     const T *__restrict__ Ub = reinterpret_cast<const T *>(a.U) + (size_t)inst * a.L.inst_stride;
     c.Yi = reinterpret_cast<T *>(a.Y) + (size_t)inst * a.L.inst_stride;
-    c.Li = AMER ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
+    c.Li = (AMER == 1) ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
     c.b2r = a.b2row + (size_t)inst * rowp;
     c.R1i = MODE ? a.R1 + (size_t)inst * a.L.inst_stride : nullptr;
     c.C2i = MODE ? a.C2 + (size_t)inst * a.L.inst_stride : nullptr;
@@ -764,6 +804,19 @@ __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : 4)) hadi_pass_a
         const int tl = threadIdx.x - grp * 64 * W * G;
         for (int e = tl; e < (j1 - j0) * HADI_RCL; e += 64 * W * G) rtab[e] = rg[(e / HADI_RCL) * HADI_RC + e % HADI_RCL];
         c.rowc = rtab;
+        c.payrow = nullptr; c.inv_dt = 0.0; c.m1_lane = -1; c.m1_r = -1;
+        if constexpr (AMER == 2) {  // payoff row (v-row 0 of the packed payoff; it depends on s only) after the tables
+            double *prow = coef + 4 * 64 * B * G + NG * 4 * W + (size_t)NG * a.R * HADI_RCL;
+            const double *__restrict__ pg = a.U0 + (size_t)inst * a.L.inst_stride;
+            for (int e = threadIdx.x; e < rowp; e += NT) prow[e] = pg[e];
+            c.payrow = prow;
+            c.inv_dt = 1.0 / ip.dt;
+            const int e1 = a.L.m1 - 1;  // node i = m1 is element m1-1 of the row's 64*B*G interior nodes
+            if (e1 / (64 * B) == half) {
+                c.m1_lane = (e1 - half * 64 * B) / B;
+                c.m1_r = (e1 - half * 64 * B) % B;
+            }
+        }
     }
 
     const int iters = (j1 > j0) ? (j1 - j0 + W - 1) / W : 0;  // this group's iterations
@@ -1179,6 +1232,7 @@ struct HadiPassBCtx {
     double *Li;         // instance base of lambda_bar (American)
     const double *P0i;  // instance base of the payoff (American)
     int pay1d;          // the payoff does not depend on v: one load per column instead of one per node
+    double inv_dt;      // 1/dt (P representation)
     double tab[5];      // this chunk's table (33 rows x 9 scalars) spread over the lanes: lane l holds entries l + 64 q
     const double *Ri;   // this wavefront's four rows of the reduced inverse in LDS, [4P][4]: for column m the
                         // coefficients of (left-neighbour last two, right-neighbour first two)
@@ -1291,9 +1345,9 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve(const HadiPassBCtx &c, int parity, 
 // Stores the solved tile `ctile` (with the Ikonen-Toivanen projection for American).  RELOAD: every row's register
 // is refilled with the same row of tile `ctile + 1` right behind its store, so one register buffer serves both
 // tiles and the loads of the next tile are in flight as soon as the stores have been issued.
-template <bool AMER, bool RELOAD, class T = double>
+template <int AMER, bool RELOAD, class T = double>
 HADI_DEV HADI_FORCEINLINE void hadi_pb_store(const HadiPassBCtx &c, int ctile, double (&y)[HADI_LC]) {
-    static_assert(sizeof(T) == 8 || !AMER, "the fp32-state sweep is European only");
+    static_assert(sizeof(T) == 8 || AMER == 0, "the fp32-state sweep is European only");
     constexpr unsigned ES = (unsigned)sizeof(T);
     HADI_STAMP_DECL(c.stamp_acc_)
     const int coln = (ctile + 1) * 64 + c.lane;
@@ -1302,7 +1356,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_store(const HadiPassBCtx &c, int ctile, d
     const bool valid = col < c.rowp;
     const int colc = valid ? col : c.rowp - 1;
     const size_t base = (size_t)c.ja * c.rowp + colc;
-    if constexpr (!AMER) {
+    if constexpr (AMER == 0) {
         const unsigned voff = (unsigned)colc * ES;
         const unsigned row0 = (unsigned)c.ja * (unsigned)c.rowp * ES, rstride = (unsigned)c.rowp * ES;
         if constexpr (RELOAD) {
@@ -1329,21 +1383,29 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_store(const HadiPassBCtx &c, int ctile, d
         // A call / put payoff depends on s only (every driver of the reference builds U_0 that way,
         // heston_calibration.cpp:183-192): then one load per column replaces 33 (8 of the 40 B per node of this pass).
         // Identity padding rows then see the payoff instead of 0: their results are never read.
-        const bool pay1d = c.pay1d != 0;
+        const bool pay1d = (AMER == 2) || c.pay1d != 0;
         const double pay_col = pay1d ? c.P0i[colc] : 0.0;
 #pragma unroll
         for (int k = 0; k < HADI_LC; k++) {
             const size_t off = (size_t)k * c.rowp;
             const double U_bar = y[k];
-            const double lamv = Lb[off];
-            double pay = pay_col;
-            if (!pay1d) pay = P0[off];
-            const double un = fmax(U_bar - dt * lamv, pay);
-            double ln = fmax(0.0, lamv + (pay - U_bar) / dt);
-            if (is_smax) ln = 0.0;
-            if (valid) {
-                dst[off] = un;
-                Lb[off] = ln;
+            if constexpr (AMER == 2) {
+                // P representation (see hadi_row_step): lambda_bar_old = max(0, (U0 - P_old)/dt), P_new = U_bar - dt lambda_bar_old.
+                // One load and one store per node, both on the array that otherwise holds U; no lambda_bar array.
+                double lamo = fmax(0.0, (pay_col - dst[off]) * c.inv_dt);
+                if (is_smax) lamo = 0.0;
+                if (valid) dst[off] = U_bar - dt * lamo;
+            } else {
+                const double lamv = Lb[off];
+                double pay = pay_col;
+                if (!pay1d) pay = P0[off];
+                const double un = fmax(U_bar - dt * lamv, pay);
+                double ln = fmax(0.0, lamv + (pay - U_bar) / dt);
+                if (is_smax) ln = 0.0;
+                if (valid) {
+                    dst[off] = un;
+                    Lb[off] = ln;
+                }
             }
             if constexpr (RELOAD) y[k] = hadi_buf_load(c.Yb, voffn, row0 + (unsigned)k * rstride);
         }
@@ -1351,7 +1413,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_store(const HadiPassBCtx &c, int ctile, d
     HADI_STAMPB(22);  // projection + store issue
 }
 
-template <bool AMER, class T = double>
+template <int AMER, class T = double>
 HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ctile, int parity, double (&y)[HADI_LC],
                                                    int younger = 0) {
     hadi_pb_solve(c, parity, y, younger);
@@ -1361,7 +1423,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ct
 // Dynamic LDS: P * (2*4*64 + 16*P) doubles (two interface-exchange buffers, each wavefront's four rows of the reduced
 // inverse); the chunk tables live in registers (HADI_PB_T).
 // MAXP only sets the launch bound (register budget): 8 -> 512 threads, 16 -> 1024 threads.
-template <int MAXP, bool AMER, class T = double>
+template <int MAXP, int AMER, class T = double>
 __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n) {
     HADI_DYN_SMEM(double, smem);
     HadiPassBCtx c;
@@ -1383,9 +1445,10 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
     c.Ui = a.U + (size_t)inst * a.L.inst_stride;
     c.Yb = hadi_make_buf(reinterpret_cast<const T *>(a.Y) + (size_t)inst * a.L.inst_stride, (size_t)a.L.inst_stride * sizeof(T));
     c.Ub = hadi_make_buf(reinterpret_cast<const T *>(a.U) + (size_t)inst * a.L.inst_stride, (size_t)a.L.inst_stride * sizeof(T));
-    c.Li = AMER ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
+    c.Li = (AMER == 1) ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
     c.P0i = AMER ? a.U0 + (size_t)inst * a.L.inst_stride : nullptr;
     c.pay1d = AMER ? (a.pay_mis[inst] == 0) : 0;
+    c.inv_dt = 1.0 / ip.dt;
     c.american = a.american;
     c.pos_m1 = a.pos_m1;
     c.dt = ip.dt;
@@ -1432,7 +1495,7 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
 // 33-row register buffers (the double-buffered code spills 650 B per lane there).  The next tile is loaded into the
 // registers of the current one row by row, right behind the stores.  Measured on MI355X: 1024x512 grid 0.250 ms per
 // launch against 0.382; at 512x256 (P = 8) the double-buffered kernel above wins, 0.144 against 0.206.
-template <int MAXP, bool AMER, class T = double>
+template <int MAXP, int AMER, class T = double>
 __global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, int n) {
     HADI_DYN_SMEM(double, smem);
     HadiPassBCtx c;
@@ -1454,9 +1517,10 @@ __global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, in
     c.Ui = a.U + (size_t)inst * a.L.inst_stride;
     c.Yb = hadi_make_buf(reinterpret_cast<const T *>(a.Y) + (size_t)inst * a.L.inst_stride, (size_t)a.L.inst_stride * sizeof(T));
     c.Ub = hadi_make_buf(reinterpret_cast<const T *>(a.U) + (size_t)inst * a.L.inst_stride, (size_t)a.L.inst_stride * sizeof(T));
-    c.Li = AMER ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
+    c.Li = (AMER == 1) ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
     c.P0i = AMER ? a.U0 + (size_t)inst * a.L.inst_stride : nullptr;
     c.pay1d = AMER ? (a.pay_mis[inst] == 0) : 0;
+    c.inv_dt = 1.0 / ip.dt;
     c.american = a.american;
     c.pos_m1 = a.pos_m1;
     c.dt = ip.dt;
@@ -1567,6 +1631,7 @@ __global__ void __launch_bounds__(64 * W) hadi_small_kernel(HadiSweepArgs a, Had
     c.rowc = rtab; c.j0 = 0;
     c.b2r = a.b2row + (size_t)inst * rowp;
     c.coef = coef; c.xch = nullptr; c.R1i = nullptr; c.C2i = nullptr;
+    c.payrow = nullptr; c.inv_dt = 0.0; c.m1_lane = -1; c.m1_r = -1;
     {
         const int ifirst = 1 + B * lane;
         c.posL = hadi_pos(B, G, ifirst - 1);
@@ -1805,6 +1870,38 @@ __global__ void __launch_bounds__(256) hadi_narrow_kernel(const double *__restri
 }
 __global__ void __launch_bounds__(256) hadi_widen_kernel(const float *__restrict__ src, double *__restrict__ dst, size_t n) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) dst[e] = (double)src[e];
+}
+
+// ------------------------------------------------------------------------------------------------
+// American, P representation <-> explicit (U, lambda_bar), elementwise on the packed arrays (payoff = its v-row 0):
+//   materialise:    U = max(P, U0),  lambda_bar = max(0, (U0 - P)/dt)  (0 at i = m1)
+//   dematerialise:  P = lambda_bar > 0 ? U0 - dt lambda_bar : U        (after a projection lambda_bar > 0 implies U = U0)
+// Used for the first step (the caller's initial U need not dominate the payoff), around dividend steps (the jump acts
+// on U alone) and for the outputs.
+__global__ void __launch_bounds__(256) hadi_am_materialise_kernel(HadiLayout L, int n_inst, const HadiInstPar *__restrict__ ipar,
+                                                                  const double *__restrict__ P0, double *__restrict__ UP,
+                                                                  double *__restrict__ LAM, int pos_m1) {
+    const size_t per = (size_t)L.nrows * L.rowp, total = (size_t)n_inst * per;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t inst = e / per, r = e - inst * per;
+        const int x = (int)(r % L.rowp);
+        const double pay = P0[inst * L.inst_stride + x], p = UP[inst * L.inst_stride + r];
+        double lam = fmax(0.0, (pay - p) / ipar[inst].dt);
+        if (x == pos_m1) lam = 0.0;
+        UP[inst * L.inst_stride + r] = fmax(p, pay);
+        LAM[inst * L.inst_stride + r] = lam;
+    }
+}
+__global__ void __launch_bounds__(256) hadi_am_dematerialise_kernel(HadiLayout L, int n_inst, const HadiInstPar *__restrict__ ipar,
+                                                                    const double *__restrict__ P0, double *__restrict__ UP,
+                                                                    const double *__restrict__ LAM) {
+    const size_t per = (size_t)L.nrows * L.rowp, total = (size_t)n_inst * per;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t inst = e / per, r = e - inst * per;
+        const int x = (int)(r % L.rowp);
+        const double lam = LAM[inst * L.inst_stride + r];
+        if (lam > 0.0) UP[inst * L.inst_stride + r] = P0[inst * L.inst_stride + x] - ipar[inst].dt * lam;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

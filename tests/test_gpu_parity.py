@@ -91,6 +91,28 @@ def test_american_dividend_variants_vs_oracle(solver, variant, name, m1, m2, N, 
         assert np.abs(lam - lamo).max() <= 1e-8 * max(1.0, np.abs(lamo).max())
 
 
+@pytest.mark.parametrize("american_p", [1, 0], ids=["P", "explicit"])
+@pytest.mark.parametrize("variant,name", [(H.AM, "AM"), (H.AM_DIV, "AM_DIV")])
+@pytest.mark.parametrize("m1,m2,N,n", [(100, 50, 30, 2), (256, 128, 25, 3), (512, 256, 12, 2), (700, 300, 6, 1), (1024, 512, 4, 1)])
+def test_american_p_representation_and_explicit_pair(solver, american_p, variant, name, m1, m2, N, n):
+    """American sweeps store P = U_bar - dt lambda_bar_old in place of U and rebuild U = max(P, U0), lambda_bar =
+    max(0, (U0 - P)/dt) on the fly (no lambda_bar array) whenever the payoff depends on s only; the first step and
+    dividend steps run on the explicit (U, lambda_bar) pair.  Both ways must give the oracle's U and lambda_bar; r_f != 0
+    and N = 25..30 put several dividend steps and conversions into the loop."""
+    strikes = Cm.strikes_for(n)
+    solver.set_tuning("american_p", american_p)
+    try:
+        grids, U0, U, lam = _hadi_solve(solver, m1, m2, N, strikes, variant, r_f=0.01, want_lambda=True)
+        d = solver.describe_last_sweep()
+    finally:
+        solver.set_tuning("american_p", 1)
+    assert ("AM-P" in d) == bool(american_p)
+    p = Cm.oracle_params(m1, m2, N, name, r_f=0.01)
+    Uo, lo, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0, want_lambda=True)
+    _assert_field(U, Uo)
+    assert np.abs(lam - lo).max() <= 1e-8 * max(1.0, np.abs(lo).max())
+
+
 @pytest.mark.parametrize("m1,m2,N,n", [(256, 128, 10, 3), (512, 256, 5, 2), (1024, 512, 3, 1), (50, 25, 10, 2)])
 def test_american_with_a_payoff_that_depends_on_v(solver, m1, m2, N, n):
     """The column pass loads a payoff that depends on s only (every driver of the reference) once per column; a general
@@ -509,7 +531,11 @@ def test_strip_row_pass_vs_oracle(solver, monkeypatch, variant, name, m1, m2, N,
     that every strip geometry (short strips, ragged last strip, one block or several per instance) meets the oracle."""
     monkeypatch.setenv("HADI_TUNE_STRIP", "1")
     strikes = Cm.strikes_for(n)
-    grids, U0, U, lam = _hadi_solve(solver, m1, m2, N, strikes, variant, r_f=0.01, want_lambda=(variant != H.EU))
+    solver.set_tuning("american_p", 0)  # the P representation runs on the shared-ring kernel; here: the strips' explicit path
+    try:
+        grids, U0, U, lam = _hadi_solve(solver, m1, m2, N, strikes, variant, r_f=0.01, want_lambda=(variant != H.EU))
+    finally:
+        solver.set_tuning("american_p", 1)
     assert "hadi_pass_a_strip" in solver.describe_last_sweep()
     p = Cm.oracle_params(m1, m2, N, name, r_f=0.01)
     Uo, lo, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0, want_lambda=True)
@@ -574,7 +600,7 @@ def test_describe_last_sweep_names_the_kernels(solver):
     assert "hadi_small_kernel" in solver.describe_last_sweep()
     _hadi_solve(solver, 128, 64, 2, [100.0], H.AM)
     d = solver.describe_last_sweep()
-    assert "hadi_pass_a<2,1" in d and "hadi_pass_b<8,AM>" in d
+    assert "hadi_pass_a<2,1" in d and "AM-P" in d and "hadi_pass_b<8,AM-P>" in d
     _hadi_solve(solver, 512, 256, 2, Cm.strikes_for(256), H.EU)   # enough rows per wavefront for the strip kernel
     d = solver.describe_last_sweep()
     assert "hadi_pass_a_strip<8,EU> (strips of 33 rows)" in d and "hadi_pass_b<8,EU>" in d
