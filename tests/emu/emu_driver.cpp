@@ -65,6 +65,26 @@ static int run_sweep_f32(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
     return 0;
 }
 
+// American, P representation (scheme == 3 in emu_solve): same kernels as hadi_api.hip picks
+template <int B, int G, int NG, int PD>
+static void run_pass_a_amp(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
+    emu::launch(pl.grid_a, 64 * pl.W * G * NG, [&]() { hadi_pass_a<B, G, 4, NG, PD, 2>(a, n); },
+                pl.smem_a + (size_t)pl.L.rowp * sizeof(double));
+}
+static int run_sweep_amp(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
+    switch (pl.L.B * 10 + pl.L.G) {
+        case 11: run_pass_a_amp<1, 1, 1, 2>(pl, a, n); break;
+        case 21: run_pass_a_amp<2, 1, 1, 2>(pl, a, n); break;
+        case 41: run_pass_a_amp<4, 1, 1, 2>(pl, a, n); break;
+        case 81: run_pass_a_amp<8, 1, 1, 1>(pl, a, n); break;
+        case 82: run_pass_a_amp<8, 2, 1, 1>(pl, a, n); break;
+        default: return 2;
+    }
+    if (pl.L.P <= 8) emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b<8, 2>(a, n); }, pl.smem_b);
+    else emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b1<16, 2>(a, n); }, pl.smem_b);
+    return 0;
+}
+
 static void run_col_pass(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
     if (pl.L.P <= 8) {  // same choice as hadi_api.hip
         if (a.american) emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b<8, true>(a, n); }, pl.smem_b);
@@ -93,7 +113,8 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
     const HadiLayout &L = pl.L;
     const int american = variant & 1, dividend = (variant >> 1) & 1;
     const size_t st = (size_t)L.inst_stride * n_inst;
-    const bool cs = scheme == 1, f32 = scheme == 2;
+    const bool cs = scheme == 1, f32 = scheme == 2, amp = scheme == 3;
+    if (amp && !american) return 3;
     if (f32 && (american || dividend)) return 3;
     std::vector<double> dV(cs ? st : 0), dR1(cs ? st : 0), dC2(cs ? st : 0);
     std::vector<double> dU(st), dY(st, 0.0), dLAM(american ? st : 0), dU0(american ? st : 0), dUT(dividend ? st : 0);
@@ -170,6 +191,13 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
         return 0;
     }
     for (int n = 1; n <= N; n++) {
+        const bool xstep = amp && (n == 1 || (dividend && flags[n - 1] >= 0));  // explicit (U, lambda_bar) step, as in hadi_api.hip
+        if (xstep && n > 1)
+            emu::launch(8, 64, [&]() { hadi_am_materialise_kernel(L, n_inst, ipar.data(), dU0.data(), dU.data(), dLAM.data(), pl.pos_m1); });
+        if (amp && !xstep) {
+            if (run_sweep_amp(pl, a, n)) return 2;
+            continue;
+        }
         if (dividend && flags[n - 1] >= 0) {  // device_solver.hpp:426-517 (host builds the step table, kernel applies)
             dUT = dU;
             emu::launch(8, 64, [&]() {
@@ -182,7 +210,11 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
             run_row_pass(pl, av, n, 2);
             run_col_pass(pl, a, n);
         }
+        if (xstep)
+            emu::launch(8, 64, [&]() { hadi_am_dematerialise_kernel(L, n_inst, ipar.data(), dU0.data(), dU.data(), dLAM.data()); });
     }
+    if (amp)
+        emu::launch(8, 64, [&]() { hadi_am_materialise_kernel(L, n_inst, ipar.data(), dU0.data(), dU.data(), dLAM.data(), pl.pos_m1); });
     emu::launch(8, 64, [&]() { hadi_unpack_kernel(L, n_inst, dU.data(), U); });
     if (american && lam_out) emu::launch(8, 64, [&]() { hadi_unpack_kernel(L, n_inst, dLAM.data(), lam_out); });
     return 0;

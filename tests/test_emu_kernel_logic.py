@@ -36,7 +36,8 @@ def emu():
 
 
 def _run(emu, m1, m2, N, strikes, variant, target_waves, r_f=0.0, small=0, scheme=0):
-    """scheme: 0 Douglas, 1 Craig-Sneyd, 2 Douglas with the state kept in fp32 between the passes."""
+    """scheme: 0 Douglas, 1 Craig-Sneyd, 2 Douglas with the state kept in fp32 between the passes, 3 Douglas with the
+    American P representation (no lambda_bar array; explicit pair on step 1 and on dividend steps)."""
     n = len(strikes)
     vs, vv, ds, dv, U0 = Cm.oracle_grids(m1, m2, strikes)
     p = Cm.oracle_params(m1, m2, N, variant, r_f=r_f)
@@ -101,6 +102,15 @@ def test_fp32_state_sweep(emu):
     _run(emu, 300, 40, 2, [100.0], O.EU, 8, scheme=2)
     _run(emu, 600, 12, 2, [100.0], O.EU, 8, scheme=2)
     _run(emu, 300, 270, 2, [100.0], O.EU, 1, scheme=2)
+
+
+def test_american_p_representation(emu):
+    # one node per lane, 4 nodes per lane with dividends (explicit steps in between), two wavefronts per row,
+    # the single-buffer column pass
+    _run(emu, 40, 12, 4, [100.0, 92.0], O.AM, 4, r_f=0.01, scheme=3)
+    _run(emu, 200, 60, 12, [100.0], O.AM_DIV, 8, scheme=3)
+    _run(emu, 530, 10, 3, [100.0], O.AM, 8, scheme=3)
+    _run(emu, 280, 265, 2, [97.0], O.AM, 1, scheme=3)
 
 
 def test_two_waves_per_row_split_solve(emu):
