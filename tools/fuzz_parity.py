@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Diagnostic (needs a GPU): random grid shapes / batch sizes / variants / parameters through libhadi against the oracle."""
+import os, sys, random
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import pde_based_heston_solver_gpu_accelerated_amd as H
+from oracle import oracle as O
+import common as Cm
+rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+s = H.HestonADI(0)
+worst = 0.0
+for c in range(cases):
+    m1 = rng.choice([rng.randint(20, 64), rng.randint(65, 128), rng.randint(129, 256), rng.randint(257, 512), rng.randint(513, 800)])
+    m2 = rng.randint(8, min(m1, 300))
+    N = rng.randint(2, 12)
+    n = rng.choice([1, 2, 3, 5, 9])
+    variant = rng.choice([H.EU, H.AM, H.DIV, H.AM_DIV])
+    name = {H.EU: "EU", H.AM: "AM", H.DIV: "DIV", H.AM_DIV: "AM_DIV"}[variant]
+    r_f = rng.choice([0.0, 0.01, 0.03])
+    model = (rng.uniform(-0.95, 0.5), rng.uniform(0.1, 0.8), rng.uniform(0.3, 4.0), rng.uniform(0.01, 0.2))
+    strikes = [rng.uniform(80, 120) for _ in range(n)]
+    grids = H.GridViewsBatch.for_strikes(m1, m2, Cm.S_0, Cm.V_0, strikes); U0 = grids.call_payoff(strikes)
+    U, lam = U0.copy(), np.zeros_like(U0)
+    div = H.Dividends(*Cm.DIVS) if variant in (H.DIV, H.AM_DIV) else None
+    if rng.random() < 0.3: s.set_tuning("american_p", 0)
+    if rng.random() < 0.3: os.environ["HADI_TUNE_STRIP"] = "1"
+    try:
+        s.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, r_f, *model, grids, U, variant=variant, U_0=U0,
+                          lambda_bar=lam if variant in (H.AM, H.AM_DIV) else None, dividends=div)
+        path = s.describe_last_sweep()
+    finally:
+        s.set_tuning("american_p", 1); os.environ.pop("HADI_TUNE_STRIP", None)
+    p = O.make_params(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, r_f, *model, variant, Cm.DIVS if div is not None else None)
+    Uo, lo, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0, want_lambda=True)
+    err = np.abs(U - Uo).max() / np.abs(Uo).max()
+    lerr = 0.0 if lo is None else np.abs(lam - lo).max() / max(1.0, np.abs(lo).max())
+    worst = max(worst, err)
+    ok = np.isfinite(err) and err < 1e-10 and lerr < 1e-8
+    print("%s %3d %s m1=%d m2=%d N=%d n=%d r_f=%.2f err=%.2e lam_err=%.2e | %s" % ("ok " if ok else "BAD", c, name, m1, m2, N, n, r_f, err, lerr, path[:70]))
+    if not ok: sys.exit(1)
+print("all ok, worst field error %.2e" % worst)
