@@ -1,0 +1,19 @@
+import os, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np, torch
+import pde_based_heston_solver_gpu_accelerated_amd as H
+dev = torch.device("cuda:0"); s = H.HestonADI(0)
+m1, m2, N = 512, 256, 1000
+g = H.GridViewsBatch.for_strikes(m1, m2, 100.0, 0.04, [100.0]); U0h = g.call_payoff([100.0])
+gd = g.to(dev); U0 = torch.from_numpy(U0h).to(dev); U = torch.empty_like(U0)
+for prof in (False, True, False):
+    s.set_profiling(prof)
+    best = 1e9
+    for _ in range(3):
+        U.copy_(U0); torch.cuda.synchronize(); t = time.perf_counter()
+        s.DO_timestepping(m1, m2, N, 1.0 / N, 0.8, 0.025, 0.0, -0.9, 0.3, 1.5, 0.04, gd, U)
+        best = min(best, time.perf_counter() - t)
+    tm = s.timing()
+    print("profiling" if prof else "plain", "wall %.2f ms" % (best * 1e3), {k: round(v, 3) for k, v in tm.items() if k.endswith("_ms")}, s.describe_last_sweep())
+for env in ("HADI_NO_GRAPH",):
+    pass
