@@ -140,8 +140,10 @@ const char *hadi_status_string(int status);
 int hadi_version(void);
 int hadi_set_profiling(hadi_ctx *ctx, int enabled);
 int hadi_get_timing(const hadi_ctx *ctx, hadi_timing *out);
-/* Execution-path switches (results are unaffected): "small_grid" = LDS-resident one-launch path for grids that
- * fit in LDS (default 1), "graph" = hipGraph replay of the time loop for small batches (default 1). */
+/* Execution-path switches (results agree to round-off): "small_grid" = LDS-resident one-launch path for grids that fit
+ * in LDS (default 1), "graph" = hipGraph replay of the time loop for small batches (default 1), "american_p" = American
+ * sweeps keep P = U_bar - dt*lambda_bar in place of U and no lambda_bar array whenever every payoff of the batch depends
+ * on s only (default 1; 0 = always the explicit (U, lambda_bar) pair). */
 int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value);
 /* Device the handle runs on: name, CU count, gcn arch string (for bench reports). */
 int hadi_device_info(const hadi_ctx *ctx, char *name, int name_len, int *compute_units, char *arch, int arch_len);
