@@ -72,10 +72,28 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         torch.cuda.set_device(dev_index)
+        collective = args.backend
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+            # RCCL carries the only collectives of this bench (barrier + MAX of one double around the timed region; the data
+            # path has none).  If RCCL cannot come up on this node the numbers are still worth having: every rank then
+            # falls back to gloo for those two calls and the JSON line says so.
+            try:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+                probe = torch.ones(1, device=torch.device("cuda", dev_index))
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+            except Exception as exc:  # noqa: BLE001
+                collective = "gloo (rccl unavailable: %s)" % str(exc).splitlines()[0][:120]
+                try:
+                    dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                dist.init_process_group(backend="gloo")
+                args.backend = "gloo"
         else:
             dist.init_process_group(backend=args.backend)
+    else:
+        collective = None
     n_gpus = world if world > 1 else 1
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
@@ -213,7 +231,8 @@ def main():
             "config": {"workload": "C2: European calls, Heston Douglas ADI, %dx%d grid, %d time steps, %d strikes per GPU "
                                    "(85..115), HBM-resident inputs" % (m1, m2, N, n_loc),
                        "m1": m1, "m2": m2, "timesteps": N, "instances_per_gpu": n_loc, "instances_total": n_glob,
-                       "parallelism": "instances sharded over %d GPU(s), no collective" % n_gpus},
+                       "parallelism": "instances sharded over %d GPU(s), no data-path collective" % n_gpus,
+                       "timing_collective": collective},
             "effective_GBps": value * B_ALG_STEP / 1e9,
             "sweep_only_point_steps_per_s": float(n_loc) * m * N * args.steps / (sweep_ms * 1e-3),
             "roofline": roofline,
