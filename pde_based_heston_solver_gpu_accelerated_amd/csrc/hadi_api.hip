@@ -219,6 +219,7 @@ hipError_t raise_all_lds_limits() {
     if ((e = raise_lds_limit(hadi_pass_a<4, 1, 4, 1, 2, 2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_a<8, 1, 4, 1, 1, 2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_a<8, 2, 4, 1, 1, 2>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a_strip<8, false, float>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b<8, false, float>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b1<16, false, float>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_a<1, 1, 4, 1, 2, false, 0, float>)) != hipSuccess) return e;
@@ -386,7 +387,12 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                     }
                     return;
                 }
-                if (f32) {  // fp32 state: shared-ring kernel for every shape
+                if (f32 && pl.use_strip) {  // fp32 state, 8 nodes per lane, large batch: strips with a ring of floats
+                    const size_t smem = (size_t)8 * 4 * L.rowp * sizeof(float) + (size_t)4 * 64 * L.B * sizeof(double);
+                    hipLaunchKernelGGL((hadi_pass_a_strip<8, false, float>), dim3(pl.grid_as), dim3(512), smem, q, ar, nstep);
+                    return;
+                }
+                if (f32) {  // fp32 state: shared-ring kernel for the other shapes
                     switch (L.B * 10 + L.G) {
                         case 11: launch_pass_a_f32<1, 1, 1, 2>(pl, ar, nstep, q); break;
                         case 21: launch_pass_a_f32<2, 1, 1, 2>(pl, ar, nstep, q); break;
@@ -517,6 +523,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         char buf[256];
         char rowk[96];
         if (amp) std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,AM-P> (tiles of %d rows, no lambda_bar array)", L.B, L.G, pl.W, pl.NG, pl.PD, pl.R);
+        else if (f32 && pl.use_strip) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,EU,float> (strips of %d rows, fp32 state)", pl.RS);
         else if (f32) std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,EU,float> (tiles of %d rows, fp32 state)", L.B, L.G, pl.W, pl.NG, pl.PD, pl.R);
         else if (pl.use_strip && !cs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<%d,%s> (strips of %d rows)", L.B, american ? "AM" : "EU", pl.RS);
         else std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,%s%s> (tiles of %d rows)", L.B, L.G, pl.W, pl.NG, pl.PD,

@@ -886,9 +886,10 @@ __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : 4)) hadi_pass_a
 // into SGPRs.  Against the shared-ring kernel:
 // no block-wide barrier (its wait was ~40 % of a wavefront's time there), twice the rows in flight per CU, a quarter
 // of the LDS reads; the price is 4 halo rows per strip read again (mostly L2 hits).
-struct HadiStripCtx {
+template <class T>
+struct HadiStripCtxT {
     const double *coef;  // LDS: Bm, Bp, Dm, Dp, each 64*B doubles in row layout
-    double *Yi;          // instance base of Y
+    T *Yi;               // instance base of Y
     const double *Li;    // instance base of lambda_bar (American)
     const double *b2r;   // instance b2 row (global)
     int lane, rowp;
@@ -896,8 +897,8 @@ struct HadiStripCtx {
     HADI_STAMP_ACC
 };
 
-template <int B, bool AMER, bool LAST>
-HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtx &c, int j, const double (&rt)[HADI_RCL],
+template <int B, bool AMER, bool LAST, class T = double>
+HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j, const double (&rt)[HADI_RCL],
                                                const double (&um2)[B], const double (&um1)[B], const double (&u0)[B],
                                                const double (&up1)[B], const double (&up2)[B], double c0m2, double c0m1,
                                                double c00, double c0p1, double c0p2) {
@@ -1078,14 +1079,16 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtx &c, int j, con
         else corr = -thdt * A2U[r];
         yo[r] = x + corr;
     }
-    hadi_put_block<B, 1>(c.Yi + (size_t)j * rowp, 0, lane, yo);
-    if (lane == 0) c.Yi[(size_t)j * rowp + c0slot] = yout_c0;
+    hadi_put_block<B, 1, T>(c.Yi + (size_t)j * rowp, 0, lane, yo);
+    if (lane == 0) c.Yi[(size_t)j * rowp + c0slot] = (T)yout_c0;
     HADI_STAMPC(29);  // final correction + store issue
 }
 
 // LDS: [8 wavefronts][4 ring slots][rowp] + the 4 s-coefficient arrays.  Grid = n_inst * sblocks blocks of 8 strips.
-template <int B, bool AMER>
+// T = float: fp32-state sweep (European only), as in hadi_pass_a.
+template <int B, bool AMER, class T = double>
 __global__ void __launch_bounds__(512, (B >= 4 ? 2 : 4)) hadi_pass_a_strip(HadiSweepArgs a, int n) {
+    static_assert(sizeof(T) == 8 || !AMER, "the fp32-state sweep is European only");
     HADI_DYN_SMEM(double, smem);
     constexpr int NS = 4, NWV = 8, c0slot = 64 * B;
     const int lane = threadIdx.x & 63;
@@ -1097,7 +1100,7 @@ __global__ void __launch_bounds__(512, (B >= 4 ? 2 : 4)) hadi_pass_a_strip(HadiS
     const HadiInstPar ip = a.ipar[inst];
     if (n > ip.N) return;
     const int nrows = a.L.nrows, npad = a.L.nrows_pad, rowp = a.L.rowp;
-    double *coef = smem + (size_t)NWV * NS * rowp;
+    double *coef = reinterpret_cast<double *>(reinterpret_cast<T *>(smem) + (size_t)NWV * NS * rowp);
     {
         const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B;
         for (int e = threadIdx.x; e < 4 * 64 * B; e += 64 * NWV) coef[e] = sc[e];
@@ -1107,7 +1110,7 @@ __global__ void __launch_bounds__(512, (B >= 4 ? 2 : 4)) hadi_pass_a_strip(HadiS
     if (j0 >= nrows) return;
     const int j1 = (j0 + a.RS < nrows) ? j0 + a.RS : nrows;
 
-    HadiStripCtx c;
+    HadiStripCtxT<T> c;
     c.lane = lane;
     c.rowp = rowp;
     c.coef = coef;
@@ -1115,18 +1118,18 @@ __global__ void __launch_bounds__(512, (B >= 4 ? 2 : 4)) hadi_pass_a_strip(HadiS
     c.half_rd = hadi_uniform_d(ip.half_rd);
     c.e_nm1 = hadi_uniform_d(exp(ip.r_f * ip.dt * (n - 1)));  // device_solver.hpp:238
     c.e_n = hadi_uniform_d(exp(ip.r_f * ip.dt * n));          // device_solver.hpp:246
-    const double *__restrict__ Ub = a.U + (size_t)inst * a.L.inst_stride;
-    c.Yi = a.Y + (size_t)inst * a.L.inst_stride;
+    const T *__restrict__ Ub = reinterpret_cast<const T *>(a.U) + (size_t)inst * a.L.inst_stride;
+    c.Yi = reinterpret_cast<T *>(a.Y) + (size_t)inst * a.L.inst_stride;
     c.Li = AMER ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
     c.b2r = a.b2row + (size_t)inst * rowp;
 
-    double *ring = smem + (size_t)wave * NS * rowp;
+    T *ring = reinterpret_cast<T *>(smem) + (size_t)wave * NS * rowp;
     auto slot = [&](int jj) { return ring + (size_t)(jj & (NS - 1)) * rowp; };
     // returns the number of vector-memory instructions issued (rows outside the allocation are zero-filled)
     auto fetch = [&](int jj) -> int {
         const bool exists = jj >= 0 && jj < npad;
         hadi_row_to_lds(Ub + (size_t)jj * rowp, slot(jj), rowp, lane, exists);
-        return exists ? (rowp / 2 + 63) / 64 : 0;
+        return exists ? hadi_row_dma_count<T>(rowp) : 0;
     };
     // Direction of the walk: even strips go up (j0 -> j1-1), odd strips come down (j1-1 -> j0).  Neighbouring strips
     // then touch their shared halo rows at the same time -- both start there or both end there -- so the second reader
@@ -1144,13 +1147,15 @@ __global__ void __launch_bounds__(512, (B >= 4 ? 2 : 4)) hadi_pass_a_strip(HadiS
     int after1 = 0;                    // ... after the DMA of the row after that
     double um2[B], um1[B], u0[B];      // rows behind by 2, behind by 1, current
     double c0m2 = 0.0, c0m1 = 0.0, c00, c0p1;
-    hadi_load_row<B>(Ub + (ptrdiff_t)(js - 2 * dir) * rowp, lane, row_ok(js - 2 * dir), um2);
-    hadi_load_row<B>(Ub + (ptrdiff_t)(js - dir) * rowp, lane, row_ok(js - dir), um1);
-    hadi_load_row<B>(Ub + (size_t)js * rowp, lane, true, u0);
-    if (row_ok(js - 2 * dir)) c0m2 = Ub[(ptrdiff_t)(js - 2 * dir) * rowp + c0slot];
-    if (row_ok(js - dir)) c0m1 = Ub[(ptrdiff_t)(js - dir) * rowp + c0slot];
-    c00 = Ub[(size_t)js * rowp + c0slot];
-    c0p1 = row_ok(js + dir) ? Ub[(ptrdiff_t)(js + dir) * rowp + c0slot] : 0.0;
+#pragma unroll
+    for (int r = 0; r < B; r++) um2[r] = um1[r] = 0.0;
+    if (row_ok(js - 2 * dir)) hadi_get_block<B, 1, T>(Ub + (ptrdiff_t)(js - 2 * dir) * rowp, 0, lane, um2);
+    if (row_ok(js - dir)) hadi_get_block<B, 1, T>(Ub + (ptrdiff_t)(js - dir) * rowp, 0, lane, um1);
+    hadi_get_block<B, 1, T>(Ub + (size_t)js * rowp, 0, lane, u0);
+    if (row_ok(js - 2 * dir)) c0m2 = (double)Ub[(ptrdiff_t)(js - 2 * dir) * rowp + c0slot];
+    if (row_ok(js - dir)) c0m1 = (double)Ub[(ptrdiff_t)(js - dir) * rowp + c0slot];
+    c00 = (double)Ub[(size_t)js * rowp + c0slot];
+    c0p1 = row_ok(js + dir) ? (double)Ub[(ptrdiff_t)(js + dir) * rowp + c0slot] : 0.0;
 #if !defined(HADI_EMU)
     // Consume the prologue's register loads HERE: otherwise hipcc parks their s_waitcnt vmcnt(0) at the loop header,
     // where it would retire the DMA prefetch and the result stores in every iteration.
@@ -1180,9 +1185,9 @@ __global__ void __launch_bounds__(512, (B >= 4 ? 2 : 4)) hadi_pass_a_strip(HadiS
         after1 = 0;
         hadi_wave_rendezvous();
         double up1[B], up2[B];
-        hadi_lds_row<B>(slot(j + dir), lane, up1);
-        hadi_lds_row<B>(slot(j + 2 * dir), lane, up2);
-        const double c0p2 = slot(j + 2 * dir)[c0slot];
+        hadi_get_block<B, 1, T>(slot(j + dir), 0, lane, up1);
+        hadi_get_block<B, 1, T>(slot(j + 2 * dir), 0, lane, up2);
+        const double c0p2 = (double)slot(j + 2 * dir)[c0slot];
         double rt[HADI_RCL];
         hadi_sload_wait(srow, rt);  // one lgkmcnt(0) for the table entry and the LDS reads above
         if (dir < 0) {  // descending: "behind" rows are j+1, j+2 -- swap the neighbour weights instead of the arrays
@@ -1192,8 +1197,8 @@ __global__ void __launch_bounds__(512, (B >= 4 ? 2 : 4)) hadi_pass_a_strip(HadiS
             w = rt[RC_L1]; rt[RC_L1] = rt[RC_U1]; rt[RC_U1] = w;
         }
         HADI_STAMPC(25);  // LDS reads + table entry + DMA issue
-        if (j == nrows - 1) hadi_strip_step<B, AMER, true>(c, j, rt, um2, um1, u0, up1, up2, c0m2, c0m1, c00, c0p1, c0p2);
-        else hadi_strip_step<B, AMER, false>(c, j, rt, um2, um1, u0, up1, up2, c0m2, c0m1, c00, c0p1, c0p2);
+        if (j == nrows - 1) hadi_strip_step<B, AMER, true, T>(c, j, rt, um2, um1, u0, up1, up2, c0m2, c0m1, c00, c0p1, c0p2);
+        else hadi_strip_step<B, AMER, false, T>(c, j, rt, um2, um1, u0, up1, up2, c0m2, c0m1, c00, c0p1, c0p2);
         after0 += B / 2;  // the row's vector stores (the i = 0 store is not counted: lower bound)
         after1 += B / 2;
 #pragma unroll
@@ -1201,7 +1206,7 @@ __global__ void __launch_bounds__(512, (B >= 4 ? 2 : 4)) hadi_pass_a_strip(HadiS
             um2[r] = um1[r];
             um1[r] = u0[r];
         }
-        hadi_lds_row<B>(slot(j + dir), lane, u0);  // again from its slot (intact until the next step) rather than held in registers
+        hadi_get_block<B, 1, T>(slot(j + dir), 0, lane, u0);  // again from its slot (intact until the next step) rather than held in registers
 #if !defined(HADI_EMU)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and retired before the next step reuses that slot
 #endif

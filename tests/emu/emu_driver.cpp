@@ -52,7 +52,10 @@ static void run_pass_a_f32(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
                 pl.smem_a - ring_elems * (sizeof(double) - sizeof(float)));
 }
 static int run_sweep_f32(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
-    switch (pl.L.B * 10 + pl.L.G) {
+    if (pl.use_strip && pl.L.B == 8) {
+        emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<8, false, float>(a, n); },
+                    (size_t)8 * 4 * pl.L.rowp * sizeof(float) + (size_t)4 * 64 * pl.L.B * sizeof(double));
+    } else switch (pl.L.B * 10 + pl.L.G) {
         case 11: run_pass_a_f32<1, 1, 1, 2>(pl, a, n); break;
         case 21: run_pass_a_f32<2, 1, 1, 2>(pl, a, n); break;
         case 41: run_pass_a_f32<4, 1, 1, 2>(pl, a, n); break;

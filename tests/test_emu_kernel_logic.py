@@ -102,6 +102,7 @@ def test_fp32_state_sweep(emu):
     _run(emu, 300, 40, 2, [100.0], O.EU, 8, scheme=2)
     _run(emu, 600, 12, 2, [100.0], O.EU, 8, scheme=2)
     _run(emu, 300, 270, 2, [100.0], O.EU, 1, scheme=2)
+    _run(emu, 300, 150, 2, [100.0], O.EU, 1, r_f=0.01, scheme=2)  # large enough for the strip row pass (ring of floats)
 
 
 def test_american_p_representation(emu):
