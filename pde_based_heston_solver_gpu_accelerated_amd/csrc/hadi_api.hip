@@ -327,7 +327,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     HIP_TRY(c, hipGetLastError());
 
     if (f32) {  // round the packed state to fp32; Y's identity padding rows must read as zeros
-        hipLaunchKernelGGL(hadi_narrow_kernel, dim3(grid1d(tot)), dim3(256), 0, s, ptr<double>(c->U), ptr<float>(c->Uf), tot);
+        hipLaunchKernelGGL(hadi_narrow_kernel, dim3(grid1d(tot)), dim3(256), 0, s, L, ptr<double>(c->U), ptr<float>(c->Uf), tot);
         HIP_TRY(c, hipMemsetAsync(c->Yf.p, 0, st / 2, s));
     }
     HadiSweepArgs a;
@@ -589,7 +589,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
     if (f32)  // back to the fp64 packed array the unpack / price-pick kernels read
-        hipLaunchKernelGGL(hadi_widen_kernel, dim3(grid1d(tot)), dim3(256), 0, s, ptr<float>(c->Uf), ptr<double>(c->U), tot);
+        hipLaunchKernelGGL(hadi_widen_kernel, dim3(grid1d(tot)), dim3(256), 0, s, L, ptr<float>(c->Uf), ptr<double>(c->U), tot);
     return HADI_OK;
 }
 

@@ -42,6 +42,15 @@ HADI_HD inline int hadi_pos(int B, int G, int i) {
     return (r >> 1) * 128 * G + 128 * g + 2 * lane + (r & 1);
 }
 HADI_HD inline int hadi_pos(const HadiLayout &L, int i) { return hadi_pos(L.B, L.G, i); }
+// Slot mapping of the fp32 state arrays: same idea with QUADS of nodes, so that a lane's accesses stay 16 bytes wide
+// (4 floats).  B >= 4: quad q of (wave g, lane l) sits at q*256*G + 256*g + 4*l; B < 4: as hadi_pos.
+HADI_HD inline int hadi_pos_f32(int B, int G, int i) {
+    if (B < 4 || i == 0) return hadi_pos(B, G, i);
+    const int e = i - 1;
+    const int g = e / (64 * B), el = e - g * 64 * B;
+    const int lane = el / B, r = el % B;
+    return (r >> 2) * 256 * G + 256 * g + 4 * lane + (r & 3);
+}
 
 // Inverse: s-index stored in `slot` (-1 for a pad slot).
 HADI_HD inline int hadi_slot_to_i(const HadiLayout &L, int slot) {

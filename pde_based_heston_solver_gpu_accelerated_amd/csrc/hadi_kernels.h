@@ -369,7 +369,13 @@ template <> struct HadiPair<double> { typedef double2 type; };
 template <> struct HadiPair<float> { typedef float2 type; };
 template <int B, int G, class T = double>
 HADI_DEV HADI_FORCEINLINE void hadi_get_block(const T *row, int half, int lane, double (&u)[B]) {
-    if constexpr (B == 1) {
+    if constexpr (sizeof(T) == 4 && B >= 4) {  // fp32 state: quads (hadi_pos_f32), 16-byte accesses
+#pragma unroll
+        for (int q = 0; q < B / 4; q++) {
+            const float4 t = *reinterpret_cast<const float4 *>(row + q * 256 * G + 256 * half + 4 * lane);
+            u[4 * q] = (double)t.x; u[4 * q + 1] = (double)t.y; u[4 * q + 2] = (double)t.z; u[4 * q + 3] = (double)t.w;
+        }
+    } else if constexpr (B == 1) {
         u[0] = (double)row[64 * half + lane];
     } else {
 #pragma unroll
@@ -383,7 +389,14 @@ HADI_DEV HADI_FORCEINLINE void hadi_get_block(const T *row, int half, int lane, 
 }
 template <int B, int G, class T = double>
 HADI_DEV HADI_FORCEINLINE void hadi_put_block(T *row, int half, int lane, const double (&u)[B]) {
-    if constexpr (B == 1) {
+    if constexpr (sizeof(T) == 4 && B >= 4) {
+#pragma unroll
+        for (int q = 0; q < B / 4; q++) {
+            float4 t;
+            t.x = (float)u[4 * q]; t.y = (float)u[4 * q + 1]; t.z = (float)u[4 * q + 2]; t.w = (float)u[4 * q + 3];
+            *reinterpret_cast<float4 *>(row + q * 256 * G + 256 * half + 4 * lane) = t;
+        }
+    } else if constexpr (B == 1) {
         row[64 * half + lane] = (T)u[0];
     } else {
 #pragma unroll
@@ -785,8 +798,13 @@ __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : 4)) hadi_pass_a
     // last).  Before i = 1 comes the i = 0 slot; after the row's last node comes a pad slot (always 0).
     {
         const int ifirst = 1 + 64 * B * half + B * lane;
-        c.posL = hadi_pos(B, G, ifirst - 1);
-        c.posR = (ifirst + B <= 64 * B * G) ? hadi_pos(B, G, ifirst + B) : c0slot + 1;
+        if constexpr (sizeof(T) == 4) {
+            c.posL = hadi_pos_f32(B, G, ifirst - 1);
+            c.posR = (ifirst + B <= 64 * B * G) ? hadi_pos_f32(B, G, ifirst + B) : c0slot + 1;
+        } else {
+            c.posL = hadi_pos(B, G, ifirst - 1);
+            c.posR = (ifirst + B <= 64 * B * G) ? hadi_pos(B, G, ifirst + B) : c0slot + 1;
+        }
     }
 
     // LDS: [NG rings of RING rows of T] [4 coefficient arrays of 64*B*G] [NG*W*4 exchange] [NG compact row tables]
@@ -1145,12 +1163,23 @@ __global__ void __launch_bounds__(512, (B >= 4 ? 2 : 4)) hadi_pass_a_strip(HadiS
     fetch(js + 2 * dir);
     int after0 = fetch(js + 3 * dir);  // vector-memory instructions issued after the DMA of the row needed next
     int after1 = 0;                    // ... after the DMA of the row after that
-    double um2[B], um1[B], u0[B];      // rows behind by 2, behind by 1, current
+    // rows behind by 2, behind by 1 (carried in the state's own type: with an fp32 state they are exact floats and cost
+    // half the registers), current row (double: used throughout the step)
+    T um2[B], um1[B];
+    double u0[B];
     double c0m2 = 0.0, c0m1 = 0.0, c00, c0p1;
+    {
+        double t2[B], t1[B];
 #pragma unroll
-    for (int r = 0; r < B; r++) um2[r] = um1[r] = 0.0;
-    if (row_ok(js - 2 * dir)) hadi_get_block<B, 1, T>(Ub + (ptrdiff_t)(js - 2 * dir) * rowp, 0, lane, um2);
-    if (row_ok(js - dir)) hadi_get_block<B, 1, T>(Ub + (ptrdiff_t)(js - dir) * rowp, 0, lane, um1);
+        for (int r = 0; r < B; r++) t2[r] = t1[r] = 0.0;
+        if (row_ok(js - 2 * dir)) hadi_get_block<B, 1, T>(Ub + (ptrdiff_t)(js - 2 * dir) * rowp, 0, lane, t2);
+        if (row_ok(js - dir)) hadi_get_block<B, 1, T>(Ub + (ptrdiff_t)(js - dir) * rowp, 0, lane, t1);
+#pragma unroll
+        for (int r = 0; r < B; r++) {
+            um2[r] = (T)t2[r];
+            um1[r] = (T)t1[r];
+        }
+    }
     hadi_get_block<B, 1, T>(Ub + (size_t)js * rowp, 0, lane, u0);
     if (row_ok(js - 2 * dir)) c0m2 = (double)Ub[(ptrdiff_t)(js - 2 * dir) * rowp + c0slot];
     if (row_ok(js - dir)) c0m1 = (double)Ub[(ptrdiff_t)(js - dir) * rowp + c0slot];
@@ -1160,7 +1189,7 @@ __global__ void __launch_bounds__(512, (B >= 4 ? 2 : 4)) hadi_pass_a_strip(HadiS
     // Consume the prologue's register loads HERE: otherwise hipcc parks their s_waitcnt vmcnt(0) at the loop header,
     // where it would retire the DMA prefetch and the result stores in every iteration.
 #pragma unroll
-    for (int r = 0; r < B; r++) asm volatile("" : "+v"(um2[r]), "+v"(um1[r]), "+v"(u0[r]));
+    for (int r = 0; r < B; r++) asm volatile("" : "+v"(um2[r]), "+v"(um1[r]), "+v"(u0[r]));  // (T and double operands)
     asm volatile("" : "+v"(c0m2), "+v"(c0m1), "+v"(c00), "+v"(c0p1));
 #endif
 
@@ -1197,14 +1226,20 @@ __global__ void __launch_bounds__(512, (B >= 4 ? 2 : 4)) hadi_pass_a_strip(HadiS
             w = rt[RC_L1]; rt[RC_L1] = rt[RC_U1]; rt[RC_U1] = w;
         }
         HADI_STAMPC(25);  // LDS reads + table entry + DMA issue
-        if (j == nrows - 1) hadi_strip_step<B, AMER, true, T>(c, j, rt, um2, um1, u0, up1, up2, c0m2, c0m1, c00, c0p1, c0p2);
-        else hadi_strip_step<B, AMER, false, T>(c, j, rt, um2, um1, u0, up1, up2, c0m2, c0m1, c00, c0p1, c0p2);
+        double dm2[B], dm1[B];
+#pragma unroll
+        for (int r = 0; r < B; r++) {
+            dm2[r] = (double)um2[r];
+            dm1[r] = (double)um1[r];
+        }
+        if (j == nrows - 1) hadi_strip_step<B, AMER, true, T>(c, j, rt, dm2, dm1, u0, up1, up2, c0m2, c0m1, c00, c0p1, c0p2);
+        else hadi_strip_step<B, AMER, false, T>(c, j, rt, dm2, dm1, u0, up1, up2, c0m2, c0m1, c00, c0p1, c0p2);
         after0 += B / 2;  // the row's vector stores (the i = 0 store is not counted: lower bound)
         after1 += B / 2;
 #pragma unroll
         for (int r = 0; r < B; r++) {
             um2[r] = um1[r];
-            um1[r] = u0[r];
+            um1[r] = (T)u0[r];
         }
         hadi_get_block<B, 1, T>(slot(j + dir), 0, lane, u0);  // again from its slot (intact until the next step) rather than held in registers
 #if !defined(HADI_EMU)
@@ -1870,11 +1905,19 @@ __global__ void __launch_bounds__(256) hadi_dividend_kernel(HadiLayout L, int n_
 
 // ------------------------------------------------------------------------------------------------
 // fp32-state sweep: the packed state is rounded to fp32 before the time loop and widened after it (same element layout).
-__global__ void __launch_bounds__(256) hadi_narrow_kernel(const double *__restrict__ src, float *__restrict__ dst, size_t n) {
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) dst[e] = (float)src[e];
+__global__ void __launch_bounds__(256) hadi_narrow_kernel(HadiLayout L, const double *__restrict__ src, float *__restrict__ dst, size_t n) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = e / L.rowp;
+        const int x = (int)(e - row * L.rowp), i = hadi_slot_to_i(L, x);  // fp64 slot -> node -> fp32 slot (pads map to themselves)
+        dst[row * L.rowp + (i >= 0 ? hadi_pos_f32(L.B, L.G, i) : x)] = (float)src[e];
+    }
 }
-__global__ void __launch_bounds__(256) hadi_widen_kernel(const float *__restrict__ src, double *__restrict__ dst, size_t n) {
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) dst[e] = (double)src[e];
+__global__ void __launch_bounds__(256) hadi_widen_kernel(HadiLayout L, const float *__restrict__ src, double *__restrict__ dst, size_t n) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = e / L.rowp;
+        const int x = (int)(e - row * L.rowp), i = hadi_slot_to_i(L, x);
+        dst[e] = (double)src[row * L.rowp + (i >= 0 ? hadi_pos_f32(L.B, L.G, i) : x)];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -183,13 +183,13 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
     }
     if (f32) {  // round the packed state to float, sweep on float arrays, widen again
         std::vector<float> fU(st), fY(st, 0.0f);
-        emu::launch(8, 64, [&]() { hadi_narrow_kernel(dU.data(), fU.data(), st); });
+        emu::launch(8, 64, [&]() { hadi_narrow_kernel(L, dU.data(), fU.data(), st); });
         HadiSweepArgs af = a;
         af.U = reinterpret_cast<double *>(fU.data());
         af.Y = reinterpret_cast<double *>(fY.data());
         for (int n = 1; n <= N; n++)
             if (run_sweep_f32(pl, af, n)) return 2;
-        emu::launch(8, 64, [&]() { hadi_widen_kernel(fU.data(), dU.data(), st); });
+        emu::launch(8, 64, [&]() { hadi_widen_kernel(L, fU.data(), dU.data(), st); });
         emu::launch(8, 64, [&]() { hadi_unpack_kernel(L, n_inst, dU.data(), U); });
         return 0;
     }

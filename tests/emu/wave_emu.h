@@ -36,6 +36,9 @@ struct double2 {
 struct float2 {
     float x, y;
 };
+struct float4 {
+    float x, y, z, w;
+};
 
 namespace emu {
 struct WaveState {
