@@ -71,6 +71,15 @@ class GridViewsBatch:
         row = np.maximum(self.Vec_s - k, 0.0)
         return np.ascontiguousarray(np.tile(row, (1, self.m2 + 1)))
 
+    def put_payoff(self, strikes):
+        """U_0 = max(K - s, 0) on every v-row.  The time stepper is payoff-agnostic, but the boundary vectors it builds
+        are the reference's call-type ones (hes_boundary_kernels.hpp:41-75: dU/ds = e^{-r_f tau} at s_max, U = s e^{-r_f tau}
+        at v_max) -- the reference has no put path, so results with this payoff match the reference's ALGORITHM on the
+        same input, not a put price."""
+        k = np.asarray(strikes, dtype=np.float64).reshape(-1, 1)
+        row = np.maximum(k - self.Vec_s, 0.0)
+        return np.ascontiguousarray(np.tile(row, (1, self.m2 + 1)))
+
     def to(self, device):
         """Copies the four arrays to a torch device (bench / HBM-resident use)."""
         import torch

@@ -113,6 +113,24 @@ def test_american_p_representation_and_explicit_pair(solver, american_p, variant
     assert np.abs(lam - lo).max() <= 1e-8 * max(1.0, np.abs(lo).max())
 
 
+@pytest.mark.parametrize("m1,m2,N,n", [(256, 128, 25, 4), (50, 25, 20, 3)])
+def test_put_shaped_payoff_american_with_dividends(solver, m1, m2, N, n):
+    """BASELINE config 3 speaks of American puts with dividends; the reference has no put path (its boundary vectors are
+    call-type), but the stepper is payoff-agnostic: with U_0 = max(K - s, 0) libhadi must reproduce the oracle -- the
+    reference's algorithm on the same input -- exactly as for calls, including the projection against this payoff."""
+    strikes = Cm.strikes_for(n)
+    grids = H.GridViewsBatch.for_strikes(m1, m2, Cm.S_0, Cm.V_0, strikes)
+    U0 = grids.put_payoff(strikes)
+    U, lam = U0.copy(), np.zeros_like(U0)
+    solver.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U,
+                           variant=H.AM_DIV, U_0=U0, lambda_bar=lam, dividends=H.Dividends(*Cm.DIVS))
+    p = Cm.oracle_params(m1, m2, N, "AM_DIV")
+    Uo, lo, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0, want_lambda=True)
+    _assert_field(U, Uo)
+    assert np.abs(lam - lo).max() <= 1e-8 * max(1.0, np.abs(lo).max())
+    assert lo.max() > 0  # the early-exercise constraint is active for this payoff
+
+
 @pytest.mark.parametrize("m1,m2,N,n", [(256, 128, 10, 3), (512, 256, 5, 2), (1024, 512, 3, 1), (50, 25, 10, 2)])
 def test_american_with_a_payoff_that_depends_on_v(solver, m1, m2, N, n):
     """The column pass loads a payoff that depends on s only (every driver of the reference) once per column; a general

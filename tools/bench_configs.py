@@ -52,7 +52,16 @@ p = solver.compute_base_prices_american_dividends(S_0, V_0, T, r_d, r_f, rho, si
                                                   theta, T / N, 1, g1, u1, ws, div)
 out["C3_american_dividend_256x128x500_x512"]["price_K100"] = float(p[0])
 out["C3_american_dividend_256x128x500_x512"]["price_abs_err_vs_reference"] = abs(float(p[0]) - 5.2760823084423789)
-del U, U0, gd
+# ---- C3 with the put-shaped payoff of the literal config (no reference put path: algorithm parity only, see grid.put_payoff)
+U0p = torch.from_numpy(g.put_payoff(ks)).to(dev)
+def c3p():
+    U.copy_(U0p)
+    solver.DO_timestepping(m1, m2, N, T / N, theta, r_d, r_f, rho, sigma, kappa, eta, gd, U, variant=H.AM_DIV, U_0=U0p, dividends=div)
+t = timed(c3p)
+out["C3_put_payoff_american_dividend_256x128x500_x512"] = {"seconds": t, "point_steps_per_s": n * (m1 + 1) * (m2 + 1) * N / t,
+                                                            "kernels": solver.describe_last_sweep()}
+
+del U, U0, U0p, gd
 
 # ---- C4: 50 strikes x 10 maturities, N_m = max(20, floor(20 T_m)) (heston_calibration.cpp:2485-2517)
 m1, m2 = 50, 25
