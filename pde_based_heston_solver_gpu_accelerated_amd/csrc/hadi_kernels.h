@@ -97,6 +97,29 @@ HADI_DEV HADI_FORCEINLINE double hadi_lane_get(double v, int src) {
 #endif
 }
 
+// Value of `v` held by lane - 1 / lane + 1: a DPP wave shift (two v_mov_b32 on the VALU) instead of a ds_bpermute round
+// trip through the LDS pipe, which the eight wavefronts of a CU share.  Lane 0 (resp. 63) gets 0.
+HADI_DEV HADI_FORCEINLINE double hadi_lane_prev(double v) {
+#if defined(HADI_EMU)
+    const double t = __shfl(v, (emu::t_lane - 1) & 63);
+    return emu::t_lane == 0 ? 0.0 : t;
+#else
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+#endif
+}
+HADI_DEV HADI_FORCEINLINE double hadi_lane_next(double v) {
+#if defined(HADI_EMU)
+    const double t = __shfl(v, (emu::t_lane + 1) & 63);
+    return emu::t_lane == 63 ? 0.0 : t;
+#else
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+#endif
+}
+
 #if defined(HADI_STAMPS) && !defined(HADI_EMU)
 // Diagnostic build only (tools/stamps.py): per-phase cycle sums of the row pass, never in the product.
 // Each wavefront accumulates its own sums and adds them to the global array once, at kernel end.
@@ -611,8 +634,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
                 ps[r] = fma(-iu[r], ps[r + 1], ps[r]) * invt[r];
                 gs[r] = -iu[r] * gs[r + 1] * invt[r];
             }
-            const int nl = (lane + 1) & 63;
-            double p0n = hadi_lane_get(ps[0], nl), g0n = hadi_lane_get(gs[0], nl), y0n = hadi_lane_get(ys[0], nl);
+            double p0n = hadi_lane_next(ps[0]), g0n = hadi_lane_next(gs[0]), y0n = hadi_lane_next(ys[0]);
             if (edge_hi) { p0n = 0.0; g0n = 0.0; y0n = 0.0; }
             ra = -il_last * ps[NB - 1];
             rb = im_last - il_last * gs[NB - 1] - iu[B - 1] * p0n;
@@ -642,13 +664,20 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
 #pragma unroll
             for (int s = 1; s < 64; s <<= 1) {
                 const int up_lane = (lane - s) & 63, dn_lane = (lane + s) & 63;
-                const double aL = hadi_lane_get(ra, up_lane), cL = hadi_lane_get(rcc, up_lane), fL = hadi_lane_get(rf, up_lane);
-                const double aR = hadi_lane_get(ra, dn_lane), cR = hadi_lane_get(rcc, dn_lane), fR = hadi_lane_get(rf, dn_lane);
+                double aL, cL, fL, aR, cR, fR;
+                if (s == 1) {  // (constant after unrolling) the first level's neighbours are one lane away
+                    aL = hadi_lane_prev(ra); cL = hadi_lane_prev(rcc); fL = hadi_lane_prev(rf);
+                    aR = hadi_lane_next(ra); cR = hadi_lane_next(rcc); fR = hadi_lane_next(rf);
+                } else {
+                    aL = hadi_lane_get(ra, up_lane); cL = hadi_lane_get(rcc, up_lane); fL = hadi_lane_get(rf, up_lane);
+                    aR = hadi_lane_get(ra, dn_lane); cR = hadi_lane_get(rcc, dn_lane); fR = hadi_lane_get(rf, dn_lane);
+                }
                 const double bn = fma(-rcc, aR, fma(-ra, cL, 1.0));
                 const double rn = hadi_rcp(bn);
                 rf = fma(-rcc, fR, fma(-ra, fL, rf)) * rn;
                 if constexpr (G > 1) {
-                    const double sL = hadi_lane_get(rs, up_lane), sR = hadi_lane_get(rs, dn_lane);
+                    const double sL = (s == 1) ? hadi_lane_prev(rs) : hadi_lane_get(rs, up_lane);
+                    const double sR = (s == 1) ? hadi_lane_next(rs) : hadi_lane_get(rs, dn_lane);
                     rs = fma(-rcc, sR, fma(-ra, sL, rs)) * rn;
                 }
                 if (s < 32) {  // the last level only needs the right-hand sides
@@ -691,11 +720,10 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
             const double xhi = (A - Bc * Cc) / (1.0 - Bc * Dd);  // last node of the low half
             const double tlo = Cc - Dd * xhi;                    // first node of the high half
             X = Ysol - (first_half ? tlo : xhi) * Ssol;
-            XL = hadi_lane_get(X, (lane - 1) & 63);
+            XL = hadi_lane_prev(X);
             if (lane == 0) XL = first_half ? 0.0 : xhi;
         } else {
-            XL = hadi_lane_get(X, (lane - 1) & 63);
-            if (lane == 0) XL = 0.0;
+            XL = hadi_lane_prev(X);
         }
         // ---- Y1 -> right-hand side of the A2 solve (device_solver.hpp:254-260) and store ----------
         double yo[B];
@@ -957,9 +985,8 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
 #pragma unroll
     for (int r = 0; r < B; r++) A2U[r] = fma(a2u2, up2[r], A2U[r]);
     // s-neighbours of the block: last node of lane-1, first node of lane+1; lane 0 borders i = 0, lane 63 the pad (0)
-    const int lp = (lane - 1) & 63, ln = (lane + 1) & 63;
-    double u0L = hadi_lane_get(u0[B - 1], lp), tL = hadi_lane_get(tt[B - 1], lp);
-    double u0R = hadi_lane_get(u0[0], ln), tR = hadi_lane_get(tt[0], ln);
+    double u0L = hadi_lane_prev(u0[B - 1]), tL = hadi_lane_prev(tt[B - 1]);
+    double u0R = hadi_lane_next(u0[0]), tR = hadi_lane_next(tt[0]);
     if (lane == 0) {
         u0L = c00;
         tL = wm * c0m1 + wz * c00 + wp * c0p1;
@@ -1050,7 +1077,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
             ps[r] = fma(-iu[r], ps[r + 1], ps[r]) * invt[r];
             gs[r] = -iu[r] * gs[r + 1] * invt[r];
         }
-        const double p0n = hadi_lane_get(ps[0], ln), g0n = hadi_lane_get(gs[0], ln), y0n = hadi_lane_get(ys[0], ln);
+        const double p0n = hadi_lane_next(ps[0]), g0n = hadi_lane_next(gs[0]), y0n = hadi_lane_next(ys[0]);
         ra = -il_last * ps[NB - 1];
         rb = im_last - il_last * gs[NB - 1] - iu[B - 1] * p0n;
         rcc = -iu[B - 1] * g0n;
@@ -1067,8 +1094,14 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
 #pragma unroll
         for (int s = 1; s < 64; s <<= 1) {
             const int up_lane = (lane - s) & 63, dn_lane = (lane + s) & 63;
-            const double aL = hadi_lane_get(ra, up_lane), cL = hadi_lane_get(rcc, up_lane), fL = hadi_lane_get(rf, up_lane);
-            const double aR = hadi_lane_get(ra, dn_lane), cR = hadi_lane_get(rcc, dn_lane), fR = hadi_lane_get(rf, dn_lane);
+            double aL, cL, fL, aR, cR, fR;
+            if (s == 1) {  // (constant after unrolling) the first level's neighbours are one lane away
+                aL = hadi_lane_prev(ra); cL = hadi_lane_prev(rcc); fL = hadi_lane_prev(rf);
+                aR = hadi_lane_next(ra); cR = hadi_lane_next(rcc); fR = hadi_lane_next(rf);
+            } else {
+                aL = hadi_lane_get(ra, up_lane); cL = hadi_lane_get(rcc, up_lane); fL = hadi_lane_get(rf, up_lane);
+                aR = hadi_lane_get(ra, dn_lane); cR = hadi_lane_get(rcc, dn_lane); fR = hadi_lane_get(rf, dn_lane);
+            }
             const double bn = fma(-rcc, aR, fma(-ra, cL, 1.0));
             const double rn = hadi_rcp(bn);
             rf = fma(-rcc, fR, fma(-ra, fL, rf)) * rn;
@@ -1083,8 +1116,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
     HADI_STAMPC(28);  // PCR
     hadi_set_prio(0);
     const double X = rf;
-    double XL = hadi_lane_get(X, lp);
-    if (lane == 0) XL = 0.0;
+    const double XL = hadi_lane_prev(X);
     // ---- Y1 -> right-hand side of the A2 solve (device_solver.hpp:254-260) and store ----------
     double yo[B];
 #pragma unroll

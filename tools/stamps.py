@@ -35,7 +35,7 @@ if os.environ.get("STAMP_LEVEL") == "3":
         print("%-32s %8.0f cycles/tile  %5.1f %%" % (nm, buf[k] / tiles, 100.0 * buf[k] / tb))
     sys.exit(0)
 if os.environ.get("STAMP_LEVEL") == "4":
-    cn = {24: "wait for the DMA (row j+2)", 25: "LDS reads + table entry + DMA issue", 26: "explicit ops + Y0 + fwd Thomas",
+    cn = {24: "wait for the DMA (row j+2)", 31: "DMA issue (row j+4)", 25: "LDS reads + table entry", 26: "explicit ops + Y0 + fwd Thomas",
           27: "bwd Thomas + reduced row", 28: "PCR", 29: "final + store issue", 30: "carry + loop"}
     rows = n * 257 * N
     tc = sum(buf[k] for k in cn)
