@@ -25,17 +25,17 @@
 #include <stddef.h>
 #include <stdint.h>
 
-// 1/x.  v_rcp_f64 + two Newton steps (each an fma pair) instead of the ~14-instruction IEEE
-// division expansion; relative error ~1 ulp, which is inside the parity tolerance by 9 orders.
+// 1/x without the ~14-instruction IEEE division expansion; relative error ~1 ulp, which is inside the parity
+// tolerance by 9 orders.
 HADI_DEV HADI_FORCEINLINE double hadi_rcp(double x) {
 #if defined(HADI_EMU)
     return 1.0 / x;
 #else
-    double r = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-x, r, 1.0);
-    r = fma(r, e, r);
-    return r;
+    // v_rcp_f64 delivers ~2^-26; one third-order step r (1 + e + e^2), e = 1 - x r, leaves e^3 -- below the rounding of
+    // the result -- in three FMAs (two Newton steps take four, and a longer dependent chain)
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    const double t = fma(e, e, e);
+    return fma(r, t, r);
 #endif
 }

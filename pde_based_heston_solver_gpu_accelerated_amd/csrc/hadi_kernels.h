@@ -98,14 +98,15 @@ HADI_DEV HADI_FORCEINLINE double hadi_lane_get(double v, int src) {
 }
 
 // Value of `v` held by lane - 1 / lane + 1: a DPP wave shift (two v_mov_b32 on the VALU) instead of a ds_bpermute round
-// trip through the LDS pipe, which the eight wavefronts of a CU share.  Lane 0 (resp. 63) gets 0.
+// trip through the LDS pipe, which the eight wavefronts of a CU share.  Lane 0 (resp. 63) gets 0 (bound_ctrl:0 -- which
+// also spares the move that would initialise the destination).
 HADI_DEV HADI_FORCEINLINE double hadi_lane_prev(double v) {
 #if defined(HADI_EMU)
     const double t = __shfl(v, (emu::t_lane - 1) & 63);
     return emu::t_lane == 0 ? 0.0 : t;
 #else
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 #endif
 }
@@ -114,8 +115,8 @@ HADI_DEV HADI_FORCEINLINE double hadi_lane_next(double v) {
     const double t = __shfl(v, (emu::t_lane + 1) & 63);
     return emu::t_lane == 63 ? 0.0 : t;
 #else
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 #endif
 }
@@ -991,11 +992,9 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
         u0L = c00;
         tL = wm * c0m1 + wz * c00 + wp * c0p1;
     }
-    if (lane == 63) {
-        u0R = 0.0;
-        tR = 0.0;
-    }
+    // (lane 63: hadi_lane_next delivered the pad's zeros already)
     const double cb1 = dt * e_nm1 + thdt * (e_n - e_nm1);
+    const double b1l = (lane == b1lane) ? b1val * cb1 : 0.0;  // this row's b1 entry, in the lane that owns its node
 
     double lam[B], b2v[B];
     if constexpr (AMER) hadi_get_block<B, 1>(c.Li + (size_t)j * rowp, 0, lane, lam);
@@ -1030,16 +1029,15 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
         const double tr = (r == B - 1) ? tR : tt[r == B - 1 ? r : r + 1];
         const double lo = fma(v, Dm[r], qd * Bm[r]);
         const double up = fma(v, Dp[r], qd * Bp[r]);
-        const double mn = -(fma(v, Dm[r] + Dp[r], qd * (Bm[r] + Bp[r])) + half_rd);
+        const double mn = -((lo + up) + half_rd);  // = -(v (Dm + Dp) + q (Bm + Bp) + r_d / 2)
         const double A1U = lo * uL + mn * u0[r] + up * uR;
         const double A0U = Bm[r] * tl - (Bm[r] + Bp[r]) * tt[r] + Bp[r] * tr;
-        const double b1h = (lane == b1lane && r == b1r) ? b1val : 0.0;
         double S = A0U + A1U + A2U[r];
         if constexpr (LAST) S += b2v[r] * e_nm1;
         if constexpr (AMER) S += lam[r];
         double y = fma(dt, S, u0[r]);
         y = fma(-thdt, A1U, y);
-        y = fma(b1h, cb1, y);
+        y = fma(b1l, (r == b1r) ? 1.0 : 0.0, y);  // wave-uniform selector: one FMA with a scalar operand
         double il = -thdt * lo;
         const double im = 1.0 - thdt * mn;
         iu[r] = -thdt * up;
