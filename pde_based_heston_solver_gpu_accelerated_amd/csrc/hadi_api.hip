@@ -235,6 +235,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         return fail(c, HADI_ERR_UNSUPPORTED,
                     "grid %dx%d not supported (need 2 <= m1 <= 1024, 3 <= m2 <= min(m1, %d))", d.m1, d.m2,
                     HADI_MAX_P * HADI_LC - 1);
+    if (!(d.theta > 0.0)) pl.use_strip = 0;  // the strip kernel scales the A1 action by (1 - theta) / theta
     const HadiLayout &L = pl.L;
     const bool american = d.variant == HADI_AM || d.variant == HADI_AM_DIV;
     const bool dividend = d.variant == HADI_DIV || d.variant == HADI_AM_DIV;

@@ -162,7 +162,7 @@ struct HadiTables {
 
 // rowc columns
 enum { RC_V = 0, RC_WM = 1, RC_WZ = 2, RC_WP = 3, RC_L2 = 4, RC_L1 = 5, RC_M = 6, RC_U1 = 7, RC_U2 = 8,
-       RC_B1VAL = 9, RC_B1COL = 10, RC_LAST = 11 };
+       RC_B1VAL = 9, RC_B1COL = 10, RC_VTH = 11 /* theta dt v */, RC_LAST = 12 };
 // pb columns: forward  y_k = (rhs_k - PB_L y_{k-1} - PB_L2 y_{k-2}) * PB_Q
 //             backward x_k = y_k - PB_C x_{k+1} - PB_C2 x_{k+2}
 //             spikes   x_k -= PB_V0 tl0 + PB_V1 tl1 + PB_W0 tr0 + PB_W1 tr1
@@ -204,6 +204,7 @@ HADI_HD inline void hadi_setup_instance(const HadiLayout &L, const HadiSetupIn &
         for (int k = 0; k < HADI_RC; k++) rc[k] = 0.0;
         const double v = in.vec_v[r];
         rc[RC_V] = v;
+        rc[RC_VTH] = thdt * v;
         if (r >= 1 && r <= m2 - 1) {
             const double c = in.rho * in.sigma * v;
             rc[RC_WM] = c * hadi_fd_beta(in.delta_v, r - 1, -1);

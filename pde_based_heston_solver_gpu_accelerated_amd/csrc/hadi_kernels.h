@@ -940,7 +940,8 @@ struct HadiStripCtxT {
     const double *Li;    // instance base of lambda_bar (American)
     const double *b2r;   // instance b2 row (global)
     int lane, rowp;
-    double dt, thdt, qd, half_rd, e_nm1, e_n;
+    double dt, thdt, e_nm1, e_n;
+    double qth, c1, c2, kap;  // theta dt (r_d - r_f), 1 + theta dt r_d / 2, theta dt r_d / 2, (1 - theta) / theta
     HADI_STAMP_ACC
 };
 
@@ -953,8 +954,8 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
     constexpr int c0slot = 64 * B;
     constexpr int NB = B - 1;
     HADI_STAMP_DECL(c.stamp_acc_)
-    const double dt = c.dt, thdt = c.thdt, qd = c.qd, half_rd = c.half_rd, e_nm1 = c.e_nm1, e_n = c.e_n;
-    const double v = rt[RC_V];
+    const double dt = c.dt, thdt = c.thdt, qth = c.qth, c1 = c.c1, c2 = c.c2, kap = c.kap, e_nm1 = c.e_nm1, e_n = c.e_n;
+    const double vth = rt[RC_VTH];
     const double wm = rt[RC_WM], wz = rt[RC_WZ], wp = rt[RC_WP];
     const double a2l2 = rt[RC_L2], a2l1 = rt[RC_L1], a2m = rt[RC_M], a2u1 = rt[RC_U1], a2u2 = rt[RC_U2];
     const double b1val = rt[RC_B1VAL];
@@ -1027,20 +1028,20 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
         const double uR = (r == B - 1) ? u0R : u0[r == B - 1 ? r : r + 1];
         const double tl = (r == 0) ? tL : tt[r == 0 ? 0 : r - 1];
         const double tr = (r == B - 1) ? tR : tt[r == B - 1 ? r : r + 1];
-        const double lo = fma(v, Dm[r], qd * Bm[r]);
-        const double up = fma(v, Dp[r], qd * Bp[r]);
-        const double mn = -((lo + up) + half_rd);  // = -(v (Dm + Dp) + q (Bm + Bp) + r_d / 2)
-        const double A1U = lo * uL + mn * u0[r] + up * uR;
+        // I - theta dt A1 directly (theta dt v comes with the row's table entry): il, im, iu; theta dt A1 U from the
+        // same three; Y0 - theta dt A1 U = U + dt (A0 U + A2 U + ...) + (1 - theta)/theta (theta dt A1 U)
+        double il = fma(-vth, Dm[r], -(qth * Bm[r]));
+        iu[r] = fma(-vth, Dp[r], -(qth * Bp[r]));
+        const double sm = il + iu[r];
+        const double im = c1 - sm;  // 1 + theta dt (lo + up + r_d / 2)
+        const double T1 = fma(-iu[r], uR, fma(-il, uL, (sm - c2) * u0[r]));
         const double A0U = Bm[r] * tl - (Bm[r] + Bp[r]) * tt[r] + Bp[r] * tr;
-        double S = A0U + A1U + A2U[r];
+        double S = A0U + A2U[r];
         if constexpr (LAST) S += b2v[r] * e_nm1;
         if constexpr (AMER) S += lam[r];
         double y = fma(dt, S, u0[r]);
-        y = fma(-thdt, A1U, y);
+        y = fma(kap, T1, y);
         y = fma(b1l, (r == b1r) ? 1.0 : 0.0, y);  // wave-uniform selector: one FMA with a scalar operand
-        double il = -thdt * lo;
-        const double im = 1.0 - thdt * mn;
-        iu[r] = -thdt * up;
         if (r == 0 && lane == 0) {  // x_0 is known: move it to the right-hand side
             y -= il * x0;
             il = 0.0;
@@ -1162,8 +1163,11 @@ __global__ void __launch_bounds__(512, (B >= 4 ? 2 : 4)) hadi_pass_a_strip(HadiS
     c.lane = lane;
     c.rowp = rowp;
     c.coef = coef;
-    c.dt = hadi_uniform_d(ip.dt); c.thdt = hadi_uniform_d(ip.thdt); c.qd = hadi_uniform_d(ip.q);
-    c.half_rd = hadi_uniform_d(ip.half_rd);
+    c.dt = hadi_uniform_d(ip.dt); c.thdt = hadi_uniform_d(ip.thdt);
+    c.qth = hadi_uniform_d(ip.thdt * ip.q);
+    c.c2 = hadi_uniform_d(ip.thdt * ip.half_rd);
+    c.c1 = hadi_uniform_d(1.0 + ip.thdt * ip.half_rd);
+    c.kap = hadi_uniform_d((ip.dt - ip.thdt) / ip.thdt);  // the host keeps theta = 0 off this kernel
     c.e_nm1 = hadi_uniform_d(exp(ip.r_f * ip.dt * (n - 1)));  // device_solver.hpp:238
     c.e_n = hadi_uniform_d(exp(ip.r_f * ip.dt * n));          // device_solver.hpp:246
     const T *__restrict__ Ub = reinterpret_cast<const T *>(a.U) + (size_t)inst * a.L.inst_stride;

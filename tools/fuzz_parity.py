@@ -4,6 +4,8 @@ import os, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
+import pde_based_heston_solver_gpu_accelerated_amd._native as nat
+if os.environ.get("HADI_LIB"): nat.LIB_PATH = os.path.abspath(os.environ["HADI_LIB"])
 import pde_based_heston_solver_gpu_accelerated_amd as H
 from oracle import oracle as O
 import common as Cm
