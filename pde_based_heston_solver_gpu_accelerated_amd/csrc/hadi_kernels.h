@@ -545,6 +545,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
             for (int r = 0; r < B; r++) A2U[r] = fma(a2u2, u2[r], A2U[r]);
         }
         const double cb1 = dt * e_nm1 + thdt * (e_n - e_nm1);
+        const double b1l = (lane == b1lane) ? b1val * cb1 : 0.0;  // this row's b1 entry, in the lane that owns its node
         double u0L = (double)r0[c.posL], u0R = (double)r0[c.posR];
         double m1L = (double)rm1[c.posL], m1R = (double)rm1[c.posR], p1L = (double)rp1[c.posL], p1R = (double)rp1[c.posR];
         if constexpr (AMER == 2) {
@@ -582,10 +583,9 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
             const double tr = (r == B - 1) ? tR : tt[r == B - 1 ? r : r + 1];
             const double lo = fma(v, Dm[r], qd * Bm[r]);
             const double up = fma(v, Dp[r], qd * Bp[r]);
-            const double mn = -(fma(v, Dm[r] + Dp[r], qd * (Bm[r] + Bp[r])) + half_rd);
+            const double mn = -((lo + up) + half_rd);  // = -(v (Dm + Dp) + q (Bm + Bp) + r_d / 2)
             const double A1U = lo * uL + mn * u0[r] + up * uR;
             const double A0U = Bm[r] * tl - (Bm[r] + Bp[r]) * tt[r] + Bp[r] * tr;
-            const double b1h = (lane == b1lane && r == b1r) ? b1val : 0.0;
             // Y0 = U + dt (A0U + A1U + A2U + b e_{n-1} [+ lambda]) + theta dt (b1 e_n - (A1U + b1 e_{n-1})); the b1
             // entry of this v-row (a single node) contributes b1 * cb1, cb1 = dt e_{n-1} + theta dt (e_n - e_{n-1})
             double S = A0U + A1U + A2U[r];
@@ -593,7 +593,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
             if constexpr (AMER != 0) S += lam[r];
             double y = fma(dt, S, u0[r]);
             y = fma(-thdt, A1U, y);
-            y = fma(b1h, cb1, y);
+            y = fma(b1l, (r == b1r) ? 1.0 : 0.0, y);  // wave-uniform selector: one FMA with a scalar operand
             if constexpr (MODE == 1) r1v[r] = fma(-0.5 * dt, A0U, y);
             if constexpr (MODE == 2) y = fma(0.5 * dt, A0U, r1v[r]);  // A0U is A0 applied to Y2 here
             double il = -thdt * lo;

@@ -462,11 +462,12 @@ def test_full_lm_calibration_reproduces_reference_run_on_gpu(solver):
     five parameters (tests/golden).  Tolerance 1e-3 relative, not the 6 printed digits the serial
     oracle reproduces: the forward-difference Jacobian (eps = 1e-6) turns the 1e-15 round-off differences of the
     parallel line solves into 1e-9 in J, and four LM steps through J^T J with cond ~1e9 (kappa runs to 47.9, barely
-    identified) carry that into the 5th digit of the final error and the 4th of kappa."""
+    identified) carry that into the 5th digit of the final error and the 3rd-4th of kappa (observed 0.4e-3 .. 1.0e-3
+    across kernel revisions that differ only in rounding), hence 3e-3 for kappa alone."""
     import test_oracle_golden as G
     g, args = G._reference_calibration_setup()
     res = H.calibrate_european(solver, *args, max_iter=15, tol=0.1)
-    G.check_calibration_against_record(res, g, tol=1e-3)
+    G.check_calibration_against_record(res, g, tol=1e-3, kappa_tol=3e-3)
 
 
 REF_DIVS = ([0.2, 0.4, 0.6, 0.8], [0.10] * 4, [0.0005] * 4)  # heston_calibration.cpp:1090-1092
