@@ -1006,7 +1006,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
     // LDS reads to the top: 32 live doubles there are what pushed this kernel into scratch).
     hadi_set_prio(1);
     double Bm[B], Bp[B], Dm[B], Dp[B];
-    double ys[B], ps[B], gs[B], iu[B], invt[B];
+    double ys[B], ps[B], gs[B], iu[B], cp[B];
     double il_last = 0.0, im_last = 1.0, d_last = 0.0;
 #pragma unroll
     for (int r = 0; r < B; r++) {
@@ -1047,15 +1047,17 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
             il = 0.0;
         }
         if (r < NB) {
+            // normalised rows (x[r] + cp[r] x[r+1] = ys[r] - ps[r] XL): the back substitution is then one FMA per vector
             if (r == 0) {
-                invt[0] = hadi_rcp(im);
-                ys[0] = y;
-                ps[0] = il;
+                const double inv = hadi_rcp(im);
+                cp[0] = iu[0] * inv;
+                ys[0] = y * inv;
+                ps[0] = il * inv;
             } else {
-                const double w = il * invt[r - 1];
-                invt[r] = hadi_rcp(fma(-w, iu[r - 1], im));
-                ys[r] = fma(-w, ys[r - 1], y);
-                ps[r] = -w * ps[r - 1];
+                const double inv = hadi_rcp(fma(-il, cp[r - 1], im));
+                cp[r] = iu[r] * inv;
+                ys[r] = fma(-il, ys[r - 1], y) * inv;
+                ps[r] = -(il * ps[r - 1]) * inv;
             }
         } else {
             il_last = il;
@@ -1067,14 +1069,12 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
     // reduced (interface) row of this lane
     double ra, rb, rcc, rf;
     {
-        gs[NB - 1] = iu[NB - 1] * invt[NB - 1];
-        ys[NB - 1] *= invt[NB - 1];
-        ps[NB - 1] *= invt[NB - 1];
+        gs[NB - 1] = cp[NB - 1];
 #pragma unroll
         for (int r = NB - 2; r >= 0; r--) {
-            ys[r] = fma(-iu[r], ys[r + 1], ys[r]) * invt[r];
-            ps[r] = fma(-iu[r], ps[r + 1], ps[r]) * invt[r];
-            gs[r] = -iu[r] * gs[r + 1] * invt[r];
+            ys[r] = fma(-cp[r], ys[r + 1], ys[r]);
+            ps[r] = fma(-cp[r], ps[r + 1], ps[r]);
+            gs[r] = -cp[r] * gs[r + 1];
         }
         const double p0n = hadi_lane_next(ps[0]), g0n = hadi_lane_next(gs[0]), y0n = hadi_lane_next(ys[0]);
         ra = -il_last * ps[NB - 1];
