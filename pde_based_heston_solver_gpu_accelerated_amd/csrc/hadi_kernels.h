@@ -573,7 +573,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
         hadi_get_block<B, G>(c.coef + 1 * 64 * B * G, half, lane, Bp);
         hadi_get_block<B, G>(c.coef + 2 * 64 * B * G, half, lane, Dm);
         hadi_get_block<B, G>(c.coef + 3 * 64 * B * G, half, lane, Dp);
-        double iu[B], invt[B];
+        double iu[B], cp[B];
         double il_last = 0.0, im_last = 1.0, d_last = 0.0;
 #pragma unroll
         for (int r = 0; r < B; r++) {
@@ -604,15 +604,17 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
                 il = 0.0;
             }
             if (r < NB) {
+                // normalised rows (x[r] + cp[r] x[r+1] = ys[r] - ps[r] XL): the back substitution is then one FMA per vector
                 if (r == 0) {
-                    invt[0] = hadi_rcp(im);
-                    ys[0] = y;
-                    ps[0] = il;
+                    const double inv = hadi_rcp(im);
+                    cp[0] = iu[0] * inv;
+                    ys[0] = y * inv;
+                    ps[0] = il * inv;
                 } else {
-                    const double w = il * invt[r - 1];
-                    invt[r] = hadi_rcp(fma(-w, iu[r - 1], im));
-                    ys[r] = fma(-w, ys[r - 1], y);
-                    ps[r] = -w * ps[r - 1];
+                    const double inv = hadi_rcp(fma(-il, cp[r - 1], im));
+                    cp[r] = iu[r] * inv;
+                    ys[r] = fma(-il, ys[r - 1], y) * inv;
+                    ps[r] = -(il * ps[r - 1]) * inv;
                 }
             } else {
                 il_last = il;
@@ -626,14 +628,12 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
         const bool edge_hi = (G > 1) && !last_half && lane == 63;  // next node belongs to the other wave
         const bool edge_lo = (G > 1) && !first_half && lane == 0;  // previous node belongs to the other wave
         if constexpr (NB > 0) {
-            gs[NB - 1] = iu[NB - 1] * invt[NB - 1];
-            ys[NB - 1] *= invt[NB - 1];
-            ps[NB - 1] *= invt[NB - 1];
+            gs[NB - 1] = cp[NB - 1];
 #pragma unroll
             for (int r = NB - 2; r >= 0; r--) {
-                ys[r] = fma(-iu[r], ys[r + 1], ys[r]) * invt[r];
-                ps[r] = fma(-iu[r], ps[r + 1], ps[r]) * invt[r];
-                gs[r] = -iu[r] * gs[r + 1] * invt[r];
+                ys[r] = fma(-cp[r], ys[r + 1], ys[r]);
+                ps[r] = fma(-cp[r], ps[r + 1], ps[r]);
+                gs[r] = -cp[r] * gs[r + 1];
             }
             double p0n = hadi_lane_next(ps[0]), g0n = hadi_lane_next(gs[0]), y0n = hadi_lane_next(ys[0]);
             if (edge_hi) { p0n = 0.0; g0n = 0.0; y0n = 0.0; }
@@ -1303,6 +1303,7 @@ struct HadiPassBCtx {
     const double *Yi;   // instance base of Y
     double *Ui;         // instance base of U
     HadiBuf Yb, Ub;     // the same two as buffer resources (uniform)
+    HadiBuf Lb;         // lambda_bar as a buffer resource (American, explicit pair)
     double *Li;         // instance base of lambda_bar (American)
     const double *P0i;  // instance base of the payoff (American)
     int pay1d;          // the payoff does not depend on v: one load per column instead of one per node
@@ -1487,6 +1488,54 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_store(const HadiPassBCtx &c, int ctile, d
     HADI_STAMPB(22);  // projection + store issue
 }
 
+// American, double-buffered kernel: what the projection of tile `ctile` needs besides the solved values -- the old P
+// (P representation) or lambda_bar (explicit pair) -- is fetched into a third register set BEFORE the tile is solved,
+// so it arrives during the solve.  Loaded inside the store loop (after the solve's barriers, which no load may cross)
+// every tile paid one full memory latency with nothing else to do: 0.28 ms per launch against 0.12 for the European
+// column pass on 512x256 x256.
+template <int AMER>
+HADI_DEV HADI_FORCEINLINE void hadi_pb_load_old(const HadiPassBCtx &c, int ctile, double (&po)[HADI_LC]) {
+    const int col = ctile * 64 + c.lane;
+    const int colc = col < c.rowp ? col : c.rowp - 1;
+    const unsigned voff = (unsigned)colc * 8u;
+    const unsigned row0 = (unsigned)c.ja * (unsigned)c.rowp * 8u, rstride = (unsigned)c.rowp * 8u;
+#pragma unroll
+    for (int k = 0; k < HADI_LC; k++) po[k] = hadi_buf_load(AMER == 2 ? c.Ub : c.Lb, voff, row0 + (unsigned)k * rstride);
+}
+// Ikonen-Toivanen projection (device_solver.hpp:358-372) of the solved tile with the prefetched old values; payoff that
+// depends on s only (one value per column).  Raw buffer stores; lanes past the pitch are dropped by the range check.
+template <int AMER>
+HADI_DEV HADI_FORCEINLINE void hadi_pb_store_am(const HadiPassBCtx &c, int ctile, const double (&y)[HADI_LC],
+                                                const double (&po)[HADI_LC]) {
+    HADI_STAMP_DECL(c.stamp_acc_)
+    const int col = ctile * 64 + c.lane;
+    const bool valid = col < c.rowp;
+    const int colc = valid ? col : c.rowp - 1;
+    const unsigned voffs = valid ? (unsigned)colc * 8u : HADI_BUF_DROP;
+    const unsigned row0 = (unsigned)c.ja * (unsigned)c.rowp * 8u, rstride = (unsigned)c.rowp * 8u;
+    const double dt = c.dt;
+    const bool is_smax = (col == c.pos_m1);
+    const double pay = c.P0i[colc];
+#pragma unroll
+    for (int k = 0; k < HADI_LC; k++) {
+        const double U_bar = y[k];
+        if constexpr (AMER == 2) {
+            // lambda_bar_old = max(0, (U0 - P_old)/dt), P_new = U_bar - dt lambda_bar_old (see hadi_row_step)
+            double lamo = fmax(0.0, (pay - po[k]) * c.inv_dt);
+            if (is_smax) lamo = 0.0;
+            hadi_buf_store(c.Ub, voffs, row0 + (unsigned)k * rstride, U_bar - dt * lamo);
+        } else {
+            const double lamv = po[k];
+            const double un = fmax(U_bar - dt * lamv, pay);
+            double ln = fmax(0.0, lamv + (pay - U_bar) / dt);
+            if (is_smax) ln = 0.0;
+            hadi_buf_store(c.Ub, voffs, row0 + (unsigned)k * rstride, un);
+            hadi_buf_store(c.Lb, voffs, row0 + (unsigned)k * rstride, ln);
+        }
+    }
+    HADI_STAMPB(22);  // projection + store issue
+}
+
 template <int AMER, class T = double>
 HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ctile, int parity, double (&y)[HADI_LC],
                                                    int younger = 0) {
@@ -1520,6 +1569,7 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
     c.Yb = hadi_make_buf(reinterpret_cast<const T *>(a.Y) + (size_t)inst * a.L.inst_stride, (size_t)a.L.inst_stride * sizeof(T));
     c.Ub = hadi_make_buf(reinterpret_cast<const T *>(a.U) + (size_t)inst * a.L.inst_stride, (size_t)a.L.inst_stride * sizeof(T));
     c.Li = (AMER == 1) ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
+    c.Lb = hadi_make_buf(c.Li, (AMER == 1) ? (size_t)a.L.inst_stride * sizeof(double) : 0);
     c.P0i = AMER ? a.U0 + (size_t)inst * a.L.inst_stride : nullptr;
     c.pay1d = AMER ? (a.pay_mis[inst] == 0) : 0;
     c.inv_dt = 1.0 / ip.dt;
@@ -1535,6 +1585,7 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
 #endif
     double ya[HADI_LC], yb[HADI_LC];
     hadi_pb_load<T>(c, t0, ya);
+    const bool am_fast = (AMER == 2) || (AMER == 1 && c.pay1d != 0);  // block-uniform
     // the chunk's table (identical for every column) is spread over the lanes' registers once per block
     {
         hadi_pb_load_table(c, a.pb + ((size_t)inst * nrows + c.ja) * HADI_PBW);
@@ -1552,6 +1603,24 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
         c.Ri = rw;
     }
     __syncthreads();
+    if constexpr (AMER != 0) {
+        if (am_fast) {
+            double po[HADI_LC];
+            for (int t = t0; t < t1; t += 2) {
+                hadi_pb_load_old<AMER>(c, t, po);  // first: it is needed before the next tile's values
+                if (t + 1 < t1) hadi_pb_load<T>(c, t + 1, yb);
+                hadi_pb_solve(c, 0, ya, 0);
+                hadi_pb_store_am<AMER>(c, t, ya, po);
+                if (t + 1 < t1) {
+                    hadi_pb_load_old<AMER>(c, t + 1, po);
+                    if (t + 2 < t1) hadi_pb_load<T>(c, t + 2, ya);
+                    hadi_pb_solve(c, 1, yb, 0);
+                    hadi_pb_store_am<AMER>(c, t + 1, yb, po);
+                }
+            }
+            return;
+        }
+    }
     for (int t = t0; t < t1; t += 2) {
         // `younger` = vector-memory operations issued after the loads of the tile being solved (diagnostic build only)
         if (t + 1 < t1) hadi_pb_load<T>(c, t + 1, yb);
@@ -1592,6 +1661,7 @@ __global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, in
     c.Yb = hadi_make_buf(reinterpret_cast<const T *>(a.Y) + (size_t)inst * a.L.inst_stride, (size_t)a.L.inst_stride * sizeof(T));
     c.Ub = hadi_make_buf(reinterpret_cast<const T *>(a.U) + (size_t)inst * a.L.inst_stride, (size_t)a.L.inst_stride * sizeof(T));
     c.Li = (AMER == 1) ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
+    c.Lb = hadi_make_buf(c.Li, (AMER == 1) ? (size_t)a.L.inst_stride * sizeof(double) : 0);
     c.P0i = AMER ? a.U0 + (size_t)inst * a.L.inst_stride : nullptr;
     c.pay1d = AMER ? (a.pay_mis[inst] == 0) : 0;
     c.inv_dt = 1.0 / ip.dt;
