@@ -669,6 +669,8 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
                 if (s == 1) {  // (constant after unrolling) the first level's neighbours are one lane away
                     aL = hadi_lane_prev(ra); cL = hadi_lane_prev(rcc); fL = hadi_lane_prev(rf);
                     aR = hadi_lane_next(ra); cR = hadi_lane_next(rcc); fR = hadi_lane_next(rf);
+                } else if (s == 32) {  // lane - 32 and lane + 32 are the same lane (mod 64): one fetch serves both sides
+                    aL = aR = hadi_lane_get(ra, up_lane); cL = cR = hadi_lane_get(rcc, up_lane); fL = fR = hadi_lane_get(rf, up_lane);
                 } else {
                     aL = hadi_lane_get(ra, up_lane); cL = hadi_lane_get(rcc, up_lane); fL = hadi_lane_get(rf, up_lane);
                     aR = hadi_lane_get(ra, dn_lane); cR = hadi_lane_get(rcc, dn_lane); fR = hadi_lane_get(rf, dn_lane);
@@ -678,7 +680,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
                 rf = fma(-rcc, fR, fma(-ra, fL, rf)) * rn;
                 if constexpr (G > 1) {
                     const double sL = (s == 1) ? hadi_lane_prev(rs) : hadi_lane_get(rs, up_lane);
-                    const double sR = (s == 1) ? hadi_lane_next(rs) : hadi_lane_get(rs, dn_lane);
+                    const double sR = (s == 1) ? hadi_lane_next(rs) : (s == 32) ? sL : hadi_lane_get(rs, dn_lane);
                     rs = fma(-rcc, sR, fma(-ra, sL, rs)) * rn;
                 }
                 if (s < 32) {  // the last level only needs the right-hand sides
@@ -1097,6 +1099,8 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
             if (s == 1) {  // (constant after unrolling) the first level's neighbours are one lane away
                 aL = hadi_lane_prev(ra); cL = hadi_lane_prev(rcc); fL = hadi_lane_prev(rf);
                 aR = hadi_lane_next(ra); cR = hadi_lane_next(rcc); fR = hadi_lane_next(rf);
+            } else if (s == 32) {  // lane - 32 and lane + 32 are the same lane (mod 64): one fetch serves both sides
+                aL = aR = hadi_lane_get(ra, up_lane); cL = cR = hadi_lane_get(rcc, up_lane); fL = fR = hadi_lane_get(rf, up_lane);
             } else {
                 aL = hadi_lane_get(ra, up_lane); cL = hadi_lane_get(rcc, up_lane); fL = hadi_lane_get(rf, up_lane);
                 aR = hadi_lane_get(ra, dn_lane); cR = hadi_lane_get(rcc, dn_lane); fR = hadi_lane_get(rf, dn_lane);
@@ -1621,7 +1625,28 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
             return;
         }
     }
-    for (int t = t0; t < t1; t += 2) {
+    // European: THREE register buffers (3 x 33 rows = 198 VGPRs of 256) -- the loads of two tiles are in flight while one
+    // is solved and stored.  With two buffers a tile's loads had only the short solve of its predecessor (~4 k cycles)
+    // to arrive in, less than the memory latency under load; measured 512x256 x256: 0.117 -> 0.113 ms per launch at the
+    // same 3 tiles per block (a block then has all its loads in flight from the start).
+    if constexpr (AMER == 0) {
+        double yc[HADI_LC];
+        if (t0 + 1 < t1) hadi_pb_load<T>(c, t0 + 1, yb);
+        for (int t = t0; t < t1; t += 3) {
+            if (t + 2 < t1) hadi_pb_load<T>(c, t + 2, yc);
+            hadi_pb_solve_store<AMER, T>(c, t, (t - t0) & 1, ya, 0);
+            if (t + 1 < t1) {
+                if (t + 3 < t1) hadi_pb_load<T>(c, t + 3, ya);
+                hadi_pb_solve_store<AMER, T>(c, t + 1, (t + 1 - t0) & 1, yb, 0);
+            }
+            if (t + 2 < t1) {
+                if (t + 4 < t1) hadi_pb_load<T>(c, t + 4, yb);
+                hadi_pb_solve_store<AMER, T>(c, t + 2, (t + 2 - t0) & 1, yc, 0);
+            }
+        }
+        return;
+    }
+    for (int t = t0; t < t1; t += 2) {  // American with a payoff that depends on v: two buffers, loads inside the store loop
         // `younger` = vector-memory operations issued after the loads of the tile being solved (diagnostic build only)
         if (t + 1 < t1) hadi_pb_load<T>(c, t + 1, yb);
         hadi_pb_solve_store<AMER, T>(c, t, 0, ya, (t + 1 < t1 ? HADI_LC : 0) + (t > t0 ? HADI_LC : 0));
