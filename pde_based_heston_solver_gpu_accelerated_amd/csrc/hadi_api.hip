@@ -388,7 +388,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                     }
                     return;
                 }
-                if (f32 && pl.use_strip) {  // fp32 state, 8 nodes per lane, large batch: strips with a ring of floats
+                if (f32 && pl.use_strip && L.B == 8) {  // fp32 state, 8 nodes per lane, large batch: strips with a ring of floats
                     const size_t smem = (size_t)8 * 4 * L.rowp * sizeof(float) + (size_t)4 * 64 * L.B * sizeof(double);
                     hipLaunchKernelGGL((hadi_pass_a_strip<8, false, float>), dim3(pl.grid_as), dim3(512), smem, q, ar, nstep);
                     return;
@@ -404,7 +404,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                     return;
                 }
                 if (pl.use_strip && mode == 0) {  // barrier-free strips (Douglas step, one wavefront per row)
-                    const dim3 g(pl.grid_as), b(512);
+                    const dim3 g(pl.grid_as), b(64 * HADI_STRIP_WAVES(L.B));
                     switch (L.B * 2 + (american ? 1 : 0)) {
                         case 16: hipLaunchKernelGGL((hadi_pass_a_strip<8, false>), g, b, pl.smem_as, q, ar, nstep); break;
                         case 17: hipLaunchKernelGGL((hadi_pass_a_strip<8, true>), g, b, pl.smem_as, q, ar, nstep); break;
@@ -524,7 +524,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         char buf[256];
         char rowk[96];
         if (amp) std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,AM-P> (tiles of %d rows, no lambda_bar array)", L.B, L.G, pl.W, pl.NG, pl.PD, pl.R);
-        else if (f32 && pl.use_strip) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,EU,float> (strips of %d rows, fp32 state)", pl.RS);
+        else if (f32 && pl.use_strip && L.B == 8) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,EU,float> (strips of %d rows, fp32 state)", pl.RS);
         else if (f32) std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,EU,float> (tiles of %d rows, fp32 state)", L.B, L.G, pl.W, pl.NG, pl.PD, pl.R);
         else if (pl.use_strip && !cs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<%d,%s> (strips of %d rows)", L.B, american ? "AM" : "EU", pl.RS);
         else std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,%s%s> (tiles of %d rows)", L.B, L.G, pl.W, pl.NG, pl.PD,

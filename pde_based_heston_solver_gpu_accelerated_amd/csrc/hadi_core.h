@@ -161,6 +161,9 @@ struct HadiTables {
 };
 
 // rowc columns
+// wavefronts (= strips) per block of the strip row pass: 8 at 8 nodes per lane (one block fills a CU's LDS and
+// registers); 4 at 4 and 2 nodes per lane, where a v-line is short and 8 strips would be ~17 rows each
+#define HADI_STRIP_WAVES(B) ((B) == 8 ? 8 : 4)
 enum { RC_V = 0, RC_WM = 1, RC_WZ = 2, RC_WP = 3, RC_L2 = 4, RC_L1 = 5, RC_M = 6, RC_U1 = 7, RC_U2 = 8,
        RC_B1VAL = 9, RC_B1COL = 10, RC_VTH = 11 /* theta dt v */, RC_LAST = 12 };
 // pb columns: forward  y_k = (rhs_k - PB_L y_{k-1} - PB_L2 y_{k-2}) * PB_Q

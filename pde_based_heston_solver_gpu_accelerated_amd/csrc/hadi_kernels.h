@@ -1137,13 +1137,13 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
     HADI_STAMPC(29);  // final correction + store issue
 }
 
-// LDS: [8 wavefronts][4 ring slots][rowp] + the 4 s-coefficient arrays.  Grid = n_inst * sblocks blocks of 8 strips.
+// LDS: [HADI_STRIP_WAVES wavefronts][4 ring slots][rowp] + the 4 s-coefficient arrays.  Grid = n_inst * sblocks blocks.
 // T = float: fp32-state sweep (European only), as in hadi_pass_a.
 template <int B, bool AMER, class T = double>
-__global__ void __launch_bounds__(512, (B >= 4 ? 2 : 4)) hadi_pass_a_strip(HadiSweepArgs a, int n) {
+__global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 4 ? 2 : 4)) hadi_pass_a_strip(HadiSweepArgs a, int n) {
     static_assert(sizeof(T) == 8 || !AMER, "the fp32-state sweep is European only");
     HADI_DYN_SMEM(double, smem);
-    constexpr int NS = 4, NWV = 8, c0slot = 64 * B;
+    constexpr int NS = 4, NWV = HADI_STRIP_WAVES(B), c0slot = 64 * B;
     const int lane = threadIdx.x & 63;
     const int wave = HADI_UNIFORM((int)(threadIdx.x >> 6));
     const int total = a.n_inst * a.sblocks;

@@ -76,10 +76,11 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
         if (rs0 < 16) rs0 = 16;
         if (rs0 > 64) rs0 = 64;
         const int ns = (L.nrows + (int)rs0 - 1) / (int)rs0;
-        p.sblocks = (ns + 7) / 8;
-        p.RS = (L.nrows + 8 * p.sblocks - 1) / (8 * p.sblocks);
+        const int nwv = HADI_STRIP_WAVES(L.B);
+        p.sblocks = (ns + nwv - 1) / nwv;
+        p.RS = (L.nrows + nwv * p.sblocks - 1) / (nwv * p.sblocks);
         p.grid_as = (int)(((long long)n_inst * p.sblocks + 7) / 8 * 8);
-        p.smem_as = ((size_t)8 * 4 * L.rowp + (size_t)4 * 64 * L.B) * sizeof(double);
+        p.smem_as = ((size_t)nwv * 4 * L.rowp + (size_t)4 * 64 * L.B) * sizeof(double);
         // Chosen automatically at 8 nodes per lane only: measured on MI355X, 512x256 x256: 0.156 -> 0.141 ms/launch; at 4
         // nodes per lane (256x128 x1024) the shared-ring kernel, which fits four wavefronts per SIMD there, stays
         // ahead (0.190 vs 0.203 ms).  HADI_TUNE_STRIP=1 forces strips for 2 and 4 nodes per lane too (tests).
@@ -90,6 +91,9 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
         const long long sblk = (long long)n_inst * p.sblocks;
         const double fill = (double)sblk / (double)(((sblk + cus - 1) / cus) * cus);
         p.use_strip = (L.B == 8 && p.RS >= 16 && p.RS <= 64 && fill >= 0.7) ? 1 : 0;
+        // 2 nodes per lane (64 < m1 <= 128), batches of several blocks per CU: 4-strip blocks beat the shared ring
+        // (128x64 x2000: 0.130 -> 0.108 ms per launch); at 4 nodes per lane the two are level (0.165 vs 0.167).
+        if (L.B == 2 && p.RS >= 16 && p.RS <= 64 && sblk >= 4 * (long long)cus) p.use_strip = 1;
         if (const char *e = getenv("HADI_TUNE_STRIP")) p.use_strip = (atoi(e) && p.RS >= 1 && p.RS <= 64) ? 1 : 0;
     }
     p.ctiles = (L.rowp + 63) / 64;
@@ -116,6 +120,10 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
                 if (cost(g) < cost(best) - 1e-9) best = g;
             groups = best;
         }
+        // Up to four chunks (m2 <= 131) a block is at most 256 threads and two or more of them share a CU: blocks of ONE
+        // tile then overlap each other better than tiles pipeline inside a block (measured, 256x128 x512 American:
+        // 0.094 -> 0.083 ms per launch; 200x100 x700: 0.087 -> 0.084; 128x64 x2000: 0.070 -> 0.068).
+        if (L.P <= 4) groups = p.ctiles;
         if (const char *e = getenv("HADI_TUNE_BG")) groups = atoi(e);
         if (groups < 1) groups = 1;
         if (groups > p.ctiles) groups = p.ctiles;

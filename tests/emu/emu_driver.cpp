@@ -26,10 +26,10 @@ static int run_row_pass(const HadiPlan &pl, const HadiSweepArgs &a, int n, int m
         switch (pl.L.B * 2 + (a.american ? 1 : 0)) {
             case 16: emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<8, false>(a, n); }, pl.smem_as); break;
             case 17: emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<8, true>(a, n); }, pl.smem_as); break;
-            case 8: emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<4, false>(a, n); }, pl.smem_as); break;
-            case 9: emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<4, true>(a, n); }, pl.smem_as); break;
-            case 4: emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<2, false>(a, n); }, pl.smem_as); break;
-            default: emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<2, true>(a, n); }, pl.smem_as); break;
+            case 8: emu::launch(pl.grid_as, 64 * HADI_STRIP_WAVES(4), [&]() { hadi_pass_a_strip<4, false>(a, n); }, pl.smem_as); break;
+            case 9: emu::launch(pl.grid_as, 64 * HADI_STRIP_WAVES(4), [&]() { hadi_pass_a_strip<4, true>(a, n); }, pl.smem_as); break;
+            case 4: emu::launch(pl.grid_as, 64 * HADI_STRIP_WAVES(2), [&]() { hadi_pass_a_strip<2, false>(a, n); }, pl.smem_as); break;
+            default: emu::launch(pl.grid_as, 64 * HADI_STRIP_WAVES(2), [&]() { hadi_pass_a_strip<2, true>(a, n); }, pl.smem_as); break;
         }
         return 0;
     }
