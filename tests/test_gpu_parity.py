@@ -563,6 +563,53 @@ def test_strip_row_pass_vs_oracle(solver, monkeypatch, variant, name, m1, m2, N,
         assert np.abs(lam - lo).max() <= 1e-8 * max(1.0, np.abs(lo).max())
 
 
+@pytest.mark.parametrize("theta", [0.0, 0.5, 1.0])
+def test_strip_row_pass_theta_range(solver, monkeypatch, theta):
+    """The strip kernel forms I - theta dt A1 directly and rebuilds the explicit A1 action from it with the factor
+    (1 - theta) / theta: theta = 1 (factor 0) and theta = 0.5 must meet the oracle, and theta = 0 -- where that factor does
+    not exist -- must be kept off the strip kernel by the host even when strips are forced."""
+    monkeypatch.setenv("HADI_TUNE_STRIP", "1")
+    m1, m2, N, n = 300, 140, 6, 2
+    strikes = Cm.strikes_for(n)
+    grids, U0 = _batch(m1, m2, strikes)
+    U = U0.copy()
+    dt = Cm.T / (50 * N) if theta > 0 else 1e-6  # (the explicit scheme is only stable for tiny steps on this grid)
+    solver.DO_timestepping(m1, m2, N, dt, theta, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U)
+    assert ("hadi_pass_a_strip" in solver.describe_last_sweep()) == (theta > 0)
+    p = O.make_params(m1, m2, N, dt, theta, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, O.EU, None)
+    Uo, _, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0)
+    _assert_field(U, Uo)
+
+
+def test_strips_chosen_by_themselves_at_two_nodes_per_lane(solver):
+    """64 < m1 <= 128 with several blocks per CU: the plan picks 4-strip blocks on its own (hadi_plan.h); 1100 instances
+    of 128x64, a few steps, against the oracle."""
+    m1, m2, N, n = 128, 64, 4, 1100
+    strikes = Cm.strikes_for(n)
+    grids, U0, U, _ = _hadi_solve(solver, m1, m2, N, strikes, H.EU)
+    assert "hadi_pass_a_strip<2,EU>" in solver.describe_last_sweep()
+    p = Cm.oracle_params(m1, m2, N, "EU")
+    Uo, _, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0)
+    _assert_field(U, Uo)
+
+
+def test_forced_strips_leave_the_fp32_state_of_narrow_grids_on_the_ring_kernel(solver, monkeypatch):
+    """The float strip kernel exists at 8 nodes per lane only: with strips forced (or auto-selected at 2 nodes per lane) a
+    narrower grid with the fp32 state must take the shared-ring float kernel, not a mismatched strip launch."""
+    monkeypatch.setenv("HADI_TUNE_STRIP", "1")
+    m1, m2, N, n = 128, 64, 6, 3
+    strikes = Cm.strikes_for(n)
+    grids, U0 = _batch(m1, m2, strikes)
+    U = U0.copy()
+    solver.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U,
+                           state_precision=H.STATE_FP32)
+    d = solver.describe_last_sweep()
+    assert "float" in d and "strip" not in d
+    p = O.make_params(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, O.EU, None, state_fp32=1)
+    Uo, _, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0)
+    _assert_field(U, Uo, rtol=2e-7 * N)
+
+
 @pytest.mark.parametrize("m1,m2,N,n", [(50, 25, 20, 3), (128, 64, 10, 2), (256, 128, 12, 3), (512, 256, 8, 2),
                                       (1024, 512, 4, 1), (700, 300, 4, 2)])
 def test_fp32_state_sweep_vs_oracle(solver, monkeypatch, m1, m2, N, n):
