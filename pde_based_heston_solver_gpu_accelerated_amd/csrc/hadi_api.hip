@@ -201,6 +201,9 @@ hipError_t raise_all_lds_limits() {
     if ((e = raise_lds_limit(hadi_pass_a_strip<4, true>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_a_strip<2, false>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_a_strip<2, true>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a_strip<8, 2>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a_strip<4, 2>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a_strip<2, 2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_kernel<1, 4, false>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_kernel<1, 4, true>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_kernel<2, 4, false>)) != hipSuccess) return e;
@@ -378,6 +381,16 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
             }
             if (prof) HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 0], q));
             auto row_pass = [&](const HadiSweepArgs &ar, int mode) {
+                if (amp && !xstep && pl.use_strip && mode == 0) {  // P representation on barrier-free strips
+                    const dim3 g(pl.grid_as), b(64 * HADI_STRIP_WAVES(L.B));
+                    const size_t sm = pl.smem_as + (size_t)L.rowp * sizeof(double);  // + the payoff row
+                    switch (L.B) {
+                        case 8: hipLaunchKernelGGL((hadi_pass_a_strip<8, 2>), g, b, sm, q, ar, nstep); break;
+                        case 4: hipLaunchKernelGGL((hadi_pass_a_strip<4, 2>), g, b, sm, q, ar, nstep); break;
+                        default: hipLaunchKernelGGL((hadi_pass_a_strip<2, 2>), g, b, sm, q, ar, nstep); break;
+                    }
+                    return;
+                }
                 if (amp && !xstep) {
                     switch (L.B * 10 + L.G) {
                         case 11: launch_pass_a_amp<1, 1, 1, 2>(pl, ar, nstep, q); break;
@@ -523,7 +536,8 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     {
         char buf[256];
         char rowk[96];
-        if (amp) std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,AM-P> (tiles of %d rows, no lambda_bar array)", L.B, L.G, pl.W, pl.NG, pl.PD, pl.R);
+        if (amp && pl.use_strip && !cs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<%d,AM-P> (strips of %d rows, no lambda_bar array)", L.B, pl.RS);
+        else if (amp) std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,AM-P> (tiles of %d rows, no lambda_bar array)", L.B, L.G, pl.W, pl.NG, pl.PD, pl.R);
         else if (f32 && pl.use_strip && L.B == 8) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,EU,float> (strips of %d rows, fp32 state)", pl.RS);
         else if (f32) std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,EU,float> (tiles of %d rows, fp32 state)", L.B, L.G, pl.W, pl.NG, pl.PD, pl.R);
         else if (pl.use_strip && !cs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<%d,%s> (strips of %d rows)", L.B, american ? "AM" : "EU", pl.RS);

@@ -944,14 +944,21 @@ struct HadiStripCtxT {
     int lane, rowp;
     double dt, thdt, e_nm1, e_n;
     double qth, c1, c2, kap;  // theta dt (r_d - r_f), 1 + theta dt r_d / 2, theta dt r_d / 2, (1 - theta) / theta
+    double inv_dt;            // P representation: 1 / dt and the (lane, slot) of the s_max node
+    int m1_lane, m1_r;
     HADI_STAMP_ACC
 };
 
-template <int B, bool AMER, bool LAST, class T = double>
+// AMER: 0 European, 1 American with the explicit (U, lambda_bar) pair (lambda_bar loaded here), 2 American in the P
+// representation: the caller rebuilt U = max(P, U_0) on the five rows and hands over the raw P of row j (p_raw) and
+// lambda_bar of the i = 0 column; lambda_bar = max(0, (U_0 - P)/dt) = (U - P)/dt is formed here, right before the sweep
+// that consumes it (formed by the caller it stayed live across the explicit operators and the kernel spilled).
+template <int B, int AMER, bool LAST, class T = double>
 HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j, const double (&rt)[HADI_RCL],
                                                const double (&um2)[B], const double (&um1)[B], const double (&u0)[B],
                                                const double (&up1)[B], const double (&up2)[B], double c0m2, double c0m1,
-                                               double c00, double c0p1, double c0p2) {
+                                               double c00, double c0p1, double c0p2, const double (&p_raw)[B],
+                                               double lamc0_in) {
     const int lane = c.lane, rowp = c.rowp;
     constexpr int c0slot = 64 * B;
     constexpr int NB = B - 1;
@@ -970,7 +977,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
     const double a2c0 = a2l2 * c0m2 + a2l1 * c0m1 + a2m * c00 + a2u1 * c0p1 + a2u2 * c0p2;
     const double b1c0 = (b1col == 0) ? b1val : 0.0;
     const double b2c0 = LAST ? c.b2r[c0slot] : 0.0;
-    const double lamc0 = AMER ? c.Li[(size_t)j * rowp + c0slot] : 0.0;
+    const double lamc0 = (AMER == 1) ? c.Li[(size_t)j * rowp + c0slot] : (AMER == 2) ? lamc0_in : 0.0;
     double y0c0 = c00 + dt * (a2c0 + (b1c0 + b2c0) * e_nm1 + lamc0);
     y0c0 = y0c0 + thdt * (b1c0 * e_n - (0.0 + b1c0 * e_nm1));
     const double c2c0 = thdt * (b2c0 * e_n - (a2c0 + b2c0 * e_nm1));
@@ -1000,7 +1007,14 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
     const double b1l = (lane == b1lane) ? b1val * cb1 : 0.0;  // this row's b1 entry, in the lane that owns its node
 
     double lam[B], b2v[B];
-    if constexpr (AMER) hadi_get_block<B, 1>(c.Li + (size_t)j * rowp, 0, lane, lam);
+    if constexpr (AMER == 1) hadi_get_block<B, 1>(c.Li + (size_t)j * rowp, 0, lane, lam);
+    if constexpr (AMER == 2) {
+#pragma unroll
+        for (int r = 0; r < B; r++) {
+            lam[r] = (u0[r] - p_raw[r]) * c.inv_dt;  // exactly max(0, (U_0 - P) / dt): U = max(P, U_0)
+            if (lane == c.m1_lane && r == c.m1_r) lam[r] = 0.0;  // s_max keeps lambda_bar = 0, as in hadi_row_step
+        }
+    }
     if constexpr (LAST) hadi_get_block<B, 1>(c.b2r, 0, lane, b2v);
 
     // ---- Y0 (device_solver.hpp:236-250) fused with the forward sweep of the in-lane Thomas ----------
@@ -1139,9 +1153,9 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
 
 // LDS: [HADI_STRIP_WAVES wavefronts][4 ring slots][rowp] + the 4 s-coefficient arrays.  Grid = n_inst * sblocks blocks.
 // T = float: fp32-state sweep (European only), as in hadi_pass_a.
-template <int B, bool AMER, class T = double>
+template <int B, int AMER, class T = double>
 __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 4 ? 2 : 4)) hadi_pass_a_strip(HadiSweepArgs a, int n) {
-    static_assert(sizeof(T) == 8 || !AMER, "the fp32-state sweep is European only");
+    static_assert(sizeof(T) == 8 || AMER == 0, "the fp32-state sweep is European only");
     HADI_DYN_SMEM(double, smem);
     constexpr int NS = 4, NWV = HADI_STRIP_WAVES(B), c0slot = 64 * B;
     const int lane = threadIdx.x & 63;
@@ -1157,6 +1171,14 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 4 ? 2 : 4)) ha
     {
         const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B;
         for (int e = threadIdx.x; e < 4 * 64 * B; e += 64 * NWV) coef[e] = sc[e];
+    }
+    // P representation: the payoff row (it depends on s only: v-row 0 of the packed payoff) behind the coefficient arrays;
+    // re-read from LDS every row rather than held in 2 B registers per lane (that version spilled)
+    const double *payl = coef + 4 * 64 * B;
+    if constexpr (AMER == 2) {
+        const double *__restrict__ pg = a.U0 + (size_t)inst * a.L.inst_stride;
+        double *pw = coef + 4 * 64 * B;
+        for (int e = threadIdx.x; e < rowp; e += 64 * NWV) pw[e] = pg[e];
     }
     __syncthreads();  // the only block-wide barrier: the coefficient arrays are shared
     const int j0 = (sb * NWV + wave) * a.RS;
@@ -1176,8 +1198,15 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 4 ? 2 : 4)) ha
     c.e_n = hadi_uniform_d(exp(ip.r_f * ip.dt * n));          // device_solver.hpp:246
     const T *__restrict__ Ub = reinterpret_cast<const T *>(a.U) + (size_t)inst * a.L.inst_stride;
     c.Yi = reinterpret_cast<T *>(a.Y) + (size_t)inst * a.L.inst_stride;
-    c.Li = AMER ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
+    c.Li = (AMER == 1) ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
     c.b2r = a.b2row + (size_t)inst * rowp;
+    // P representation: 1/dt, and which node is s_max (lambda_bar stays 0 there, as in hadi_row_step)
+    c.inv_dt = 0.0; c.m1_lane = -1; c.m1_r = -1;
+    if constexpr (AMER == 2) {
+        c.inv_dt = hadi_uniform_d(1.0 / ip.dt);
+        c.m1_lane = (a.L.m1 - 1) / B;
+        c.m1_r = (a.L.m1 - 1) - c.m1_lane * B;
+    }
 
     T *ring = reinterpret_cast<T *>(smem) + (size_t)wave * NS * rowp;
     auto slot = [&](int jj) { return ring + (size_t)(jj & (NS - 1)) * rowp; };
@@ -1205,13 +1234,24 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 4 ? 2 : 4)) ha
     // half the registers), current row (double: used throughout the step)
     T um2[B], um1[B];
     double u0[B];
-    double c0m2 = 0.0, c0m1 = 0.0, c00, c0p1;
+    // The i = 0 column of the five stencil rows is wave-uniform: ONE register pair carries it, spread over the lanes
+    // (lane k = row j - 2 + k in walking order), read with v_readlane where needed and shifted by a DPP move per step.
+    double c0vec;
     {
         double t2[B], t1[B];
 #pragma unroll
         for (int r = 0; r < B; r++) t2[r] = t1[r] = 0.0;
         if (row_ok(js - 2 * dir)) hadi_get_block<B, 1, T>(Ub + (ptrdiff_t)(js - 2 * dir) * rowp, 0, lane, t2);
         if (row_ok(js - dir)) hadi_get_block<B, 1, T>(Ub + (ptrdiff_t)(js - dir) * rowp, 0, lane, t1);
+        if constexpr (AMER == 2) {  // U = max(P, U_0) on the rows behind (the current row keeps its raw P for lambda_bar)
+            double pay[B];
+            hadi_get_block<B, 1>(payl, 0, lane, pay);
+#pragma unroll
+            for (int r = 0; r < B; r++) {
+                t2[r] = fmax(t2[r], pay[r]);
+                t1[r] = fmax(t1[r], pay[r]);
+            }
+        }
 #pragma unroll
         for (int r = 0; r < B; r++) {
             um2[r] = (T)t2[r];
@@ -1219,16 +1259,16 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 4 ? 2 : 4)) ha
         }
     }
     hadi_get_block<B, 1, T>(Ub + (size_t)js * rowp, 0, lane, u0);
-    if (row_ok(js - 2 * dir)) c0m2 = (double)Ub[(ptrdiff_t)(js - 2 * dir) * rowp + c0slot];
-    if (row_ok(js - dir)) c0m1 = (double)Ub[(ptrdiff_t)(js - dir) * rowp + c0slot];
-    c00 = (double)Ub[(size_t)js * rowp + c0slot];
-    c0p1 = row_ok(js + dir) ? (double)Ub[(ptrdiff_t)(js + dir) * rowp + c0slot] : 0.0;
+    {
+        const int rr = js + (lane - 2) * dir;
+        c0vec = (lane < 4 && row_ok(rr)) ? (double)Ub[(ptrdiff_t)rr * rowp + c0slot] : 0.0;
+    }
 #if !defined(HADI_EMU)
     // Consume the prologue's register loads HERE: otherwise hipcc parks their s_waitcnt vmcnt(0) at the loop header,
     // where it would retire the DMA prefetch and the result stores in every iteration.
 #pragma unroll
     for (int r = 0; r < B; r++) asm volatile("" : "+v"(um2[r]), "+v"(um1[r]), "+v"(u0[r]));  // (T and double operands)
-    asm volatile("" : "+v"(c0m2), "+v"(c0m1), "+v"(c00), "+v"(c0p1));
+    asm volatile("" : "+v"(c0vec));
 #endif
 
 #if defined(HADI_STAMPS) && !defined(HADI_EMU)
@@ -1254,7 +1294,10 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 4 ? 2 : 4)) ha
         double up1[B], up2[B];
         hadi_get_block<B, 1, T>(slot(j + dir), 0, lane, up1);
         hadi_get_block<B, 1, T>(slot(j + 2 * dir), 0, lane, up2);
-        const double c0p2 = (double)slot(j + 2 * dir)[c0slot];
+        {
+            const double c0new = (double)slot(j + 2 * dir)[c0slot];  // (every lane reads the same word)
+            c0vec = (lane == 4) ? c0new : c0vec;
+        }
         double rt[HADI_RCL];
         hadi_sload_wait(srow, rt);  // one lgkmcnt(0) for the table entry and the LDS reads above
         if (dir < 0) {  // descending: "behind" rows are j+1, j+2 -- swap the neighbour weights instead of the arrays
@@ -1270,8 +1313,29 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 4 ? 2 : 4)) ha
             dm2[r] = (double)um2[r];
             dm1[r] = (double)um1[r];
         }
-        if (j == nrows - 1) hadi_strip_step<B, AMER, true, T>(c, j, rt, dm2, dm1, u0, up1, up2, c0m2, c0m1, c00, c0p1, c0p2);
-        else hadi_strip_step<B, AMER, false, T>(c, j, rt, dm2, dm1, u0, up1, up2, c0m2, c0m1, c00, c0p1, c0p2);
+        double praw[B], lamc0 = 0.0;
+        const double c0m2 = hadi_read_lane(c0vec, 0), c0m1 = hadi_read_lane(c0vec, 1), c00 = hadi_read_lane(c0vec, 2);
+        const double c0p1 = hadi_read_lane(c0vec, 3), c0p2 = hadi_read_lane(c0vec, 4);
+        double e0m2 = c0m2, e0m1 = c0m1, e00 = c00, e0p1 = c0p1, e0p2 = c0p2;  // (the carried i = 0 values stay raw)
+#pragma unroll
+        for (int r = 0; r < B; r++) praw[r] = 0.0;
+        if constexpr (AMER == 2) {
+            double pay[B];
+            hadi_get_block<B, 1>(payl, 0, lane, pay);
+            const double pay_c0 = payl[c0slot];
+#pragma unroll
+            for (int r = 0; r < B; r++) {
+                praw[r] = u0[r];  // the raw P of row j: lambda_bar comes from it inside the step
+                u0[r] = fmax(u0[r], pay[r]);
+                up1[r] = fmax(up1[r], pay[r]);
+                up2[r] = fmax(up2[r], pay[r]);
+            }
+            lamc0 = fmax(0.0, (pay_c0 - c00) * c.inv_dt);
+            e0m2 = fmax(c0m2, pay_c0); e0m1 = fmax(c0m1, pay_c0); e00 = fmax(c00, pay_c0);
+            e0p1 = fmax(c0p1, pay_c0); e0p2 = fmax(c0p2, pay_c0);
+        }
+        if (j == nrows - 1) hadi_strip_step<B, AMER, true, T>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0);
+        else hadi_strip_step<B, AMER, false, T>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0);
         after0 += B / 2;  // the row's vector stores (the i = 0 store is not counted: lower bound)
         after1 += B / 2;
 #pragma unroll
@@ -1283,10 +1347,7 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 4 ? 2 : 4)) ha
 #if !defined(HADI_EMU)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and retired before the next step reuses that slot
 #endif
-        c0m2 = c0m1;
-        c0m1 = c00;
-        c00 = c0p1;
-        c0p1 = c0p2;
+        c0vec = hadi_lane_next(c0vec);  // lane k takes lane k + 1: one row on
 #if defined(HADI_STAMPS) && !defined(HADI_EMU)
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev_) :: "memory");  // the step stamped itself
 #endif

@@ -75,7 +75,15 @@ static void run_pass_a_amp(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
                 pl.smem_a + (size_t)pl.L.rowp * sizeof(double));
 }
 static int run_sweep_amp(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
-    switch (pl.L.B * 10 + pl.L.G) {
+    if (pl.use_strip) {  // same choice as hadi_api.hip
+        const unsigned nt = 64 * HADI_STRIP_WAVES(pl.L.B);
+        const size_t sm = pl.smem_as + (size_t)pl.L.rowp * sizeof(double);
+        switch (pl.L.B) {
+            case 8: emu::launch(pl.grid_as, nt, [&]() { hadi_pass_a_strip<8, 2>(a, n); }, sm); break;
+            case 4: emu::launch(pl.grid_as, nt, [&]() { hadi_pass_a_strip<4, 2>(a, n); }, sm); break;
+            default: emu::launch(pl.grid_as, nt, [&]() { hadi_pass_a_strip<2, 2>(a, n); }, sm); break;
+        }
+    } else switch (pl.L.B * 10 + pl.L.G) {
         case 11: run_pass_a_amp<1, 1, 1, 2>(pl, a, n); break;
         case 21: run_pass_a_amp<2, 1, 1, 2>(pl, a, n); break;
         case 41: run_pass_a_amp<4, 1, 1, 2>(pl, a, n); break;

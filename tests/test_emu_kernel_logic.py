@@ -112,6 +112,11 @@ def test_american_p_representation(emu):
     _run(emu, 200, 60, 12, [100.0], O.AM_DIV, 8, scheme=3)
     _run(emu, 530, 10, 3, [100.0], O.AM, 8, scheme=3)
     _run(emu, 280, 265, 2, [97.0], O.AM, 1, scheme=3)
+    # batches large enough for the strip row pass: 8 nodes per lane (payoff row in LDS), with dividend steps in between,
+    # and 4-strip blocks at 2 nodes per lane
+    _run(emu, 300, 150, 3, [100.0], O.AM, 1, r_f=0.01, scheme=3)
+    _run(emu, 300, 140, 12, [95.0], O.AM_DIV, 1, scheme=3)
+    _run(emu, 100, 70, 3, [100.0, 95.0, 105.0, 90.0], O.AM, 1, scheme=3)
 
 
 def test_two_waves_per_row_split_solve(emu):

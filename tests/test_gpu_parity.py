@@ -563,6 +563,23 @@ def test_strip_row_pass_vs_oracle(solver, monkeypatch, variant, name, m1, m2, N,
         assert np.abs(lam - lo).max() <= 1e-8 * max(1.0, np.abs(lo).max())
 
 
+@pytest.mark.parametrize("variant,name", [(H.AM, "AM"), (H.AM_DIV, "AM_DIV")])
+@pytest.mark.parametrize("m1,m2,N,n", [(512, 256, 12, 2), (300, 140, 25, 2), (256, 128, 25, 3), (128, 64, 10, 2)])
+def test_strip_row_pass_with_the_p_representation(solver, monkeypatch, variant, name, m1, m2, N, n):
+    """American sweeps in the P representation on the barrier-free strips (chosen by itself for large batches at 8 and 2
+    nodes per lane; forced here): U = max(P, U_0) rebuilt on the register window and the ring rows, lambda_bar from the
+    raw P of row j, payoff row in LDS.  N = 25 puts dividend steps (explicit pair, materialise / dematerialise) in between."""
+    monkeypatch.setenv("HADI_TUNE_STRIP", "1")
+    strikes = Cm.strikes_for(n)
+    grids, U0, U, lam = _hadi_solve(solver, m1, m2, N, strikes, variant, r_f=0.01, want_lambda=True)
+    d = solver.describe_last_sweep()
+    assert "hadi_pass_a_strip" in d and "AM-P" in d
+    p = Cm.oracle_params(m1, m2, N, name, r_f=0.01)
+    Uo, lo, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0, want_lambda=True)
+    _assert_field(U, Uo)
+    assert np.abs(lam - lo).max() <= 1e-8 * max(1.0, np.abs(lo).max())
+
+
 @pytest.mark.parametrize("theta", [0.0, 0.5, 1.0])
 def test_strip_row_pass_theta_range(solver, monkeypatch, theta):
     """The strip kernel forms I - theta dt A1 directly and rebuilds the explicit A1 action from it with the factor
