@@ -958,7 +958,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
                                                const double (&um2)[B], const double (&um1)[B], const double (&u0)[B],
                                                const double (&up1)[B], const double (&up2)[B], double c0m2, double c0m1,
                                                double c00, double c0p1, double c0p2, const double (&p_raw)[B],
-                                               double lamc0_in) {
+                                               double lamc0_in, const T *next_row, double (&u_next)[B]) {
     const int lane = c.lane, rowp = c.rowp;
     constexpr int c0slot = 64 * B;
     constexpr int NB = B - 1;
@@ -1132,6 +1132,9 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
     }
     HADI_STAMPC(28);  // PCR
     hadi_set_prio(0);
+    // the next row (this step's "row ahead") again from its ring slot, intact until the next step: issued here so that the
+    // read flies during the final combination and the stores instead of being waited for at the end of the step
+    hadi_get_block<B, 1, T>(next_row, 0, lane, u_next);
     const double X = rf;
     const double XL = hadi_lane_prev(X);
     // ---- Y1 -> right-hand side of the A2 solve (device_solver.hpp:254-260) and store ----------
@@ -1334,18 +1337,19 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 4 ? 2 : 4)) ha
             e0m2 = fmax(c0m2, pay_c0); e0m1 = fmax(c0m1, pay_c0); e00 = fmax(c00, pay_c0);
             e0p1 = fmax(c0p1, pay_c0); e0p2 = fmax(c0p2, pay_c0);
         }
-        if (j == nrows - 1) hadi_strip_step<B, AMER, true, T>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0);
-        else hadi_strip_step<B, AMER, false, T>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0);
+        double un[B];
+        if (j == nrows - 1) hadi_strip_step<B, AMER, true, T>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un);
+        else hadi_strip_step<B, AMER, false, T>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un);
         after0 += B / 2;  // the row's vector stores (the i = 0 store is not counted: lower bound)
         after1 += B / 2;
 #pragma unroll
         for (int r = 0; r < B; r++) {
             um2[r] = um1[r];
             um1[r] = (T)u0[r];
+            u0[r] = un[r];
         }
-        hadi_get_block<B, 1, T>(slot(j + dir), 0, lane, u0);  // again from its slot (intact until the next step) rather than held in registers
 #if !defined(HADI_EMU)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and retired before the next step reuses that slot
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the re-read is retired before the next step reuses that slot
 #endif
         c0vec = hadi_lane_next(c0vec);  // lane k takes lane k + 1: one row on
 #if defined(HADI_STAMPS) && !defined(HADI_EMU)
