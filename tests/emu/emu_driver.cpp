@@ -113,6 +113,18 @@ extern "C" int emu_plan(int m1, int m2, int n_inst, int target_waves, int *out /
     return 0;
 }
 
+// every launch-geometry field of the plan, for the host-logic invariants test
+extern "C" int emu_plan_full(int m1, int m2, int n_inst, int target_waves, long long *o /*[24]*/) {
+    HadiPlan pl;
+    if (hadi_make_plan(m1, m2, n_inst, target_waves, &pl)) return 1;
+    const HadiLayout &L = pl.L;
+    o[0] = L.B; o[1] = L.G; o[2] = L.rowp; o[3] = L.P; o[4] = L.nrows; o[5] = L.nrows_pad; o[6] = L.inst_stride;
+    o[7] = pl.W; o[8] = pl.NG; o[9] = pl.PD; o[10] = pl.R; o[11] = pl.ntiles; o[12] = pl.grid_a; o[13] = (long long)pl.smem_a;
+    o[14] = pl.use_strip; o[15] = pl.RS; o[16] = pl.sblocks; o[17] = pl.grid_as; o[18] = (long long)pl.smem_as;
+    o[19] = pl.ctiles; o[20] = pl.btpw; o[21] = pl.bgroups; o[22] = pl.grid_b; o[23] = (long long)pl.smem_b;
+    return 0;
+}
+
 // variant bit0 = american, bit1 = dividends.  Arrays natural layout [n][...].
 extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double theta, double r_d, double r_f,
                          const double *par /*[n][4] rho sigma kappa eta*/, int variant, const double *vec_s,

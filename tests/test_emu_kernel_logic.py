@@ -142,6 +142,41 @@ def test_small_grid_lds_resident_kernel(emu):
     _run(emu, 100, 30, 3, [96.0], O.EU, 8, r_f=0.01, small=2)
 
 
+def test_plan_invariants_over_shapes_and_batch_sizes(emu):
+    """Host logic (hadi_plan.h): for every supported shape and a range of batch sizes the launch geometry covers all rows,
+    columns and instances, and every kernel's dynamic LDS fits the 160 KB of a CU (incl. the payoff row the American P
+    representation adds to the row kernels)."""
+    LDS = 160 * 1024
+    o = (C.c_longlong * 24)()
+    shapes = [(m1, m2) for m1 in (20, 50, 64, 65, 100, 128, 129, 200, 256, 257, 300, 400, 512, 513, 700, 1024)
+              for m2 in (8, 25, 32, 33, 64, 66, 100, 128, 131, 132, 200, 256, 263, 264, 300, 512) if m2 <= m1]
+    seen_strip = set()
+    for m1, m2 in shapes:
+        for n in (1, 3, 64, 160, 256, 300, 512, 1100, 4000):
+            for tw in (8, 2048):  # emulator-sized and MI355X-sized (8 wavefronts x 256 CUs)
+                assert emu.emu_plan_full(m1, m2, n, tw, o) == 0, (m1, m2, n)
+                (B, G, rowp, P, nrows, npad, stride, W, NG, PD, R, ntiles, grid_a, smem_a, use_strip, RS, sblocks, grid_as,
+                 smem_as, ctiles, btpw, bgroups, grid_b, smem_b) = list(o)
+                assert nrows == m2 + 1 and npad == 33 * P and npad >= nrows and stride == rowp * npad
+                assert 64 * B * G >= m1 and rowp == 64 * B * G + 8 and B in (1, 2, 4, 8) and G in (1, 2)
+                assert R % W == 0 and R * ntiles >= nrows and grid_a * NG >= n * ntiles
+                assert smem_a + rowp * 8 <= LDS
+                nwv = 8 if B == 8 else 4
+                if B >= 2 and G == 1:  # strips can be forced for any of these (HADI_TUNE_STRIP), so check them all
+                    assert RS * nwv * sblocks >= nrows and grid_as >= n * sblocks
+                    assert smem_as + rowp * 8 <= LDS
+                else:
+                    assert not use_strip
+                if use_strip:
+                    assert B in (2, 8) and 16 <= RS <= 64
+                    seen_strip.add(B)
+                assert btpw * bgroups >= ctiles and (btpw - 1) * bgroups < ctiles + bgroups and ctiles * 64 >= rowp
+                assert grid_b == n * bgroups and smem_b <= LDS and P <= 16
+    assert seen_strip == {2, 8}
+    assert emu.emu_plan_full(100, 101, 1, 8, o) != 0 and emu.emu_plan_full(1025, 100, 1, 8, o) != 0  # m2 > m1, m1 too wide
+    assert emu.emu_plan_full(600, 528, 1, 8, o) != 0  # more than 16 chunks
+
+
 def test_setup_tables_against_oracle_operators(emu):
     """The O(m1+m2) tables reproduce the reference's dense operators: apply them to a random field and
     compare with the oracle's A0U / A1U / A2U of step 1."""
