@@ -775,7 +775,13 @@ HADI_DEV HADI_FORCEINLINE void hadi_wait_vmcnt(int n) {
         case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
         case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
         case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+        case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+        case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+        case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;  // n >= 25: stricter than asked, still safe
     }
 #else
     (void)n;
@@ -1284,13 +1290,14 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 4 ? 2 : 4)) ha
         HADI_STAMPC(30);  // carry + loop
         HadiSRow srow;
         hadi_sload_issue(a.rowc + ((size_t)inst * nrows + j) * HADI_RC, srow);  // flies during the DMA wait
-        hadi_wait_vmcnt(after0);  // the row two ahead has landed (the row one ahead landed a step earlier)
-        HADI_STAMPC(24);  // wait for the DMA
         hadi_wave_rendezvous();
         // the row four ahead goes to the slot of row j: row j is in registers, and this wavefront's last read of that
-        // slot (the reload at the end of the previous step) has been retired there
+        // slot (the re-read in the previous step) has been retired there.  Issued BEFORE the wait below, so that the
+        // prefetch does not queue behind it.
         int z = 0;
         if (t + 4 <= cnt + 1) z = fetch(j + 4 * dir);
+        hadi_wait_vmcnt(after0 + z);  // the row two ahead has landed (the row one ahead landed a step earlier)
+        HADI_STAMPC(24);  // wait for the DMA
         after0 = after1 + z;
         after1 = 0;
         hadi_wave_rendezvous();
