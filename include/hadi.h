@@ -48,7 +48,7 @@ extern "C" {
 #endif
 
 #define HADI_VERSION_MAJOR 0
-#define HADI_VERSION_MINOR 1
+#define HADI_VERSION_MINOR 2
 
 typedef struct hadi_ctx hadi_ctx;
 
@@ -74,6 +74,17 @@ enum hadi_scheme { HADI_SCHEME_DOUGLAS = 0, HADI_SCHEME_CRAIG_SNEYD = 1 };
  * evaluated in fp64 in registers.  European Douglas sweeps only; the caller's arrays stay fp64.  Not a reference
  * feature: parity is against the oracle run with the same two roundings per step (tests), ~1e-6 relative to fp64. */
 enum hadi_state_precision { HADI_STATE_FP64 = 0, HADI_STATE_FP32 = 1 };
+/* Boundary data of the option type.  HADI_CALL is the reference's only boundary class (call-specific,
+ * src/BoundaryConditions.hpp:7-12, hes_boundary_kernels.hpp:41-75).  HADI_PUT is NOT a reference feature (README.md:26
+ * claims puts, no code exists): the same operators with the put's boundary data --
+ *   s = s_max:  du/ds = 0             -> b1 == 0                  (call: du/ds = e^{-r_f t} -> b1 = (r_d - r_f) s_max E)
+ *   v = v_max:  u = K e^{-r_d t}      -> b2 = -1/2 r_d K on the last v-row, time factor e^{-r_d dt n}
+ *                                                                  (call: u = s e^{-r_f t} -> b2 = -1/2 r_d s_i E)
+ *   s = 0:      u = K e^{-r_d t}      -> the i = 0 row of A1 carries the reaction term -1/2 r_d like every other row
+ *                                        (the call leaves that row empty, hes_a1_kernels.hpp:56-61: its value stays 0)
+ *   v = 0 and the two top v-rows: the PDE rows / empty rows of A2 exactly as for the call.
+ * Needs hadi_problem.strike_i.  Validated by put-call parity against the call path and the semi-analytic Heston price. */
+enum hadi_option_type { HADI_CALL = 0, HADI_PUT = 1 };
 
 /* One batch of independent option instances = one league of teams in the reference
  * (TeamPolicy(nInstances, AUTO), device_solver.hpp:83-88). */
@@ -118,6 +129,14 @@ typedef struct hadi_problem {
     int scheme;
     /* enum hadi_state_precision; 0 (fp64) is what every reference launcher runs */
     int state_precision;
+    /* enum hadi_option_type; 0 (call boundary data) is what every reference launcher runs */
+    int option_type;
+    /* strikes, host array [n]; required for HADI_PUT (boundary value K e^{-r_d t}), ignored for HADI_CALL */
+    const double *strike_i;
+    /* hadi_compute_base_prices* / hadi_compute_jacobian* only: per-instance V_0 (host array [n]) overriding the
+     * scalar argument -- every instance's v-grid is rebuilt on the device for its own V_0, as every team of the
+     * reference does in-kernel (GridViews::rebuild_variance_views, src/grid_pod.hpp:25-73).  NULL = the scalar V_0. */
+    const double *V_0_i;
 } hadi_problem;
 
 /* Timing of the last sweep on this handle, measured with HIP events on the handle's
@@ -140,17 +159,33 @@ const char *hadi_status_string(int status);
 int hadi_version(void);
 int hadi_set_profiling(hadi_ctx *ctx, int enabled);
 int hadi_get_timing(const hadi_ctx *ctx, hadi_timing *out);
-/* Execution-path switches (results agree to round-off): "small_grid" = LDS-resident one-launch path for grids that fit
- * in LDS (default 1), "graph" = hipGraph replay of the time loop for small batches (default 1), "american_p" = American
- * sweeps keep P = U_bar - dt*lambda_bar in place of U and no lambda_bar array whenever every payoff of the batch depends
- * on s only (default 1; 0 = always the explicit (U, lambda_bar) pair). */
+/* Execution-path switches (results agree to round-off; the library reads NO environment variables):
+ *   "small_grid"  LDS-resident one-launch path for grids that fit in LDS (default 1)
+ *   "graph"       hipGraph replay of the time loop for small batches (default 1)
+ *   "american_p"  American sweeps keep P = U_bar - dt*lambda_bar in place of U and no lambda_bar array whenever every
+ *                 payoff of the batch depends on s only (default 1; 0 = always the explicit (U, lambda_bar) pair)
+ *   "strip"       strip row pass: -1 automatic (default), 0 never, 1 whenever the geometry allows it
+ *   "row_tile"    shared-ring row pass: v-rows per block tile (0 = automatic)
+ *   "col_groups"  column pass: blocks per instance (0 = automatic)
+ *   "small_waves" small-grid kernel: wavefronts per instance, 4 or 8 (0 = automatic)
+ *   "device_vgrid" v-grids of compute_base_prices / compute_jacobian rebuilt per instance on the device (default 1;
+ *                 0 = built once on the host with glibc sinh/asinh and broadcast -- bit-identical to the reference's
+ *                 host-side Grid, needs one shared V_0) */
 int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value);
+int hadi_get_tuning(const hadi_ctx *ctx, const char *key, int *value);
 /* Device the handle runs on: name, CU count, gcn arch string (for bench reports). */
 int hadi_device_info(const hadi_ctx *ctx, char *name, int name_len, int *compute_units, char *arch, int arch_len);
 /* Which kernels the last sweep on this handle ran (kernel names and tile geometry), for bench reports and profiles. */
 int hadi_describe_last_sweep(const hadi_ctx *ctx, char *buf, int len);
 /* Opaque hipStream_t of the handle (void*), so callers can order their own work after it. */
 void *hadi_stream(hadi_ctx *ctx);
+/* Input ordering (HADI_MEM_DEVICE).  The handle runs on its own non-blocking stream, which does not wait for the
+ * caller's streams: work the caller enqueued on `producer_stream` (a hipStream_t; NULL = the legacy default stream)
+ * that writes arrays of the next hadi_* call must be ordered before it with this call (an event is recorded on
+ * `producer_stream` and the handle's stream waits for it; nothing blocks on the host), or the caller must synchronise
+ * that stream itself.  The reference gets the same guarantee from deep_copy + Kokkos::fence (device_solver.cpp:718-726).
+ * Outputs need no such call: every hadi_* entry point returns after its results are complete. */
+int hadi_wait_stream(hadi_ctx *ctx, void *producer_stream);
 
 /* ---- grids (host code, no GPU needed) ------------------------------------------------------ */
 int hadi_make_grid(int m1, double S, double S_0, double K, double c,
@@ -192,11 +227,26 @@ int hadi_compute_jacobian_american_dividends(hadi_ctx *ctx, const hadi_problem *
  * partial[0..24] = J^T J (row-major), partial[25..29] = J^T r, partial[30] = sum r^2.
  * The 31 doubles are what gets all-reduced across GPUs. */
 int hadi_lm_partials(int n, const double *J, const double *residuals, double *partial31);
+/* The same reduction on the GPU (replaces KokkosBlas gemm/gemv + the residual kernel, src/jacobian_computation.cpp:117,
+ * 154, heston_calibration.cpp:271-275): J [n][5], model prices [n] and market prices [n] are DEVICE arrays (what
+ * hadi_compute_jacobian wrote with HADI_MEM_DEVICE); r = market - model; the 31 doubles come back to the host array
+ * partial31 -- the only data that leaves the GPU per LM iteration.  Deterministic (fixed-shape tree reduction). */
+int hadi_lm_partials_device(hadi_ctx *ctx, int n, const double *J, const double *model_prices,
+                            const double *market_prices, double *partial31);
 /* delta = (J^T J with diagonal *(1+lambda))^-1 J^T r by 5x5 partial-pivot elimination. */
 int hadi_lm_solve(const double *partial31, double lambda, double *delta5);
 /* Both steps on one rank: compute_parameter_update_on_device. */
 int hadi_compute_parameter_update(int n, const double *J, const double *residuals, double lambda,
                                   double *delta5);
+
+
+/* ---- diagnostics (tests): the two directional passes of ONE Douglas step as operators ----------------------------
+ * hadi_debug_row_pass:   Y1rhs = what the row pass of step `step` hands to the A2 solve (device_solver.hpp:236-260:
+ *                        explicit stage, A1 line solve, + theta dt (b2 (e_n - e_{n-1}) - A2 U)), from p->U as U_{n-1}.
+ * hadi_debug_col_solve:  X = (I - theta dt A2)^{-1} p->U  (hes_a2_shuffled_kernels.hpp:243-299), European, no projection.
+ * Both run the product kernels the batch shape selects; p->U is not modified; out is [n][m] in p->memspace. */
+int hadi_debug_row_pass(hadi_ctx *ctx, const hadi_problem *p, int step, double *Y1rhs);
+int hadi_debug_col_solve(hadi_ctx *ctx, const hadi_problem *p, double *X);
 
 #ifdef __cplusplus
 }

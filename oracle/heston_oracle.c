@@ -156,12 +156,18 @@ static void ws_free(ho_ws *w) {
 }
 
 /* ---- hes_boundary_kernels.hpp:41-75 --------------------------------------- */
-static void bc_initialize(ho_ws *w, const double *vec_s, double r_d, double r_f, int N, double dt) {
+static void bc_initialize(ho_ws *w, const double *vec_s, double r_d, double r_f, int N, double dt, int put, double strike) {
     const int m1 = w->m1, m2 = w->m2, m = w->m;
     memset(w->b0, 0, sizeof(double) * m);
     memset(w->b1, 0, sizeof(double) * m);
     memset(w->b2, 0, sizeof(double) * m);
     memset(w->b, 0, sizeof(double) * m);
+    if (put) { /* NOT in the reference (see ho_params.option_type): b1 == 0; b2 makes u = K e^{-r_d t} exact on the last
+                * v-row; the time factor e^{-r_d dt n} is applied by timestepping() */
+        for (int i = 0; i <= m1; i++) w->b2[m - m1 - 1 + i] = -0.5 * r_d * strike;
+        for (int i = 0; i < m; i++) w->b[i] = w->b0[i] + w->b1[i] + w->b2[i];
+        return;
+    }
     for (int j = 0; j <= m2; j++) {
         const double exp_factor = exp(-r_f * dt * (N - 1));
         const long idx = (long)m1 * (j + 1); /* (quirk) not m1 + j*(m1+1) */
@@ -214,13 +220,17 @@ static void a0_multiply(const ho_ws *w, const double *x, double *result) {
 
 /* ---- hes_a1_kernels.hpp:51-107 -------------------------------------------- */
 static void a1_build(ho_ws *w, const double *vec_s, const double *vec_v, const double *ds,
-                     double r_d, double r_f, double theta, double dt) {
+                     double r_d, double r_f, double theta, double dt, int put) {
     const int m1 = w->m1, m2 = w->m2, ld = m1 + 1;
     for (int j = 0; j <= m2; j++) {
         double *mn = w->a1_main + (size_t)j * ld, *lo = w->a1_lower + (size_t)j * ld, *up = w->a1_upper + (size_t)j * ld;
         double *imn = w->a1_imain + (size_t)j * ld, *ilo = w->a1_ilower + (size_t)j * ld, *iup = w->a1_iupper + (size_t)j * ld;
         mn[0] = 0.0; imn[0] = 1.0;
         up[0] = 0.0; iup[0] = 0.0; /* reference guards j<m2; row m2 stays View-zero: same value */
+        if (put) { /* NOT in the reference: the s = 0 row carries the reaction term, so that u(0) = K e^{-r_d t} */
+            mn[0] = -0.5 * r_d;
+            imn[0] = 1.0 - theta * dt * mn[0];
+        }
         for (int i = 1; i < m1; i++) {
             const double s = vec_s[i];
             const double v = vec_v[j];
@@ -393,7 +403,7 @@ static void a2_solve(ho_ws *w, double *x, const double *b) {
 }
 
 /* ---- device_solver.hpp:448-504 (dividend jump) ----------------------------- */
-static void dividend_jump(ho_ws *w, const double *vec_s, double *U, double amount, double pct) {
+static void dividend_jump(ho_ws *w, const double *vec_s, double *U, double amount, double pct, int put) {
     const int m1 = w->m1, m2 = w->m2, m = w->m;
     memcpy(w->Utmp, U, sizeof(double) * m);
     for (int j = 0; j <= m2; j++) {
@@ -416,7 +426,8 @@ static void dividend_jump(ho_ws *w, const double *vec_s, double *U, double amoun
                     U[offset + i] = w->Utmp[offset + m1]; /* unreachable (quirk) */
                 }
             } else {
-                U[offset + i] = 0.0;
+                /* ex-dividend spot <= 0: a call is worth 0 (device_solver.hpp:499-503); put extension: its s = 0 value */
+                U[offset + i] = put ? w->Utmp[offset] : 0.0;
             }
         }
     }
@@ -425,7 +436,7 @@ static void dividend_jump(ho_ws *w, const double *vec_s, double *U, double amoun
 static void build_all(ho_ws *w, const ho_params *p, const double *vec_s, const double *vec_v,
                       const double *ds, const double *dv, double rho, double sigma, double kappa, double eta) {
     a0_build(w, vec_s, vec_v, ds, dv, rho, sigma);
-    a1_build(w, vec_s, vec_v, ds, p->r_d, p->r_f, p->theta, p->delta_t);
+    a1_build(w, vec_s, vec_v, ds, p->r_d, p->r_f, p->theta, p->delta_t, p->option_type == 1);
     a2_build(w, vec_v, dv, p->r_d, kappa, eta, sigma, p->theta, p->delta_t);
 }
 
@@ -472,7 +483,10 @@ static void timestepping(ho_ws *w, const ho_params *p, const double *vec_s,
         return;
     }
     const int m1 = w->m1, m = w->m, N = p->N;
-    const double delta_t = p->delta_t, theta = p->theta, r_f = p->r_f;
+    const double delta_t = p->delta_t, theta = p->theta;
+    /* boundary data carry exp(rate dt n): rate = r_f in the reference (device_solver.hpp:238,246); -r_d for the put
+     * extension (boundary value K e^{-r_d t}).  The variable keeps the reference's name. */
+    const double r_f = (p->option_type == 1) ? -p->r_d : p->r_f;
     const int american = (p->variant == HO_AM || p->variant == HO_AM_DIV);
     const int dividend = (p->variant == HO_DIV || p->variant == HO_AM_DIV);
     int current_div_idx = 0;
@@ -493,7 +507,7 @@ static void timestepping(ho_ws *w, const ho_params *p, const double *vec_s,
                                  t <= p->div_dates[current_div_idx] &&
                                  p->div_dates[current_div_idx] < (n + 1) * delta_t);
             if (process)
-                dividend_jump(w, vec_s, U, p->div_amounts[current_div_idx], p->div_percentages[current_div_idx]);
+                dividend_jump(w, vec_s, U, p->div_amounts[current_div_idx], p->div_percentages[current_div_idx], p->option_type == 1);
             if (current_div_idx < p->num_dividends && t > p->div_dates[current_div_idx]) current_div_idx++;
         }
         a0_multiply(w, U, w->A0U);
@@ -554,7 +568,7 @@ int ho_solve(const ho_params *p, const double *vec_s, const double *vec_v,
         if (!lambda_bar) { lam_own = zalloc((size_t)(p->m1 + 1) * (p->m2 + 1)); lambda_bar = lam_own; }
     }
     ho_ws *w = ws_new(p->m1, p->m2);
-    bc_initialize(w, vec_s, p->r_d, p->r_f, p->N, p->delta_t);
+    bc_initialize(w, vec_s, p->r_d, p->r_f, p->N, p->delta_t, p->option_type == 1, p->strike);
     build_all(w, p, vec_s, vec_v, delta_s, delta_v, p->rho, p->sigma, p->kappa, p->eta);
     if (dump) {
         if (dump->b) memcpy(dump->b, w->b, sizeof(double) * w->m);
@@ -564,6 +578,26 @@ int ho_solve(const ho_params *p, const double *vec_s, const double *vec_v,
     timestepping(w, p, vec_s, U, U_0, lambda_bar, dump);
     ws_free(w);
     free(lam_own);
+    return 0;
+}
+
+/* The reference's per-operator acceptance drivers, see heston_oracle.h. */
+int ho_operator(const ho_params *p, int which,
+                const double *vec_s, const double *vec_v, const double *delta_s, const double *delta_v,
+                const double *x, const double *b, double *result, double *xsol) {
+    if (p->m1 < 2 || p->m2 < 3 || which < 0 || which > 2) return -1;
+    ho_ws *w = ws_new(p->m1, p->m2);
+    build_all(w, p, vec_s, vec_v, delta_s, delta_v, p->rho, p->sigma, p->kappa, p->eta);
+    if (which == 0) {
+        if (result) a0_multiply(w, x, result);
+    } else if (which == 1) {
+        if (result) a1_multiply(w, x, result);
+        if (xsol) a1_solve(w, xsol, b);
+    } else {
+        if (result) a2_multiply(w, x, result);
+        if (xsol) a2_solve(w, xsol, b);
+    }
+    ws_free(w);
     return 0;
 }
 
@@ -590,7 +624,9 @@ int ho_solve_batch(const ho_params *p, int n,
     const int t = pick_threads(threads, n);
 #pragma omp parallel for num_threads(t) schedule(dynamic, 1)
     for (int k = 0; k < n; k++) {
-        ho_solve(p, vec_s + (size_t)k * (p->m1 + 1), vec_v + (size_t)k * (p->m2 + 1),
+        ho_params pk = *p;
+        if (p->strike_i) pk.strike = p->strike_i[k];
+        ho_solve(&pk, vec_s + (size_t)k * (p->m1 + 1), vec_v + (size_t)k * (p->m2 + 1),
                  delta_s + (size_t)k * p->m1, delta_v + (size_t)k * p->m2,
                  U + k * m, U_0 ? U_0 + k * m : NULL, lambda_bar ? lambda_bar + k * m : NULL, NULL);
     }
@@ -610,7 +646,9 @@ int ho_base_prices(const ho_params *p, int n, double S_0, double V_0, double V, 
         const double *vs = vec_s + (size_t)k * (m1 + 1);
         double *vv = vec_v + (size_t)k * (m2 + 1), *dvv = delta_v + (size_t)k * m2;
         ho_rebuild_variance(m2, V_0, V, d, vv, dvv);
-        ho_solve(p, vs, vv, delta_s + (size_t)k * m1, dvv, U + k * m, U_0 ? U_0 + k * m : NULL, NULL, NULL);
+        ho_params pk = *p;
+        if (p->strike_i) pk.strike = p->strike_i[k];
+        ho_solve(&pk, vs, vv, delta_s + (size_t)k * m1, dvv, U + k * m, U_0 ? U_0 + k * m : NULL, NULL, NULL);
         const int is = ho_find_s_index(m1, vs, S_0);
         const int iv = ho_find_v_index(m2, vv, V_0);
         if (is < 0) {
@@ -640,7 +678,10 @@ int ho_jacobian(const ho_params *p, int n, double S_0, double V_0, double V, dou
         double *U = zalloc(m), *lam = zalloc(m);
         ho_ws *w = ws_new(m1, m2);
         ho_rebuild_variance(m2, V_0, V, d, vv, dvv);
-        bc_initialize(w, vs, p->r_d, p->r_f, p->N, p->delta_t); /* built once (jacobian_computation.cpp:255) */
+        ho_params pkv = *p;
+        if (p->strike_i) pkv.strike = p->strike_i[k];
+        const ho_params *const pk = &pkv;
+        bc_initialize(w, vs, pk->r_d, pk->r_f, pk->N, pk->delta_t, pk->option_type == 1, pk->strike); /* built once (jacobian_computation.cpp:255) */
         const int is = ho_find_s_index(m1, vs, S_0);
         const int iv = ho_find_v_index(m2, vv, V_0);
         if (is < 0) {
@@ -649,8 +690,8 @@ int ho_jacobian(const ho_params *p, int n, double S_0, double V_0, double V, dou
         }
         const int isx = is < 0 ? 0 : is;
         memcpy(U, u0, sizeof(double) * m);
-        build_all(w, p, vs, vv, dss, dvv, p->rho, p->sigma, p->kappa, p->eta);
-        timestepping(w, p, vs, U, u0, lam, NULL);
+        build_all(w, pk, vs, vv, dss, dvv, p->rho, p->sigma, p->kappa, p->eta);
+        timestepping(w, pk, vs, U, u0, lam, NULL);
         const double base = U[isx + (size_t)iv * (m1 + 1)];
         base_prices[k] = base;
         for (int param = 0; param < 4; param++) {
@@ -662,15 +703,15 @@ int ho_jacobian(const ho_params *p, int n, double S_0, double V_0, double V, dou
                 case 3: rho_p += eps; break;
             }
             memcpy(U, u0, sizeof(double) * m);
-            build_all(w, p, vs, vv, dss, dvv, rho_p, sigma_p, kappa_p, eta_p);
-            timestepping(w, p, vs, U, u0, lam, NULL);
+            build_all(w, pk, vs, vv, dss, dvv, rho_p, sigma_p, kappa_p, eta_p);
+            timestepping(w, pk, vs, U, u0, lam, NULL);
             J[(size_t)k * 5 + param] = (U[isx + (size_t)iv * (m1 + 1)] - base) / eps;
         }
         memcpy(U, u0, sizeof(double) * m);
         ho_rebuild_variance(m2, V_0 + eps, V, d, vv, dvv); /* boundary vectors NOT rebuilt */
         const int ivp = ho_find_v_index(m2, vv, V_0 + eps);
-        build_all(w, p, vs, vv, dss, dvv, p->rho, p->sigma, p->kappa, p->eta);
-        timestepping(w, p, vs, U, u0, lam, NULL);
+        build_all(w, pk, vs, vv, dss, dvv, p->rho, p->sigma, p->kappa, p->eta);
+        timestepping(w, pk, vs, U, u0, lam, NULL);
         J[(size_t)k * 5 + 4] = (U[isx + (size_t)ivp * (m1 + 1)] - base) / eps;
         ws_free(w);
         free(U); free(lam);

@@ -31,6 +31,13 @@ typedef struct ho_params {
     int scheme; /* 0 = Douglas (device_solver.hpp), 1 = Craig-Sneyd (solver.hpp:781-907, European only) */
     int state_fp32; /* 1 = round the state to float between the directional passes (checker for libhadi's fp32-state
                      * sweep; NOT a reference feature, European Douglas only) */
+    /* Put boundary data (checker for libhadi's HADI_PUT; NOT a reference feature -- the reference's only boundary class
+     * is call-specific, BoundaryConditions.hpp:7-12).  option_type 1: b1 == 0 (du/ds = 0 at s_max), b2 = -1/2 r_d K on
+     * the last v-row with time factor e^{-r_d dt n} (u = K e^{-r_d t} at v_max), and the i = 0 row of A1 carries the
+     * reaction term -1/2 r_d (u = K e^{-r_d t} at s = 0).  `strike` is K; batch calls read strike_i[k] when non-NULL. */
+    int option_type;
+    double strike;
+    const double *strike_i;
 } ho_params;
 
 /* Optional capture of the intermediates of time step `step` (1-based); every
@@ -88,6 +95,17 @@ int ho_jacobian(const ho_params *p, int n, double S_0, double V_0, double V, dou
 /* solve_5x5_device + compute_parameter_update_on_device
  * (jacobian_computation.cpp:20-195): delta = (J^T J (.) (1+lambda on diag))^-1 J^T r */
 void ho_lm_update(int n, const double *J, const double *residuals, double lambda, double *delta);
+
+/* The reference's per-operator acceptance drivers (hes_a0_kernels.cpp:8-121, hes_a1_kernels.cpp:130-277,
+ * hes_a2_shuffled_kernels.cpp:13-157,271-277): build the three operators for one instance, then
+ *   which = 0: result = A0 x                              (multiply_parallel_v)
+ *   which = 1: result = A1 x,  xsol = (I - theta dt A1)^{-1} b   (multiply_parallel_v, solve_implicit_parallel_v)
+ *   which = 2: result = A2 x,  xsol = (I - theta dt A2)^{-1} b   (multiply_parallel_s, solve_implicit_parallel_s;
+ *              x, b, result, xsol in the NATURAL layout idx = i + j (m1+1): the shuffle is internal)
+ * so that a test can form the printed residual ||xsol - theta dt A xsol - b||_2.  result / xsol may be NULL. */
+int ho_operator(const ho_params *p, int which,
+                const double *vec_s, const double *vec_v, const double *delta_s, const double *delta_v,
+                const double *x, const double *b, double *result, double *xsol);
 
 int ho_max_threads(void);
 

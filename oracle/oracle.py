@@ -26,6 +26,9 @@ class _Params(C.Structure):
         ("div_dates", _dp), ("div_amounts", _dp), ("div_percentages", _dp),
         ("scheme", C.c_int),
         ("state_fp32", C.c_int),
+        ("option_type", C.c_int),
+        ("strike", C.c_double),
+        ("strike_i", _dp),
     ]
 
 
@@ -69,15 +72,25 @@ def _f64(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
 
 
+CALL, PUT = 0, 1
+
+
 def make_params(m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, variant=EU,
-                dividends=None, scheme=0, state_fp32=0):
+                dividends=None, scheme=0, state_fp32=0, option_type=CALL, strikes=None):
+    """strikes: scalar or per-instance array, needed for option_type=PUT only (boundary value K e^{-r_d t})."""
     p = _Params()
     p.m1, p.m2, p.N, p.variant = m1, m2, N, variant
     p.delta_t, p.theta, p.r_d, p.r_f = delta_t, theta, r_d, r_f
     p.rho, p.sigma, p.kappa, p.eta = rho, sigma, kappa, eta
     p.scheme = scheme
     p.state_fp32 = state_fp32
+    p.option_type = option_type
     keep = []
+    if strikes is not None:
+        ks = _f64(np.atleast_1d(strikes))
+        keep.append(ks)
+        p.strike = float(ks[0])
+        p.strike_i = _p(ks)
     if dividends is not None:
         dates, amounts, pcts = (_f64(x) for x in dividends)
         keep = [dates, amounts, pcts]
@@ -173,6 +186,19 @@ def lm_update(J, residuals, lam):
     delta = np.empty(5)
     lib().ho_lm_update(C.c_int(J.shape[0]), _p(J), _p(r), C.c_double(lam), _p(delta))
     return delta
+
+
+def operator(params, which, vec_s, vec_v, delta_s, delta_v, x, b=None):
+    """The reference's per-operator drivers: which = 0/1/2 -> (A_which x, (I - theta dt A_which)^{-1} b or None)."""
+    m = (params.m1 + 1) * (params.m2 + 1)
+    x = _f64(x)
+    res = np.zeros(m)
+    sol = np.zeros(m) if (b is not None and which > 0) else None
+    rc = lib().ho_operator(C.byref(params), C.c_int(which), _p(_f64(vec_s)), _p(_f64(vec_v)), _p(_f64(delta_s)),
+                           _p(_f64(delta_v)), _p(x), _p(_f64(b)), _p(res), _p(sol))
+    if rc != 0:
+        raise RuntimeError("ho_operator failed rc=%d" % rc)
+    return res, sol
 
 
 def max_threads():

@@ -14,6 +14,7 @@ EU, AM, DIV, AM_DIV = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
 SCHEME_DOUGLAS, SCHEME_CRAIG_SNEYD = 0, 1
 STATE_FP64, STATE_FP32 = 0, 1
+CALL, PUT = 0, 1
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -40,6 +41,9 @@ class Problem(C.Structure):
         ("U", _dp), ("U_0", _dp), ("lambda_bar", _dp),
         ("scheme", C.c_int),
         ("state_precision", C.c_int),
+        ("option_type", C.c_int),
+        ("strike_i", _dp),
+        ("V_0_i", _dp),
     ]
 
 
@@ -56,14 +60,16 @@ class Timing(C.Structure):
 # every symbol include/hadi.h declares (tests check the library exports all of them)
 EXPORTS = [
     "hadi_create", "hadi_destroy", "hadi_last_error", "hadi_status_string", "hadi_version",
-    "hadi_set_profiling", "hadi_get_timing", "hadi_set_tuning", "hadi_device_info", "hadi_describe_last_sweep", "hadi_stream",
+    "hadi_set_profiling", "hadi_get_timing", "hadi_set_tuning", "hadi_get_tuning", "hadi_device_info", "hadi_describe_last_sweep",
+    "hadi_stream", "hadi_wait_stream",
     "hadi_make_grid", "hadi_rebuild_variance", "hadi_find_s_index", "hadi_find_v_index",
     "hadi_DO_timestepping", "hadi_parallel_DO_solve",
     "hadi_compute_base_prices", "hadi_compute_base_prices_american",
     "hadi_compute_base_prices_dividends", "hadi_compute_base_prices_american_dividends",
     "hadi_compute_jacobian", "hadi_compute_jacobian_american",
     "hadi_compute_jacobian_dividends", "hadi_compute_jacobian_american_dividends",
-    "hadi_lm_partials", "hadi_lm_solve", "hadi_compute_parameter_update",
+    "hadi_lm_partials", "hadi_lm_partials_device", "hadi_lm_solve", "hadi_compute_parameter_update",
+    "hadi_debug_row_pass", "hadi_debug_col_solve",
 ]
 
 _lib = None
@@ -94,6 +100,11 @@ def lib():
     L.hadi_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.hadi_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
     L.hadi_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.hadi_get_tuning.argtypes = [C.c_void_p, C.c_char_p, _ip]
+    L.hadi_wait_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.hadi_lm_partials_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _dp]
+    L.hadi_debug_row_pass.argtypes = [C.c_void_p, C.POINTER(Problem), C.c_int, C.c_void_p]
+    L.hadi_debug_col_solve.argtypes = [C.c_void_p, C.POINTER(Problem), C.c_void_p]
     L.hadi_device_info.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _ip, C.c_char_p, C.c_int]
     L.hadi_describe_last_sweep.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.hadi_stream.argtypes = [C.c_void_p]

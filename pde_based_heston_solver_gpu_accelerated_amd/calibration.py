@@ -125,12 +125,26 @@ def calibrate(solver, variant, S_0, T, r_d, r_f, kappa, eta, sigma, rho, V_0, m1
     history = []
     model = None
 
+    # Device-resident shards (CUDA tensors through a real handle): the Jacobian rows and prices stay in HBM and
+    # J^T J / J^T r / sum r^2 are reduced there (hadi_lm_partials_device) -- 31 doubles per iteration leave the GPU, as
+    # after the reference's KokkosBlas gemm/gemv (jacobian_computation.cpp:117,154).  Host arrays take the host loop.
+    on_device = _solver._is_device(U_0) and hasattr(solver, "_h") and lm_partials is _solver.lm_partials
+    market_d = None
+    if on_device:
+        import torch
+        market_d = torch.from_numpy(np.ascontiguousarray(market)).to(U_0.device)
+
     for it in range(max_iter):
         J, base = jac(*cur, eps)
-        J, base = _to_numpy(J), _to_numpy(base)
         model = base
-        resid = market - base                                            # heston_calibration.cpp:271-275
-        part = comm.allreduce_sum(lm_partials(J, resid))                 # the only collective of the step
+        if on_device:
+            part_loc = _solver.lm_partials_device(solver, J, base, market_d)
+        else:
+            J, base = _to_numpy(J), _to_numpy(base)
+            model = base
+            resid = market - base                                        # heston_calibration.cpp:271-275
+            part_loc = lm_partials(J, resid)
+        part = comm.allreduce_sum(part_loc)                              # the only collective of the step
         delta = lm_solve(part, lam)
         new = clamp_parameters(*(c + d for c, d in zip(cur, delta)))
         delta_norm = float(np.sqrt(np.sum(delta * delta)))
@@ -143,10 +157,17 @@ def calibrate(solver, variant, S_0, T, r_d, r_f, kappa, eta, sigma, rho, V_0, m1
             final_error = current_error
             iteration_count = it + 1
             break
-        trial = _to_numpy(base_fn(*new))
+        trial = base_fn(*new)
         model = trial
-        r_new = market - trial
-        new_error = float(comm.allreduce_sum(np.array([np.sum(r_new * r_new)]))[0])
+        if on_device:
+            solver.wait_stream()  # (trial is complete; torch ops below run on torch's stream)
+            loc_err = float(((market_d - trial) ** 2).sum().item())      # one double leaves the GPU
+        else:
+            trial = _to_numpy(trial)
+            model = trial
+            r_new = market - trial
+            loc_err = float(np.sum(r_new * r_new))
+        new_error = float(comm.allreduce_sum(np.array([loc_err]))[0])
         history[-1]["trial_error"] = new_error
         if new_error < current_error:                                    # heston_calibration.cpp:398-408
             cur = new
@@ -159,7 +180,8 @@ def calibrate(solver, variant, S_0, T, r_d, r_f, kappa, eta, sigma, rho, V_0, m1
     return {"kappa": cur[0], "eta": cur[1], "sigma": cur[2], "rho": cur[3], "v0": cur[4],
             "final_error": final_error, "iterations": iteration_count, "converged": converged,
             "pde_solves": n_glob * 7 * iteration_count - n_glob,          # heston_calibration.cpp:428
-            "initial": (kappa, eta, sigma, rho, V_0), "model_prices": model, "history": history}
+            "initial": (kappa, eta, sigma, rho, V_0), "model_prices": None if model is None else _to_numpy(model),
+            "history": history}
 
 
 def calibrate_european(solver, S_0, T, r_d, r_f, kappa, eta, sigma, rho, V_0, m1, m2, N, theta, grids, U_0,

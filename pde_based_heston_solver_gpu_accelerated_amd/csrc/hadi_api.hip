@@ -48,6 +48,10 @@ struct Ctx {
     int use_graph = 1;
     int use_small = 1;  // LDS-resident one-launch path for small grids
     int use_amp = 1;    // American sweeps without the lambda_bar array when the payoff depends on s only
+    int device_vgrid = 1;  // compute_base_prices / compute_jacobian: v-grids rebuilt per instance on the device
+    HadiTuning tune;    // kernel-selection overrides (hadi_set_tuning)
+    hipEvent_t wait_ev = nullptr;  // hadi_wait_stream
+    DevBuf lm31;
     std::string last_path;  // which kernels the last sweep ran (hadi_describe_last_sweep)
     DevBuf div_flag, div_amt, div_pct;
     DevBuf pay_mis;  // American: per-instance payoff-shape flags (hadi_payoff_shape_kernel)
@@ -147,6 +151,8 @@ struct SweepDesc {
     int n_src = 0;                    // natural arrays hold n_src instances, instance k reads k % n_src
     int num_div = 0;
     const double *div_dates = nullptr, *div_amounts = nullptr, *div_pcts = nullptr;
+    // diagnostics (hadi_debug_*): 1 = only the row pass of step debug_step, 2 = only one column solve of the packed input
+    int debug = 0, debug_step = 1;
 };
 
 template <int B, int G, int NG, int PD>
@@ -234,9 +240,8 @@ hipError_t raise_all_lds_limits() {
 }
 
 int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
-    if (hadi_make_plan(d.m1, d.m2, d.n, 8 * c->cu_count, &pl))
-        return fail(c, HADI_ERR_UNSUPPORTED,
-                    "grid %dx%d not supported (need 2 <= m1 <= 1024, 3 <= m2 <= min(m1, %d))", d.m1, d.m2,
+    if (hadi_make_plan(d.m1, d.m2, d.n, 8 * c->cu_count, &pl, c->tune))
+        return fail(c, HADI_ERR_UNSUPPORTED, "grid %dx%d not supported (need 2 <= m1 <= 1024, 3 <= m2 <= %d)", d.m1, d.m2,
                     HADI_MAX_P * HADI_LC - 1);
     if (!(d.theta > 0.0)) pl.use_strip = 0;  // the strip kernel scales the A1 action by (1 - theta) / theta
     const HadiLayout &L = pl.L;
@@ -274,7 +279,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     std::vector<int> div_flags;
     std::vector<char> div_step(d.Nmax + 1, 0);
     const int flag_stride = d.uniform_steps ? 0 : d.Nmax;
-    const bool have_div = dividend && d.num_div > 0;
+    const bool have_div = dividend && d.num_div > 0 && !d.debug;  // (diagnostics take p->U as the state the pass starts from)
     if (have_div) {
         const int rows = d.uniform_steps ? 1 : d.n;
         div_flags.resize((size_t)rows * d.Nmax);
@@ -320,8 +325,8 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     // American in the P representation (hadi_row_step, AMER == 2): every payoff of the batch must depend on s only.
     // One small device-to-host copy per solve decides it.
     bool amp = false;
-    const bool takes_small_path = c->use_small && !c->profiling && !cs && !f32 && (american ? pl.smem_small_am : pl.smem_small_eu) > 0;
-    if (american && c->use_amp && !cs && !takes_small_path) {
+    const bool takes_small_path = c->use_small && !c->profiling && !cs && !f32 && !d.debug && (american ? pl.smem_small_am : pl.smem_small_eu) > 0;
+    if (american && c->use_amp && !cs && !takes_small_path && !d.debug) {
         std::vector<int> mis(d.n);
         HIP_TRY(c, hipMemcpyAsync(mis.data(), c->pay_mis.p, sizeof(int) * n, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
@@ -354,7 +359,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     HadiSweepArgs av = a;
     if (cs) av.U = ptr<double>(c->V);
 
-    const bool prof = c->profiling != 0;
+    const bool prof = c->profiling != 0 && !d.debug;
     if (prof) {
         const size_t need = (size_t)4 * d.Nmax;
         while (c->kev.size() < need) {
@@ -365,7 +370,8 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     }
     // The whole time loop as a function of the stream, so it can be enqueued directly or captured.
     auto enqueue_loop = [&](hipStream_t q) -> int {
-        for (int nstep = 1; nstep <= d.Nmax; nstep++) {
+        const int n_first = d.debug ? d.debug_step : 1, n_last = d.debug ? d.debug_step : d.Nmax;
+        for (int nstep = n_first; nstep <= n_last; nstep++) {
             // P representation: the first step (the caller's initial U need not dominate the payoff) and dividend steps
             // (the jump acts on U alone) run on the explicit (U, lambda_bar) pair, converted on the way in and out
             const bool xstep = amp && (nstep == 1 || (have_div && div_step[nstep]));
@@ -375,7 +381,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
             if (have_div && div_step[nstep]) {  // device_solver.hpp:426-517: U_temp <- U, U <- interpolated jump
                 HIP_TRY(c, hipMemcpyAsync(c->UT.p, c->U.p, st, hipMemcpyDeviceToDevice, q));
                 const size_t npts = (size_t)d.n * L.nrows * (L.m1 + 1);
-                hipLaunchKernelGGL(hadi_dividend_kernel, dim3(grid1d(npts)), dim3(256), 0, q, L, d.n, d.d_vec_s,
+                hipLaunchKernelGGL(hadi_dividend_kernel, dim3(grid1d(npts)), dim3(256), 0, q, L, d.n, ptr<HadiInstPar>(c->ipar), d.d_vec_s,
                                    ptr<double>(c->UT), ptr<double>(c->U), ptr<int>(c->div_flag), flag_stride, nstep,
                                    ptr<double>(c->div_amt), ptr<double>(c->div_pct));
             }
@@ -459,7 +465,13 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                     else hipLaunchKernelGGL((hadi_pass_b1<16, false>), g, b, pl.smem_b, q, ar, nstep);
                 }
             };
+            if (d.debug == 2) {  // diagnostics: one column solve of the packed input (moved to Y), nothing else
+                HIP_TRY(c, hipMemcpyAsync(f32 ? c->Yf.p : c->Y.p, f32 ? c->Uf.p : c->U.p, f32 ? st / 2 : st, hipMemcpyDeviceToDevice, q));
+                col_pass(a);
+                break;
+            }
             row_pass(a, cs ? 1 : 0);
+            if (d.debug == 1) break;  // diagnostics: Y now holds the right-hand side of the A2 solve
             if (prof) {
                 HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 1], q));
                 HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 2], q));
@@ -482,11 +494,11 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
 
     // ---- small grids: the whole instance fits in LDS -> one launch runs the entire time loop ----------
     const size_t smem_small = american ? pl.smem_small_am : pl.smem_small_eu;
-    if (c->use_small && !prof && !cs && !f32 && smem_small > 0) {
+    if (takes_small_path) {
         {
             char buf[160];
             std::snprintf(buf, sizeof buf, "hadi_small_kernel<%d,%d,%s>: whole time loop in one launch, instance resident in LDS (%zu B)", L.B,
-                          d.n <= 2 * c->cu_count ? 8 : 4, american ? "AM" : "EU", smem_small);
+                          (c->tune.small_waves ? c->tune.small_waves : (d.n <= 2 * c->cu_count ? 8 : 4)) == 8 ? 8 : 4, american ? "AM" : "EU", smem_small);
             c->last_path = buf;
         }
         HadiSmallArgs sm;
@@ -511,8 +523,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         // wavefronts per instance: 4 when the batch fills the GPU (throughput), 8 for small batches (latency of the
         // dependent per-step phases; more waves share the rows of the row pass)
         // (measured, 50x25 grid: 1 instance x 100 steps 1.27 -> 1.04 ms with 8; 3000 instances x 50 steps 4.19 -> 4.58 ms)
-        const int sw = std::getenv("HADI_TUNE_SMALLW") ? std::atoi(std::getenv("HADI_TUNE_SMALLW"))
-                                                       : (d.n <= 2 * c->cu_count ? 8 : 4);
+        const int sw = c->tune.small_waves ? c->tune.small_waves : (d.n <= 2 * c->cu_count ? 8 : 4);
         if (sw == 8) {
             if (L.B == 1) {
                 if (american) hipLaunchKernelGGL((hadi_small_kernel<1, 8, true>), dim3(d.n), dim3(512), smem_small, s, a, sm);
@@ -551,7 +562,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     // Small batches are launch-bound (2*N dependent launches of a few microseconds each): replay the loop
     // from a cached hipGraph.  Every kernel argument is baked into the nodes, so the key is everything they
     // depend on; the library's own buffers are stable between calls.
-    const bool graphable = c->use_graph && !prof && (long long)d.n * L.inst_stride <= (8ll << 20);
+    const bool graphable = c->use_graph && !prof && !d.debug && (long long)d.n * L.inst_stride <= (8ll << 20);
     if (graphable) {
         std::string key;
         auto put = [&](const void *p_, size_t nbytes) { key.append(static_cast<const char *>(p_), nbytes); };
@@ -622,7 +633,7 @@ int finish_timing(Ctx *c, const SweepDesc &d, const HadiPlan &pl) {
     const long long m = (long long)(d.m1 + 1) * (d.m2 + 1);
     for (int k = 0; k < d.n; k++) ps += m * (long long)d.par8[(size_t)k * 8 + 5];
     t.point_steps = ps;
-    if (c->profiling) {
+    if (c->profiling && !d.debug) {
         for (int k = 0; k < d.Nmax; k++) {
             HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[4 * k], c->kev[4 * k + 1])); t.pass_a_ms += ms;
             HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[4 * k + 2], c->kev[4 * k + 3])); t.pass_b_ms += ms;
@@ -663,7 +674,27 @@ int check_problem(Ctx *c, const hadi_problem *p, bool need_U, bool need_vgrid) {
     if (need_vgrid && (!p->vec_v || !p->delta_v)) return fail(c, HADI_ERR_INVALID, "vec_v / delta_v missing");
     if (need_U && !p->U) return fail(c, HADI_ERR_INVALID, "U missing");
     if (!p->N_i && p->N < 1) return fail(c, HADI_ERR_INVALID, "N must be >= 1");
-    if (!p->delta_t_i && !(p->delta_t > 0)) return fail(c, HADI_ERR_INVALID, "delta_t must be > 0");
+    if (!p->delta_t_i && !(p->delta_t > 0 && std::isfinite(p->delta_t))) return fail(c, HADI_ERR_INVALID, "delta_t must be > 0");
+    for (int k = 0; k < p->n_instances; k++) {  // per-instance overrides: every entry, not only the shared scalars
+        if (p->N_i && p->N_i[k] < 1) return fail(c, HADI_ERR_INVALID, "N_i[%d] = %d must be >= 1", k, p->N_i[k]);
+        if (p->delta_t_i && !(p->delta_t_i[k] > 0 && std::isfinite(p->delta_t_i[k])))
+            return fail(c, HADI_ERR_INVALID, "delta_t_i[%d] = %g must be > 0 and finite", k, p->delta_t_i[k]);
+    }
+    if (!(p->theta >= 0 && std::isfinite(p->theta))) return fail(c, HADI_ERR_INVALID, "theta must be >= 0");
+    if (p->option_type != HADI_CALL && p->option_type != HADI_PUT) return fail(c, HADI_ERR_INVALID, "bad option_type %d", p->option_type);
+    if (p->option_type == HADI_PUT) {
+        if (!p->strike_i) return fail(c, HADI_ERR_INVALID, "option_type = HADI_PUT needs strike_i (boundary value K e^{-r_d t})");
+        for (int k = 0; k < p->n_instances; k++)
+            if (!(p->strike_i[k] > 0 && std::isfinite(p->strike_i[k]))) return fail(c, HADI_ERR_INVALID, "strike_i[%d] must be > 0", k);
+        if (p->scheme != HADI_SCHEME_DOUGLAS) return fail(c, HADI_ERR_UNSUPPORTED, "put boundary data are available for Douglas steps only");
+    }
+    if (p->V_0_i && need_vgrid) return fail(c, HADI_ERR_INVALID, "V_0_i applies to hadi_compute_base_prices* / hadi_compute_jacobian* only");
+    {  // grid shape, before anything is staged
+        HadiPlan tmp;
+        if (p->m1 < 2 || p->m2 < 3 || hadi_make_plan(p->m1, p->m2, p->n_instances, 8 * c->cu_count, &tmp, c->tune))
+            return fail(c, HADI_ERR_UNSUPPORTED, "grid %dx%d not supported (need 2 <= m1 <= 1024, 3 <= m2 <= %d)", p->m1, p->m2,
+                        HADI_MAX_P * HADI_LC - 1);
+    }
     const bool dividend = p->variant == HADI_DIV || p->variant == HADI_AM_DIV;
     if (dividend && p->num_dividends > 0 && (!p->dividend_dates || !p->dividend_amounts || !p->dividend_percentages))
         return fail(c, HADI_ERR_INVALID, "dividend arrays missing");
@@ -696,6 +727,8 @@ void fill_par(const hadi_problem *p, SweepDesc &d, int groups) {
             r[4] = p->delta_t_i ? p->delta_t_i[k] : p->delta_t;
             const int N = p->N_i ? p->N_i[k] : p->N;
             r[5] = (double)N;
+            r[6] = (p->option_type == HADI_PUT) ? p->strike_i[k] : 0.0;
+            r[7] = (p->option_type == HADI_PUT) ? 1.0 : 0.0;
             d.Nmax = std::max(d.Nmax, N);
         }
 }
@@ -708,22 +741,55 @@ void fill_common(const hadi_problem *p, SweepDesc &d) {
     d.div_dates = p->dividend_dates; d.div_amounts = p->dividend_amounts; d.div_pcts = p->dividend_percentages;
 }
 
-// Shared driver of hadi_DO_timestepping / hadi_parallel_DO_solve / hadi_compute_base_prices*.
-int solve_common(Ctx *c, const hadi_problem *p, bool rebuild_v, bool pick, double S_0, double V_0, double *prices_out) {
+// v-grids of all `n` instances rebuilt ON THE DEVICE, each for its own V_0 (v0i: host vector of n values): what every
+// team of the reference does in-kernel (rebuild_variance_views, grid_pod.hpp:25-73; call sites use V = 5, d = 5/500,
+// jacobian_computation.cpp:253).  Results in c->g_v / c->g_dv; c->v0_i keeps the per-instance V_0 for the price pick.
+int rebuild_v_device(Ctx *c, int n, int m2, const std::vector<double> &v0i) {
+    int rc;
+    if ((rc = ensure(c, c->v0_i, (size_t)n * 8)) || (rc = ensure(c, c->g_v, (size_t)n * (m2 + 1) * 8)) ||
+        (rc = ensure(c, c->g_dv, (size_t)n * m2 * 8)))
+        return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->v0_i.p, v0i.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(hadi_rebuild_variance_kernel, dim3(n), dim3(256), (size_t)2 * (m2 + 1) * sizeof(double), c->stream, m2, n,
+                       ptr<double>(c->v0_i), 5.0, 5.0 / 500, ptr<double>(c->g_v), ptr<double>(c->g_dv));
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // v0i is the caller's (pageable) vector
+    return HADI_OK;
+}
+
+// Shared driver of hadi_DO_timestepping / hadi_parallel_DO_solve / hadi_compute_base_prices* and the diagnostics
+// (debug != 0: p->U is input only, the pass's result goes to debug_out).
+int solve_common(Ctx *c, const hadi_problem *p, bool rebuild_v, bool pick, double S_0, double V_0, double *prices_out,
+                 int debug = 0, int debug_step = 1, double *debug_out = nullptr) {
     int rc = check_problem(c, p, true, !rebuild_v);
     if (rc) return rc;
+    if (debug && !debug_out) return fail(c, HADI_ERR_INVALID, "output array missing");
+    if (debug && (p->scheme != HADI_SCHEME_DOUGLAS || p->state_precision != HADI_STATE_FP64))
+        return fail(c, HADI_ERR_UNSUPPORTED, "diagnostics cover fp64 Douglas steps");
+    if (debug == 2 && p->variant != HADI_EU && p->variant != HADI_DIV)
+        return fail(c, HADI_ERR_UNSUPPORTED, "hadi_debug_col_solve is the plain A2 solve (no projection): European variants only");
     DeviceGuard guard(c->device);
     const int n = p->n_instances, m1 = p->m1, m2 = p->m2;
-    if (m1 < 2 || m2 < 3) return fail(c, HADI_ERR_UNSUPPORTED, "grid %dx%d too small", m1, m2);
     const size_t m = (size_t)(m1 + 1) * (m2 + 1);
     SweepDesc d;
     fill_common(p, d);
     d.n = n; d.n_src = n;
+    d.debug = debug; d.debug_step = debug_step;
     fill_par(p, d, 1);
+    if (debug == 1 && (debug_step < 1 || debug_step > d.Nmax)) return fail(c, HADI_ERR_INVALID, "step %d outside 1..%d", debug_step, d.Nmax);
     if ((rc = to_device(c, p->memspace, p->vec_s, (size_t)n * (m1 + 1), c->g_s, &d.d_vec_s))) return rc;
     if ((rc = to_device(c, p->memspace, p->delta_s, (size_t)n * m1, c->g_ds, &d.d_delta_s))) return rc;
-    if (rebuild_v) {
-        // every instance gets the v-grid rebuilt for V_0 (jacobian_computation.cpp:253, V = 5, d = 5/500)
+    const bool per_inst_v0 = rebuild_v && c->device_vgrid;
+    if (rebuild_v && !c->device_vgrid && p->V_0_i)
+        return fail(c, HADI_ERR_INVALID, "V_0_i needs the device v-grid rebuild (hadi_set_tuning \"device_vgrid\", 1)");
+    if (per_inst_v0) {
+        std::vector<double> v0i(n);
+        for (int k = 0; k < n; k++) v0i[k] = p->V_0_i ? p->V_0_i[k] : V_0;
+        if ((rc = rebuild_v_device(c, n, m2, v0i))) return rc;
+        d.d_vec_v = ptr<double>(c->g_v);
+        d.d_delta_v = ptr<double>(c->g_dv);
+    } else if (rebuild_v) {
+        // host build (glibc sinh/asinh, bit-identical to the reference's host-side Grid), broadcast to every instance
         std::vector<double> hv(m2 + 1), hdv(m2);
         build_v(m2, V_0, 5.0, 5.0 / 500, hv.data(), hdv.data());
         if ((rc = ensure(c, c->src_v, (m2 + 1) * 8)) || (rc = ensure(c, c->src_dv, m2 * 8))) return rc;
@@ -747,16 +813,18 @@ int solve_common(Ctx *c, const hadi_problem *p, bool rebuild_v, bool pick, doubl
     HadiPlan pl;
     if ((rc = run_sweep(c, d, pl))) return rc;
 
-    // solution back to the caller's U (natural layout)
+    // solution back to the caller's U (natural layout); diagnostics: the pass's result to debug_out, U untouched
+    double *const host_dst = debug ? debug_out : p->U;
     double *d_out;
-    if (p->memspace == HADI_MEM_DEVICE) d_out = p->U;
+    if (p->memspace == HADI_MEM_DEVICE) d_out = host_dst;
     else {
         if ((rc = ensure(c, c->natOut, n * m * 8))) return rc;
         d_out = ptr<double>(c->natOut);
     }
-    hipLaunchKernelGGL(hadi_unpack_kernel, dim3(grid1d(n * m)), dim3(256), 0, c->stream, pl.L, n, ptr<double>(c->U), d_out);
-    if (p->memspace == HADI_MEM_HOST && (rc = from_device(c, p->memspace, p->U, d_out, n * m))) return rc;
-    const bool american = p->variant == HADI_AM || p->variant == HADI_AM_DIV;
+    hipLaunchKernelGGL(hadi_unpack_kernel, dim3(grid1d(n * m)), dim3(256), 0, c->stream, pl.L, n,
+                       debug == 1 ? ptr<double>(c->Y) : ptr<double>(c->U), d_out);
+    if (p->memspace == HADI_MEM_HOST && (rc = from_device(c, p->memspace, host_dst, d_out, n * m))) return rc;
+    const bool american = (p->variant == HADI_AM || p->variant == HADI_AM_DIV) && !debug;
     if (american && p->lambda_bar) {
         double *d_l;
         if (p->memspace == HADI_MEM_DEVICE) d_l = p->lambda_bar;
@@ -771,8 +839,8 @@ int solve_common(Ctx *c, const hadi_problem *p, bool rebuild_v, bool pick, doubl
     if (pick) {
         if ((rc = ensure(c, c->prices, n * 8)) || (rc = ensure(c, c->status, n * sizeof(int)))) return rc;
         hipLaunchKernelGGL(hadi_pick_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, pl.L, n, d.d_vec_s, d.d_vec_v,
-                           ptr<double>(c->U), S_0, (const double *)nullptr, V_0, ptr<double>(c->prices), 1,
-                           ptr<int>(c->status));
+                           ptr<double>(c->U), S_0, per_inst_v0 ? ptr<double>(c->v0_i) : (const double *)nullptr, V_0,
+                           ptr<double>(c->prices), 1, ptr<int>(c->status));
         if ((rc = from_device(c, p->memspace, prices_out, ptr<double>(c->prices), n))) return rc;
         hstatus.resize(n);
         HIP_TRY(c, hipMemcpyAsync(hstatus.data(), c->status.p, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -794,7 +862,8 @@ int jacobian_common(Ctx *c, const hadi_problem *p, double S_0, double V_0, doubl
     if (!p->U_0) return fail(c, HADI_ERR_INVALID, "U_0 (initial condition) is required for the Jacobian");
     if (!J || !base_prices) return fail(c, HADI_ERR_INVALID, "J / base_prices missing");
     const int n0 = p->n_instances, m1 = p->m1, m2 = p->m2, G = 6;
-    if (m1 < 2 || m2 < 3) return fail(c, HADI_ERR_UNSUPPORTED, "grid %dx%d too small", m1, m2);
+    if (!c->device_vgrid && p->V_0_i)
+        return fail(c, HADI_ERR_INVALID, "V_0_i needs the device v-grid rebuild (hadi_set_tuning \"device_vgrid\", 1)");
     const int n = n0 * G;
     const size_t m = (size_t)(m1 + 1) * (m2 + 1);
     SweepDesc d;
@@ -817,11 +886,9 @@ int jacobian_common(Ctx *c, const hadi_problem *p, double S_0, double V_0, doubl
         for (int k = 0; k < n0; k++) {
             sel_a[g * n0 + k] = k;
             sel_b[g * n0 + k] = (g == 5) ? 1 : 0;
-            v0i[g * n0 + k] = (g == 5) ? V_0 + eps : V_0;
+            const double v0k = p->V_0_i ? p->V_0_i[k] : V_0;
+            v0i[g * n0 + k] = (g == 5) ? v0k + eps : v0k;
         }
-    std::vector<double> hv(2 * (m2 + 1)), hdv(2 * m2);
-    build_v(m2, V_0, 5.0, 5.0 / 500, hv.data(), hdv.data());
-    build_v(m2, V_0 + eps, 5.0, 5.0 / 500, hv.data() + m2 + 1, hdv.data() + m2);
     if ((rc = ensure(c, c->sel_a, n * sizeof(int))) || (rc = ensure(c, c->sel_b, n * sizeof(int))) ||
         (rc = ensure(c, c->v0_i, n * 8)) || (rc = ensure(c, c->src_v, 2 * (m2 + 1) * 8)) ||
         (rc = ensure(c, c->src_dv, 2 * m2 * 8)) || (rc = ensure(c, c->g_s, (size_t)n * (m1 + 1) * 8)) ||
@@ -830,18 +897,27 @@ int jacobian_common(Ctx *c, const hadi_problem *p, double S_0, double V_0, doubl
         return rc;
     hipStream_t s = c->stream;
     HIP_TRY(c, hipMemcpyAsync(c->sel_a.p, sel_a.data(), n * sizeof(int), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->sel_b.p, sel_b.data(), n * sizeof(int), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->v0_i.p, v0i.data(), n * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->src_v.p, hv.data(), 2 * (m2 + 1) * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->src_dv.p, hdv.data(), 2 * m2 * 8, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(hadi_bcast_rows_kernel, dim3(grid1d((size_t)n * (m1 + 1))), dim3(256), 0, s, m1 + 1, n, src_s,
                        ptr<int>(c->sel_a), ptr<double>(c->g_s));
     hipLaunchKernelGGL(hadi_bcast_rows_kernel, dim3(grid1d((size_t)n * m1)), dim3(256), 0, s, m1, n, src_ds,
                        ptr<int>(c->sel_a), ptr<double>(c->g_ds));
-    hipLaunchKernelGGL(hadi_bcast_rows_kernel, dim3(grid1d((size_t)n * (m2 + 1))), dim3(256), 0, s, m2 + 1, n,
-                       ptr<double>(c->src_v), ptr<int>(c->sel_b), ptr<double>(c->g_v));
-    hipLaunchKernelGGL(hadi_bcast_rows_kernel, dim3(grid1d((size_t)n * m2)), dim3(256), 0, s, m2, n,
-                       ptr<double>(c->src_dv), ptr<int>(c->sel_b), ptr<double>(c->g_dv));
+    std::vector<double> hv(2 * (m2 + 1)), hdv(2 * m2);
+    if (c->device_vgrid) {
+        // every instance rebuilds its own v-grid on the device: V_0 for the groups 0..4, V_0 + eps for group 5
+        // (jacobian_computation.cpp:253,339-341)
+        if ((rc = rebuild_v_device(c, n, m2, v0i))) return rc;
+    } else {
+        build_v(m2, V_0, 5.0, 5.0 / 500, hv.data(), hdv.data());
+        build_v(m2, V_0 + eps, 5.0, 5.0 / 500, hv.data() + m2 + 1, hdv.data() + m2);
+        HIP_TRY(c, hipMemcpyAsync(c->sel_b.p, sel_b.data(), n * sizeof(int), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->v0_i.p, v0i.data(), n * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->src_v.p, hv.data(), 2 * (m2 + 1) * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->src_dv.p, hdv.data(), 2 * m2 * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(hadi_bcast_rows_kernel, dim3(grid1d((size_t)n * (m2 + 1))), dim3(256), 0, s, m2 + 1, n,
+                           ptr<double>(c->src_v), ptr<int>(c->sel_b), ptr<double>(c->g_v));
+        hipLaunchKernelGGL(hadi_bcast_rows_kernel, dim3(grid1d((size_t)n * m2)), dim3(256), 0, s, m2, n,
+                           ptr<double>(c->src_dv), ptr<int>(c->sel_b), ptr<double>(c->g_dv));
+    }
     HIP_TRY(c, hipStreamSynchronize(s));  // host vectors + natU/natOut staging are reused below
     d.d_vec_s = ptr<double>(c->g_s); d.d_delta_s = ptr<double>(c->g_ds);
     d.d_vec_v = ptr<double>(c->g_v); d.d_delta_v = ptr<double>(c->g_dv);
@@ -854,26 +930,25 @@ int jacobian_common(Ctx *c, const hadi_problem *p, double S_0, double V_0, doubl
     if ((rc = ensure(c, c->prices, n * 8)) || (rc = ensure(c, c->status, n * sizeof(int)))) return rc;
     hipLaunchKernelGGL(hadi_pick_kernel, dim3((n + 63) / 64), dim3(64), 0, s, pl.L, n, d.d_vec_s, d.d_vec_v,
                        ptr<double>(c->U), S_0, ptr<double>(c->v0_i), V_0, ptr<double>(c->prices), 1, ptr<int>(c->status));
-    std::vector<double> hp(n);
+    // J(k, param) = (pert - base) / eps on the device (jacobian_computation.cpp:329,360): with HADI_MEM_DEVICE the rows
+    // never leave HBM (hadi_lm_partials_device reduces them there); only the n status words come back
+    double *dJ = J, *db = base_prices;
+    if (p->memspace == HADI_MEM_HOST) {
+        if ((rc = ensure(c, c->natOut, (size_t)n0 * 6 * 8))) return rc;
+        dJ = ptr<double>(c->natOut);
+        db = dJ + (size_t)n0 * 5;
+    }
+    hipLaunchKernelGGL(hadi_jacobian_rows_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, n0, ptr<double>(c->prices), eps, dJ, db);
+    if (p->memspace == HADI_MEM_HOST) {
+        HIP_TRY(c, hipMemcpyAsync(J, dJ, (size_t)n0 * 5 * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(base_prices, db, (size_t)n0 * 8, hipMemcpyDeviceToHost, s));
+    }
     std::vector<int> hs(n);
-    HIP_TRY(c, hipMemcpyAsync(hp.data(), c->prices.p, n * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(hs.data(), c->status.p, n * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipGetLastError());
     if ((rc = finish_timing(c, d, pl))) return rc;
     for (int k = 0; k < n0; k++)
         if (hs[k]) return fail(c, HADI_ERR_NOT_ON_GRID, "S_0 = %.17g is not a node of instance %d's s-grid", S_0, k);
-    // J(k, param) = (pert - base) / eps, jacobian_computation.cpp:329,360
-    std::vector<double> hJ((size_t)n0 * 5), hb(n0);
-    for (int k = 0; k < n0; k++) {
-        hb[k] = hp[k];
-        for (int g = 1; g <= 5; g++) hJ[(size_t)k * 5 + (g - 1)] = (hp[(size_t)g * n0 + k] - hp[k]) / eps;
-    }
-    if (p->memspace == HADI_MEM_DEVICE) {
-        HIP_TRY(c, hipMemcpy(J, hJ.data(), hJ.size() * 8, hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(base_prices, hb.data(), hb.size() * 8, hipMemcpyHostToDevice));
-    } else {
-        std::memcpy(J, hJ.data(), hJ.size() * 8);
-        std::memcpy(base_prices, hb.data(), hb.size() * 8);
-    }
     return HADI_OK;
 }
 
@@ -883,6 +958,25 @@ int with_variant(hadi_ctx *ctx, const hadi_problem *p, int variant, hadi_problem
     *tmp = *p;
     tmp->variant = variant;
     return HADI_OK;
+}
+
+// Frees everything a (possibly half-built) handle owns.  The caller has made the handle's device current.
+void release_handle(Ctx *c) {
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->U, &c->Y, &c->LAM, &c->U0, &c->UT, &c->scoef, &c->b2row, &c->rowc, &c->a2i, &c->pb,
+                      &c->rinv, &c->rwork, &c->ipar, &c->par8, &c->g_s, &c->g_v, &c->g_ds, &c->g_dv, &c->src_v,
+                      &c->src_dv, &c->sel_a, &c->sel_b, &c->v0_i, &c->natU, &c->natU0, &c->natOut, &c->prices,
+                      &c->status, &c->div_flag, &c->div_amt, &c->div_pct, &c->V, &c->R1, &c->C2, &c->pay_mis, &c->Uf, &c->Yf,
+                      &c->order, &c->lm31};
+    for (DevBuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (auto &g : c->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+    for (auto e : c->kev) (void)hipEventDestroy(e);
+    for (auto e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->wait_ev) (void)hipEventDestroy(c->wait_ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
 }
 
 }  // namespace
@@ -923,7 +1017,7 @@ int hadi_create(hadi_ctx **out, int device_id) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count < 1) return HADI_ERR_NO_DEVICE;
     if (device_id < 0 || device_id >= count) return HADI_ERR_INVALID;
-    if (hipSetDevice(device_id) != hipSuccess) return HADI_ERR_HIP;
+    DeviceGuard guard(device_id);  // the caller's current device is left as it was found
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return HADI_ERR_HIP;
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return HADI_ERR_NO_DEVICE;  // code object is gfx950-only
@@ -932,13 +1026,14 @@ int hadi_create(hadi_ctx **out, int device_id) {
     c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->name = prop.name;
     c->arch = prop.gcnArchName;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return HADI_ERR_HIP; }
-    if (raise_all_lds_limits() != hipSuccess) { delete c; return HADI_ERR_HIP; }
-    if (const char *e = std::getenv("HADI_NO_GRAPH")) c->use_graph = std::atoi(e) ? 0 : 1;
-    if (const char *e = std::getenv("HADI_NO_SMALL")) c->use_small = std::atoi(e) ? 0 : 1;
-    if (const char *e = std::getenv("HADI_NO_AMP")) c->use_amp = std::atoi(e) ? 0 : 1;
-    for (auto &e : c->ev)
-        if (hipEventCreate(&e) != hipSuccess) { delete c; return HADI_ERR_HIP; }
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && raise_all_lds_limits() == hipSuccess;
+    for (auto &e : c->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {  // one way out: whatever was created is released
+        release_handle(c);
+        return HADI_ERR_HIP;
+    }
     *out = reinterpret_cast<hadi_ctx *>(c);
     return HADI_OK;
 }
@@ -946,20 +1041,8 @@ int hadi_create(hadi_ctx **out, int device_id) {
 int hadi_destroy(hadi_ctx *ctx) {
     Ctx *c = reinterpret_cast<Ctx *>(ctx);
     if (!c) return HADI_OK;
-    (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->U, &c->Y, &c->LAM, &c->U0, &c->UT, &c->scoef, &c->b2row, &c->rowc, &c->a2i, &c->pb,
-                      &c->rinv, &c->rwork, &c->ipar, &c->par8, &c->g_s, &c->g_v, &c->g_ds, &c->g_dv, &c->src_v,
-                      &c->src_dv, &c->sel_a, &c->sel_b, &c->v0_i, &c->natU, &c->natU0, &c->natOut, &c->prices,
-                      &c->status, &c->div_flag, &c->div_amt, &c->div_pct, &c->V, &c->R1, &c->C2, &c->pay_mis, &c->Uf, &c->Yf, &c->order};
-    for (DevBuf *b : bufs)
-        if (b->p) (void)hipFree(b->p);
-    for (auto &g : c->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
-    for (auto e : c->kev) (void)hipEventDestroy(e);
-    for (auto e : c->ev)
-        if (e) (void)hipEventDestroy(e);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
-    delete c;
+    DeviceGuard guard(c->device);
+    release_handle(c);
     return HADI_OK;
 }
 
@@ -981,7 +1064,38 @@ int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value) {
     if (!std::strcmp(key, "graph")) c->use_graph = value ? 1 : 0;
     else if (!std::strcmp(key, "small_grid")) c->use_small = value ? 1 : 0;
     else if (!std::strcmp(key, "american_p")) c->use_amp = value ? 1 : 0;
-    else return fail(c, HADI_ERR_INVALID, "unknown tuning key '%s'", key);
+    else if (!std::strcmp(key, "device_vgrid")) c->device_vgrid = value ? 1 : 0;
+    else if (!std::strcmp(key, "strip")) c->tune.strip = value < 0 ? -1 : (value ? 1 : 0);
+    else if (!std::strcmp(key, "row_tile")) c->tune.row_tile = value > 0 ? value : 0;
+    else if (!std::strcmp(key, "col_groups")) c->tune.col_groups = value > 0 ? value : 0;
+    else if (!std::strcmp(key, "small_waves")) {
+        if (value != 0 && value != 4 && value != 8) return fail(c, HADI_ERR_INVALID, "small_waves must be 0, 4 or 8");
+        c->tune.small_waves = value;
+    } else return fail(c, HADI_ERR_INVALID, "unknown tuning key '%s'", key);
+    return HADI_OK;
+}
+
+int hadi_get_tuning(const hadi_ctx *ctx, const char *key, int *value) {
+    const Ctx *c = reinterpret_cast<const Ctx *>(ctx);
+    if (!c || !key || !value) return HADI_ERR_INVALID;
+    if (!std::strcmp(key, "graph")) *value = c->use_graph;
+    else if (!std::strcmp(key, "small_grid")) *value = c->use_small;
+    else if (!std::strcmp(key, "american_p")) *value = c->use_amp;
+    else if (!std::strcmp(key, "device_vgrid")) *value = c->device_vgrid;
+    else if (!std::strcmp(key, "strip")) *value = c->tune.strip;
+    else if (!std::strcmp(key, "row_tile")) *value = c->tune.row_tile;
+    else if (!std::strcmp(key, "col_groups")) *value = c->tune.col_groups;
+    else if (!std::strcmp(key, "small_waves")) *value = c->tune.small_waves;
+    else return HADI_ERR_INVALID;
+    return HADI_OK;
+}
+
+int hadi_wait_stream(hadi_ctx *ctx, void *producer_stream) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return HADI_ERR_INVALID;
+    DeviceGuard guard(c->device);
+    HIP_TRY(c, hipEventRecord(c->wait_ev, static_cast<hipStream_t>(producer_stream)));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->wait_ev, 0));
     return HADI_OK;
 }
 
@@ -1061,6 +1175,14 @@ int hadi_compute_base_prices(hadi_ctx *ctx, const hadi_problem *p, double S_0, d
     return solve_common(c, p, true, true, S_0, V_0, base_prices);
 }
 
+int hadi_debug_row_pass(hadi_ctx *ctx, const hadi_problem *p, int step, double *Y1rhs) {
+    return solve_common(reinterpret_cast<Ctx *>(ctx), p, false, false, 0.0, 0.0, nullptr, 1, step, Y1rhs);
+}
+
+int hadi_debug_col_solve(hadi_ctx *ctx, const hadi_problem *p, double *X) {
+    return solve_common(reinterpret_cast<Ctx *>(ctx), p, false, false, 0.0, 0.0, nullptr, 2, 1, X);
+}
+
 #define HADI_VARIANT_WRAPPERS(suffix, variant)                                                                   \
     int hadi_compute_base_prices_##suffix(hadi_ctx *ctx, const hadi_problem *p, double S_0, double V_0,          \
                                           double *base_prices) {                                                 \
@@ -1102,6 +1224,22 @@ int hadi_lm_partials(int n, const double *J, const double *r, double *out) {
     double s2 = 0.0;
     for (int k = 0; k < n; k++) s2 += r[k] * r[k];
     out[30] = s2;
+    return HADI_OK;
+}
+
+int hadi_lm_partials_device(hadi_ctx *ctx, int n, const double *J, const double *model_prices, const double *market_prices,
+                            double *partial31) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return HADI_ERR_INVALID;
+    if (n < 0 || !partial31 || (n > 0 && (!J || !model_prices || !market_prices))) return fail(c, HADI_ERR_INVALID, "bad arguments");
+    DeviceGuard guard(c->device);
+    int rc = ensure(c, c->lm31, 31 * sizeof(double));
+    if (rc) return rc;
+    hipLaunchKernelGGL(hadi_lm_partials_kernel, dim3(1), dim3(256), (size_t)21 * 256 * sizeof(double), c->stream, n, J, model_prices,
+                       market_prices, ptr<double>(c->lm31));
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(partial31, c->lm31.p, 31 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return HADI_OK;
 }
 

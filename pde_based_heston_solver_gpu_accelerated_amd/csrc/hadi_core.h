@@ -18,6 +18,7 @@
 #define HADI_PBW 12  // doubles per v-row in the column-pass table
 #define HADI_MAX_P 16 // max chunks (waves) per column in the column pass
 #define HADI_LC 33   // max rows per chunk in the column pass
+#define HADI_B1_BOTH 2048  // row-table flag added to RC_B1COL: the row has a b1 entry at column 0 as well (m2 > m1 only)
 
 struct HadiLayout {
     int m1, m2, nrows;  // nrows = m2 + 1
@@ -78,10 +79,13 @@ struct HadiInstPar {
     double dt, thdt;   // delta_t, theta*delta_t
     double q;          // r_d - r_f
     double half_rd;    // 0.5*r_d
-    double r_f;
+    double bc_rate;    // boundary data carry the time factor e_n = exp(bc_rate dt n): r_f for the call
+                       // (device_solver.hpp:238,246), -r_d for the put (u = K e^{-r_d t} on the Dirichlet edges)
+    double hr0;        // reaction term of the i = 0 row of A1: 0 for the call (hes_a1_kernels.hpp:56-61 leaves the row
+                       // empty), 0.5*r_d for the put (see hadi_option_type in hadi.h)
     int N;             // time steps of this instance
     int idx_s, idx_v;  // price node (filled by the pick step), -1 if S_0 is off-grid
-    int pad;
+    int put;           // 1 = put boundary data (hadi.h, enum hadi_option_type)
 };
 
 // ---- coeff.hpp:24-126 ------------------------------------------------------------------------
@@ -145,6 +149,8 @@ struct HadiSetupIn {
     const double *vec_s, *vec_v, *delta_s, *delta_v;  // this instance's grid
     double r_d, r_f, rho, sigma, kappa, eta, theta, dt;
     int N;
+    int put;        // 0 = call boundary data (the reference), 1 = put (hadi.h, enum hadi_option_type)
+    double strike;  // put only
 };
 
 // Output tables of one instance (all device pointers, already offset to the instance).
@@ -179,13 +185,16 @@ template <class Sync>
 HADI_HD inline void hadi_setup_instance(const HadiLayout &L, const HadiSetupIn &in, const HadiTables &t,
                                         int tid, int nth, Sync sync) {
     const int m1 = L.m1, m2 = L.m2, nrows = L.nrows, npad = L.nrows_pad, nslot = 64 * L.B * L.G;
-    const double E = exp(-in.r_f * in.dt * (in.N - 1));  // hes_boundary_kernels.hpp:56
+    // call: hes_boundary_kernels.hpp:56.  put: the boundary value K e^{-r_d dt n} carries its whole time factor in e_n
+    const double E = in.put ? 1.0 : exp(-in.r_f * in.dt * (in.N - 1));
     const double thdt = in.theta * in.dt;
 
     if (tid == 0) {
         HadiInstPar ip;
-        ip.dt = in.dt; ip.thdt = thdt; ip.q = in.r_d - in.r_f; ip.half_rd = 0.5 * in.r_d; ip.r_f = in.r_f;
-        ip.N = in.N; ip.idx_s = -1; ip.idx_v = 0; ip.pad = 0;
+        ip.dt = in.dt; ip.thdt = thdt; ip.q = in.r_d - in.r_f; ip.half_rd = 0.5 * in.r_d;
+        ip.bc_rate = in.put ? -in.r_d : in.r_f;
+        ip.hr0 = in.put ? 0.5 * in.r_d : 0.0;
+        ip.N = in.N; ip.idx_s = -1; ip.idx_v = 0; ip.put = in.put;
         *t.ipar = ip;
     }
     // --- s-direction coefficients (hes_a0_kernels.hpp:37-49, hes_a1_kernels.hpp:69-91) ---------
@@ -200,7 +209,9 @@ HADI_HD inline void hadi_setup_instance(const HadiLayout &L, const HadiSetupIn &
         t.scoef[2 * nslot + pos] = 0.5 * s * s * hadi_fd_delta(in.delta_s, i - 1, -1);
         t.scoef[3 * nslot + pos] = 0.5 * s * s * hadi_fd_delta(in.delta_s, i - 1, 1);
     }
-    for (int i = tid; i <= m1; i += nth) t.b2row[hadi_pos(L, i)] = -0.5 * in.r_d * in.vec_s[i] * E;
+    // b2 on the last v-row: the value that makes the far-field solution exact there -- u = s e^{-r_f t} for the call
+    // (hes_boundary_kernels.hpp:62-66), u = K e^{-r_d t} for the put
+    for (int i = tid; i <= m1; i += nth) t.b2row[hadi_pos(L, i)] = -0.5 * in.r_d * (in.put ? in.strike : in.vec_s[i]) * E;
     // --- v-rows: A0 weights, explicit A2, boundary b1 ---------------------------------------------
     for (int r = tid; r < nrows; r += nth) {
         double *rc = t.rowc + (size_t)r * HADI_RC;
@@ -231,14 +242,20 @@ HADI_HD inline void hadi_setup_instance(const HadiLayout &L, const HadiSetupIn &
         t.a2i[3 * npad + r] = 0.0; t.a2i[4 * npad + r] = 0.0;
     }
     sync();
-    // b1_(m1*(j+1)) (quirk: not idx(m1,j)), hes_boundary_kernels.hpp:54-58.  The host rejects
-    // m2 > m1, so every v-row receives at most one entry.
-    for (int jj = tid; jj <= m2; jj += nth) {
-        const long long idx = (long long)m1 * (jj + 1);
-        const int row = (int)(idx / (m1 + 1)), col = (int)(idx % (m1 + 1));
-        double *rc = t.rowc + (size_t)row * HADI_RC;
-        rc[RC_B1VAL] = (in.r_d - in.r_f) * in.vec_s[m1] * E;
-        rc[RC_B1COL] = (double)col;
+    // b1_(m1*(j+1)), j = 0..m2 (quirk: not idx(m1,j)), hes_boundary_kernels.hpp:54-58: every entry has the same value.
+    // v-row r holds the multiples of m1 inside [r(m1+1), r(m1+1) + m1]: one for r < m1 (column m1 - r), and -- only
+    // when m2 > m1 -- two on the rows r = k m1 (columns 0 AND m1), one on the rows in between.  RC_B1COL = the column
+    // (-1: none), + HADI_B1_BOTH when column 0 carries a second entry.
+    for (int r = tid; r < nrows; r += nth) {
+        double *rc = t.rowc + (size_t)r * HADI_RC;
+        const long long lo = (long long)r * (m1 + 1), hi = lo + m1;
+        long long q = (lo + m1 - 1) / m1;  // first multiple of m1 >= lo is q*m1
+        if (q < 1) q = 1;                  // j + 1 >= 1
+        int ncol = 0, cols[2] = {-1, -1};
+        for (; q * m1 <= hi && q <= (long long)m2 + 1 && ncol < 2; q++) cols[ncol++] = (int)(q * m1 - lo);
+        if (ncol > 0) rc[RC_B1VAL] = in.put ? 0.0 : (in.r_d - in.r_f) * in.vec_s[m1] * E;  // put: du/ds = 0 at s_max
+        if (ncol == 1) rc[RC_B1COL] = (double)cols[0];
+        if (ncol == 2) rc[RC_B1COL] = (double)(cols[1] + HADI_B1_BOTH);  // cols = {0, m1}
     }
     // --- column pass: per-chunk pentadiagonal LU + SPIKE vectors ----------------------------------
     const double *l2 = t.a2i, *l1 = t.a2i + npad, *dm = t.a2i + 2 * npad, *u1 = t.a2i + 3 * npad,

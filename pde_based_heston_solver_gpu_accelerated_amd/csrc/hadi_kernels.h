@@ -377,6 +377,7 @@ struct HadiRowCtxT {
     double *R1i, *C2i;   // instance bases of the Craig-Sneyd carry-over arrays (MODE 1 writes, MODE 2 reads)
     int lane, half, wrow, posL, posR, rowp;
     double dt, thdt, qd, half_rd, e_nm1, e_n;
+    double hr0, inv0;    // i = 0 row of A1: reaction term (0 for the call) and 1 / (1 + theta dt hr0)
     // American without the lambda_bar array (AMER == 2, see hadi_row_step): LDS copy of the payoff row (it depends on s
     // only), 1/dt, and which (lane, node) of this wavefront is i = m1 (lambda_bar is forced to 0 there), -1 if none
     const double *payrow;
@@ -466,7 +467,9 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
         const double wm = rc[RC_WM], wz = rc[RC_WZ], wp = rc[RC_WP];
         const double a2l2 = rc[RC_L2], a2l1 = rc[RC_L1], a2m = rc[RC_M], a2u1 = rc[RC_U1], a2u2 = rc[RC_U2];
         const double b1val = rc[RC_B1VAL];
-        const int b1col = (int)rc[RC_B1COL];
+        const int b1raw = (int)rc[RC_B1COL];
+        const bool b1_at0 = b1raw == 0 || b1raw >= HADI_B1_BOTH;  // (two entries on one v-row: m2 > m1 only)
+        const int b1col = b1raw >= HADI_B1_BOTH ? b1raw - HADI_B1_BOTH : b1raw;
         // which (wave, lane, slot) holds the b1 node of this v-row
         const int b1e = b1col - 1;
         const int b1half = (b1col >= 1) ? b1e / (64 * B) : -1;
@@ -485,10 +488,11 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
             c0 = fmax(c0, pay0); c0m2 = fmax(c0m2, pay0); c0m1 = fmax(c0m1, pay0); c0p1 = fmax(c0p1, pay0); c0p2 = fmax(c0p2, pay0);
         }
         const double a2c0 = a2l2 * c0m2 + a2l1 * c0m1 + a2m * c0 + a2u1 * c0p1 + a2u2 * c0p2;
-        const double b1c0 = (b1col == 0) ? b1val : 0.0;
+        const double b1c0 = b1_at0 ? b1val : 0.0;
         const double b2c0 = LAST ? c.b2r[c0slot] : 0.0;
-        double y0c0 = c0 + dt * (a2c0 + (b1c0 + b2c0) * e_nm1 + lamc0);
-        y0c0 = y0c0 + thdt * (b1c0 * e_n - (0.0 + b1c0 * e_nm1));
+        const double a1c0 = -c.hr0 * c0;  // A1 row 0: empty for the call (hr0 = 0), the reaction term for the put
+        double y0c0 = c0 + dt * (a2c0 + a1c0 + (b1c0 + b2c0) * e_nm1 + lamc0);
+        y0c0 = y0c0 + thdt * (b1c0 * e_n - (a1c0 + b1c0 * e_nm1));
         double c2c0 = thdt * (b2c0 * e_n - (a2c0 + b2c0 * e_nm1));
         if constexpr (MODE == 1) {  // A0 is zero on i = 0: R1 = Y1rhs there
             if (lane == 0 && first_half) {
@@ -500,7 +504,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
             y0c0 = c.R1i[(size_t)j * rowp + c0slot];
             c2c0 = c.C2i[(size_t)j * rowp + c0slot];
         }
-        const double x0 = y0c0;  // A1 row 0 is the identity (hes_a1_kernels.hpp:56-61)
+        const double x0 = y0c0 * c.inv0;  // A1 row 0 is decoupled: the identity for the call (hes_a1_kernels.hpp:56-61)
         yout_c0 = x0 + c2c0;
 
         HADI_STAMP(0);  // row scalars + column 0
@@ -821,8 +825,9 @@ __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : 4)) hadi_pass_a
     c.wrow = wrow;
     c.rowp = rowp;
     c.dt = ip.dt; c.thdt = ip.thdt; c.qd = ip.q; c.half_rd = ip.half_rd;
-    c.e_nm1 = exp(ip.r_f * ip.dt * (n - 1));  // device_solver.hpp:238
-    c.e_n = exp(ip.r_f * ip.dt * n);          // device_solver.hpp:246
+    c.hr0 = ip.hr0; c.inv0 = 1.0 / (1.0 + ip.thdt * ip.hr0);
+    c.e_nm1 = exp(ip.bc_rate * ip.dt * (n - 1));  // device_solver.hpp:238
+    c.e_n = exp(ip.bc_rate * ip.dt * n);          // device_solver.hpp:246
     const T *__restrict__ Ub = reinterpret_cast<const T *>(a.U) + (size_t)inst * a.L.inst_stride;
     c.Yi = reinterpret_cast<T *>(a.Y) + (size_t)inst * a.L.inst_stride;
     c.Li = (AMER == 1) ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
@@ -950,6 +955,7 @@ struct HadiStripCtxT {
     int lane, rowp;
     double dt, thdt, e_nm1, e_n;
     double qth, c1, c2, kap;  // theta dt (r_d - r_f), 1 + theta dt r_d / 2, theta dt r_d / 2, (1 - theta) / theta
+    double hr0, inv0;         // i = 0 row of A1: reaction term (0 for the call) and 1 / (1 + theta dt hr0)
     double inv_dt;            // P representation: 1 / dt and the (lane, slot) of the s_max node
     int m1_lane, m1_r;
     HADI_STAMP_ACC
@@ -974,20 +980,23 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
     const double wm = rt[RC_WM], wz = rt[RC_WZ], wp = rt[RC_WP];
     const double a2l2 = rt[RC_L2], a2l1 = rt[RC_L1], a2m = rt[RC_M], a2u1 = rt[RC_U1], a2u2 = rt[RC_U2];
     const double b1val = rt[RC_B1VAL];
-    const int b1col = (int)rt[RC_B1COL];
+    const int b1raw = (int)rt[RC_B1COL];
+    const bool b1_at0 = b1raw == 0 || b1raw >= HADI_B1_BOTH;  // (two entries on one v-row: m2 > m1 only)
+    const int b1col = b1raw >= HADI_B1_BOTH ? b1raw - HADI_B1_BOTH : b1raw;
     const int b1e = b1col - 1;
     const int b1lane = (b1col >= 1) ? b1e / B : -1;
     const int b1r = b1e - (b1e / B) * B;
 
     // ---- column i = 0 (A0 and A1 rows are zero there; only A2 and the boundary act) ----------------
     const double a2c0 = a2l2 * c0m2 + a2l1 * c0m1 + a2m * c00 + a2u1 * c0p1 + a2u2 * c0p2;
-    const double b1c0 = (b1col == 0) ? b1val : 0.0;
+    const double b1c0 = b1_at0 ? b1val : 0.0;
     const double b2c0 = LAST ? c.b2r[c0slot] : 0.0;
     const double lamc0 = (AMER == 1) ? c.Li[(size_t)j * rowp + c0slot] : (AMER == 2) ? lamc0_in : 0.0;
-    double y0c0 = c00 + dt * (a2c0 + (b1c0 + b2c0) * e_nm1 + lamc0);
-    y0c0 = y0c0 + thdt * (b1c0 * e_n - (0.0 + b1c0 * e_nm1));
+    const double a1c0 = -c.hr0 * c00;  // A1 row 0: empty for the call (hr0 = 0), the reaction term for the put
+    double y0c0 = c00 + dt * (a2c0 + a1c0 + (b1c0 + b2c0) * e_nm1 + lamc0);
+    y0c0 = y0c0 + thdt * (b1c0 * e_n - (a1c0 + b1c0 * e_nm1));
     const double c2c0 = thdt * (b2c0 * e_n - (a2c0 + b2c0 * e_nm1));
-    const double x0 = y0c0;  // A1 row 0 is the identity (hes_a1_kernels.hpp:56-61)
+    const double x0 = y0c0 * c.inv0;  // A1 row 0 is decoupled: the identity for the call (hes_a1_kernels.hpp:56-61)
     const double yout_c0 = x0 + c2c0;
 
     // ---- explicit operators (same evaluation order as hadi_row_step) -------------------------------------
@@ -1203,8 +1212,9 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 4 ? 2 : 4)) ha
     c.c2 = hadi_uniform_d(ip.thdt * ip.half_rd);
     c.c1 = hadi_uniform_d(1.0 + ip.thdt * ip.half_rd);
     c.kap = hadi_uniform_d((ip.dt - ip.thdt) / ip.thdt);  // the host keeps theta = 0 off this kernel
-    c.e_nm1 = hadi_uniform_d(exp(ip.r_f * ip.dt * (n - 1)));  // device_solver.hpp:238
-    c.e_n = hadi_uniform_d(exp(ip.r_f * ip.dt * n));          // device_solver.hpp:246
+    c.hr0 = hadi_uniform_d(ip.hr0); c.inv0 = hadi_uniform_d(1.0 / (1.0 + ip.thdt * ip.hr0));
+    c.e_nm1 = hadi_uniform_d(exp(ip.bc_rate * ip.dt * (n - 1)));  // device_solver.hpp:238
+    c.e_n = hadi_uniform_d(exp(ip.bc_rate * ip.dt * n));          // device_solver.hpp:246
     const T *__restrict__ Ub = reinterpret_cast<const T *>(a.U) + (size_t)inst * a.L.inst_stride;
     c.Yi = reinterpret_cast<T *>(a.Y) + (size_t)inst * a.L.inst_stride;
     c.Li = (AMER == 1) ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
@@ -1868,6 +1878,7 @@ __global__ void __launch_bounds__(64 * W) hadi_small_kernel(HadiSweepArgs a, Had
     HadiRowCtx c;
     c.lane = lane; c.half = 0; c.wrow = wave; c.rowp = rowp;
     c.dt = ip.dt; c.thdt = ip.thdt; c.qd = ip.q; c.half_rd = ip.half_rd;
+    c.hr0 = ip.hr0; c.inv0 = 1.0 / (1.0 + ip.thdt * ip.hr0);
     c.Yi = Yl; c.Li = AMER ? LAMl : nullptr;
     c.rowc = rtab; c.j0 = 0;
     c.b2r = a.b2row + (size_t)inst * rowp;
@@ -1898,7 +1909,7 @@ __global__ void __launch_bounds__(64 * W) hadi_small_kernel(HadiSweepArgs a, Had
                 const int j = e / (m1 + 1), i = e - j * (m1 + 1);
                 const double *src = Yl + (size_t)j * rowp;
                 const double new_s = vs[i] * (1.0 - pct) - amount;
-                double out = 0.0;
+                double out = ip.put ? src[c0slot] : 0.0;  // ex-dividend spot <= 0: a call is worth 0 (device_solver.hpp:499-503), a put its s = 0 value
                 if (new_s > 0) {
                     int lo = 0, hi = m1 + 1;  // first k with s[k] > new_s (0 if none)
                     while (lo < hi) {
@@ -1920,8 +1931,8 @@ __global__ void __launch_bounds__(64 * W) hadi_small_kernel(HadiSweepArgs a, Had
             __syncthreads();
         }
         // ---- row pass: 4 rows at a time, straight out of LDS -----------------------------------------
-        c.e_nm1 = exp(ip.r_f * ip.dt * (n - 1));
-        c.e_n = exp(ip.r_f * ip.dt * n);
+        c.e_nm1 = exp(ip.bc_rate * ip.dt * (n - 1));
+        c.e_n = exp(ip.bc_rate * ip.dt * n);
         HADI_STAMP(8);
         for (int J = 0; J < nrows; J += W) {
             const int j = J + wave;
@@ -1984,7 +1995,7 @@ struct HadiSetupArgs {
     HadiLayout L;
     int n_inst;
     const double *vec_s, *vec_v, *delta_s, *delta_v;  // [n][..] natural arrays (device)
-    const double *par;  // [n][8]: rho, sigma, kappa, eta, dt, N (as double), spare, spare
+    const double *par;  // [n][8]: rho, sigma, kappa, eta, dt, N (as double), strike (put), option type (0 call, 1 put)
     double r_d, r_f, theta;
     double *scoef, *b2row, *rowc, *a2i, *pb, *rinv, *rwork;
     HadiInstPar *ipar;
@@ -2007,6 +2018,7 @@ __global__ void __launch_bounds__(256) hadi_setup_kernel(HadiSetupArgs s) {
     in.rho = par[0]; in.sigma = par[1]; in.kappa = par[2]; in.eta = par[3];
     in.dt = par[4]; in.N = (int)par[5];
     in.r_d = s.r_d; in.r_f = s.r_f; in.theta = s.theta;
+    in.strike = par[6]; in.put = (par[7] != 0.0) ? 1 : 0;
     HadiTables t;
     const int n4 = 4 * L.P;
     t.scoef = s.scoef + (size_t)inst * 4 * 64 * L.B * L.G;
@@ -2061,7 +2073,8 @@ __global__ void __launch_bounds__(256) hadi_fill_kernel(double *__restrict__ p, 
 // UT is a copy of U taken before the jump.  One thread per (row, s-node); the reference's linear
 // search "first k with s_k > new_s" is a binary search on the ascending s-grid.  Which dividend (if any) an
 // instance pays at the start of step n comes from the host-built table div_flag (see HadiSmallArgs).
-__global__ void __launch_bounds__(256) hadi_dividend_kernel(HadiLayout L, int n_inst, const double *__restrict__ vec_s,
+__global__ void __launch_bounds__(256) hadi_dividend_kernel(HadiLayout L, int n_inst, const HadiInstPar *__restrict__ ipar,
+                                                            const double *__restrict__ vec_s,
                                                             const double *__restrict__ UT, double *__restrict__ U,
                                                             const int *__restrict__ div_flag, int flag_stride, int n,
                                                             const double *__restrict__ div_amounts,
@@ -2081,7 +2094,8 @@ __global__ void __launch_bounds__(256) hadi_dividend_kernel(HadiLayout L, int n_
         const double *__restrict__ src = UT + inst * L.inst_stride + (size_t)j * L.rowp;
         const double old_s = s[i];
         const double new_s = old_s * (1.0 - pct) - amount;
-        double out = 0.0;
+        // ex-dividend spot <= 0: a call is worth 0 (device_solver.hpp:499-503), a put its s = 0 value
+        double out = ipar[inst].put ? src[hadi_pos(L, 0)] : 0.0;
         if (new_s > 0) {
             // idx = first k in [0, m1] with s[k] > new_s, 0 if none
             int lo = 0, hi = m1 + 1;
@@ -2165,6 +2179,87 @@ __global__ void __launch_bounds__(256) hadi_payoff_shape_kernel(HadiLayout L, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// GridViews::rebuild_variance_views (grid_pod.hpp:25-73) for every instance of the batch, each for its own V_0: one
+// block per instance.  v_j = d sinh(j asinh(V/d)/m2), j = 0..m2; V_0 is pushed, the m2+2 values are sorted and the
+// largest is dropped (the reference bubble-sorts them on one thread, grid_pod.hpp:47-57; the raw nodes are ascending,
+// so sorting = inserting V_0 behind the last node <= V_0).  Delta_v follows.  sinh/asinh are the device library's, as
+// in the reference's in-kernel rebuild.
+__global__ void __launch_bounds__(256) hadi_rebuild_variance_kernel(int m2, int n_inst, const double *__restrict__ v0_i,
+                                                                    double V, double d, double *__restrict__ vec_v,
+                                                                    double *__restrict__ delta_v) {
+    HADI_DYN_SMEM(double, raw);  // 2 (m2 + 1) doubles
+    const int inst = blockIdx.x;
+    if (inst >= n_inst) return;
+    const int n = m2 + 1;
+    double *outv = raw + n;
+    const double V_0 = v0_i[inst];
+    const double Delta_eta = (1.0 / m2) * asinh(V / d);
+    for (int j = threadIdx.x; j < n; j += blockDim.x) raw[j] = d * sinh(j * Delta_eta);
+    __syncthreads();
+    int lo = 0, hi = n;  // pos = number of raw nodes <= V_0 (first index with raw > V_0)
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (raw[mid] > V_0) hi = mid;
+        else lo = mid + 1;
+    }
+    const int pos = lo;  // pos == n: V_0 is the largest of the m2+2 values and is the one dropped
+    for (int k = threadIdx.x; k < n; k += blockDim.x) outv[k] = (k < pos) ? raw[k] : (k == pos) ? V_0 : raw[k - 1];
+    __syncthreads();
+    double *vv = vec_v + (size_t)inst * n, *dv = delta_v + (size_t)inst * m2;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) vv[k] = outv[k];
+    for (int k = threadIdx.x; k < m2; k += blockDim.x) dv[k] = outv[k + 1] - outv[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Levenberg-Marquardt normal equations of this rank's rows on the device (replaces KokkosBlas::gemm("T","N") /
+// gemv("T") and the residual kernel, jacobian_computation.cpp:117,154, heston_calibration.cpp:271-275):
+//   out[0..24] = J^T J (row-major), out[25..29] = J^T r, out[30] = sum r^2,  r = market - model.
+// One block, fixed-shape tree reduction: the result does not depend on scheduling (n is a few thousand at most).
+__global__ void __launch_bounds__(256) hadi_lm_partials_kernel(int n, const double *__restrict__ J,
+                                                               const double *__restrict__ model,
+                                                               const double *__restrict__ market, double *__restrict__ out) {
+    HADI_DYN_SMEM(double, redm);  // 21 x 256 doubles
+    double (*red)[256] = reinterpret_cast<double (*)[256]>(redm);
+    double acc[21];
+#pragma unroll
+    for (int q = 0; q < 21; q++) acc[q] = 0.0;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        double jr[5];
+#pragma unroll
+        for (int a = 0; a < 5; a++) jr[a] = J[(size_t)k * 5 + a];
+        const double r = market[k] - model[k];
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 5; a++)
+#pragma unroll
+            for (int b = a; b < 5; b++) { acc[q] = fma(jr[a], jr[b], acc[q]); q++; }
+#pragma unroll
+        for (int a = 0; a < 5; a++) acc[15 + a] = fma(jr[a], r, acc[15 + a]);
+        acc[20] = fma(r, r, acc[20]);
+    }
+#pragma unroll
+    for (int q = 0; q < 21; q++) red[q][threadIdx.x] = acc[q];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+#pragma unroll
+            for (int q = 0; q < 21; q++) red[q][threadIdx.x] += red[q][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int q = 0;
+        for (int a = 0; a < 5; a++)
+            for (int b = a; b < 5; b++) {
+                out[a * 5 + b] = red[q][0];
+                out[b * 5 + a] = red[q][0];
+                q++;
+            }
+        for (int a = 0; a < 5; a++) out[25 + a] = red[15 + a][0];
+        out[30] = red[20][0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Price pick (jacobian_computation.cpp:275-288): first s-node with |s_i - S_0| < 1e-10, first
 // v-node with |v_j - V_0| < 1e-10 (0 if none, grid_pod.hpp:76-87).  status[inst] = 1 if S_0 is off-grid.
 __global__ void __launch_bounds__(64) hadi_pick_kernel(HadiLayout L, int n_inst, const double *__restrict__ vec_s,
@@ -2189,6 +2284,17 @@ __global__ void __launch_bounds__(64) hadi_pick_kernel(HadiLayout L, int n_inst,
     }
     status[inst] = 0;
     prices[(size_t)inst * price_stride] = U[(size_t)inst * L.inst_stride + (size_t)iv * L.rowp + hadi_pos(L, is)];
+}
+
+// J(k, param) = (perturbed price - base price) / eps from the 6 n0 prices of a flattened Jacobian sweep (groups: base, kappa,
+// eta, sigma, rho, v0), jacobian_computation.cpp:329,360.
+__global__ void __launch_bounds__(256) hadi_jacobian_rows_kernel(int n0, const double *__restrict__ prices, double eps,
+                                                                 double *__restrict__ J, double *__restrict__ base) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n0) return;
+    const double b = prices[k];
+    base[k] = b;
+    for (int g = 1; g <= 5; g++) J[(size_t)k * 5 + (g - 1)] = (prices[(size_t)g * n0 + k] - b) / eps;
 }
 
 // Replicate one of `nsrc` source rows (length len) into every instance's row: dst[inst] = src[sel[inst]]

@@ -26,10 +26,18 @@ struct HadiPlan {
     size_t smem_small_eu, smem_small_am;
 };
 
+// Execution-path choices a caller may override through hadi_set_tuning (tests force kernel variants with them; results
+// agree to round-off).  Defaults = automatic.  There is no environment-variable back door.
+struct HadiTuning {
+    int row_tile = 0;     // shared-ring row pass: v-rows per block tile (0 = automatic)
+    int strip = -1;       // strip row pass: -1 automatic, 0 never, 1 whenever the geometry allows it
+    int col_groups = 0;   // column pass: blocks per instance (0 = automatic)
+    int small_waves = 0;  // LDS-resident small-grid kernel: wavefronts per instance, 4 or 8 (0 = automatic)
+};
+
 // Returns 0 on success, 1 if the shape is outside what the kernels cover.
-inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan *out) {
+inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan *out, const HadiTuning &tu = HadiTuning()) {
     if (m1 < 2 || m2 < 3 || n_inst < 1) return 1;
-    if (m2 > m1) return 1;           // b1 would put two entries on one v-row (hadi_core.h)
     if (m1 > 1024) return 1;         // row pass: 2 waves x 64 lanes x 8 nodes
     HadiPlan p;
     HadiLayout &L = p.L;
@@ -61,7 +69,7 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
     if (p.NG == 2 && (ntiles & 1) && ntiles > 1) ntiles++;  // pair the tiles up
     R = ((L.nrows + ntiles - 1) / ntiles + W - 1) / W * W;  // balance
     ntiles = (L.nrows + R - 1) / R;
-    if (const char *e = getenv("HADI_TUNE_R")) { R = atoi(e); if (R < W) R = W; R = (R + W - 1) / W * W; if (R > Rmax) R = Rmax; ntiles = (L.nrows + R - 1) / R; }
+    if (tu.row_tile > 0) { R = tu.row_tile; if (R < W) R = W; R = (R + W - 1) / W * W; if (R > Rmax) R = Rmax; ntiles = (L.nrows + R - 1) / R; }
     p.R = R;
     p.ntiles = ntiles;
     p.smem_a = ((size_t)p.NG * ((p.PD + 1) * W + 4) * L.rowp + (size_t)4 * 64 * L.B * L.G + (size_t)p.NG * 4 * W +
@@ -83,7 +91,7 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
         p.smem_as = ((size_t)nwv * 4 * L.rowp + (size_t)4 * 64 * L.B) * sizeof(double);
         // Chosen automatically at 8 nodes per lane only: measured on MI355X, 512x256 x256: 0.156 -> 0.141 ms/launch; at 4
         // nodes per lane (256x128 x1024) the shared-ring kernel, which fits four wavefronts per SIMD there, stays
-        // ahead (0.190 vs 0.203 ms).  HADI_TUNE_STRIP=1 forces strips for 2 and 4 nodes per lane too (tests).
+        // ahead (0.190 vs 0.203 ms).  hadi_set_tuning("strip", 1) forces strips for 2 and 4 nodes per lane too (tests).
         // One strip block occupies a CU: the launch runs in ceil(blocks / CUs) rounds.  When the last round is mostly
         // empty (e.g. 160 instances -> 320 blocks on 256 CUs) the shared-ring kernel, whose small blocks fill the tail,
         // is faster (measured: 160 instances 0.142 ms with strips, ~0.127 ms with the ring).
@@ -94,7 +102,7 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
         // 2 nodes per lane (64 < m1 <= 128), batches of several blocks per CU: 4-strip blocks beat the shared ring
         // (128x64 x2000: 0.130 -> 0.108 ms per launch); at 4 nodes per lane the two are level (0.165 vs 0.167).
         if (L.B == 2 && p.RS >= 16 && p.RS <= 64 && sblk >= 4 * (long long)cus) p.use_strip = 1;
-        if (const char *e = getenv("HADI_TUNE_STRIP")) p.use_strip = (atoi(e) && p.RS >= 1 && p.RS <= 64) ? 1 : 0;
+        if (tu.strip >= 0) p.use_strip = (tu.strip && p.RS >= 1 && p.RS <= 64) ? 1 : 0;
     }
     p.ctiles = (L.rowp + 63) / 64;
     // Each block walks over btpw column tiles (loads of the next tile overlap the solve of the current
@@ -124,7 +132,7 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
         // tile then overlap each other better than tiles pipeline inside a block (measured, 256x128 x512 American:
         // 0.094 -> 0.083 ms per launch; 200x100 x700: 0.087 -> 0.084; 128x64 x2000: 0.070 -> 0.068).
         if (L.P <= 4) groups = p.ctiles;
-        if (const char *e = getenv("HADI_TUNE_BG")) groups = atoi(e);
+        if (tu.col_groups > 0) groups = tu.col_groups;
         if (groups < 1) groups = 1;
         if (groups > p.ctiles) groups = p.ctiles;
         p.btpw = (p.ctiles + groups - 1) / groups;

@@ -42,15 +42,25 @@ def shard_range(n, world_size, rank, costs=None):
 class Communicator:
     """Thin wrapper over torch.distributed (RCCL on GPUs, gloo on CPU); world_size 1 needs no init."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, group=None):
+        """`group`: the process group the collectives run on (None = the default group).
+        `device`: where the collective's tensors live.  None = chosen from the process group's backend: RCCL
+        (`nccl`) only moves GPU memory, so the tensors go to this process's current CUDA device (one process per GPU:
+        the launcher has called torch.cuda.set_device(LOCAL_RANK)); gloo takes CPU tensors."""
         self.dist = None
         self.rank, self.world_size = 0, 1
         self.device = device
+        self.group = group
+        self.backend = None
         try:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():
                 self.dist = dist
                 self.rank, self.world_size = dist.get_rank(), dist.get_world_size()
+                self.backend = str(dist.get_backend(group))
+                if self.device is None and "nccl" in self.backend:
+                    import torch
+                    self.device = torch.device("cuda", torch.cuda.current_device())
         except ImportError:
             pass
 
@@ -63,7 +73,7 @@ class Communicator:
         t = torch.from_numpy(v.copy())
         if self.device is not None:
             t = t.to(self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t.cpu().numpy()
 
     def allgather_rows(self, local, counts):
@@ -80,11 +90,11 @@ class Communicator:
         if self.device is not None:
             t = t.to(self.device)
         outs = [torch.empty_like(t) for _ in range(self.world_size)]
-        self.dist.all_gather(outs, t)
+        self.dist.all_gather(outs, t, group=self.group)
         parts = [o.cpu().numpy()[:c] for o, c in zip(outs, counts)]
         out = np.concatenate(parts, axis=0)
         return out.reshape((-1,) + local.shape[1:]) if local.ndim > 1 else out.reshape(-1)
 
     def barrier(self):
         if self.dist is not None and self.world_size > 1:
-            self.dist.barrier()
+            self.dist.barrier(group=self.group)

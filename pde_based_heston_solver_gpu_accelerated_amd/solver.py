@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 
 from . import _native as nat
-from ._native import EU, AM, DIV, AM_DIV, HadiError  # noqa: F401  (re-exported)
+from ._native import EU, AM, DIV, AM_DIV, CALL, PUT, HadiError  # noqa: F401  (re-exported)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -106,8 +106,27 @@ class HestonADI:
         self._lib.hadi_set_profiling(self._h, 1 if enabled else 0)
 
     def set_tuning(self, key, value):
-        """Execution-path switch ('small_grid', 'graph'); never changes results."""
+        """Execution-path switch (hadi.h: 'small_grid', 'graph', 'american_p', 'strip', 'row_tile', 'col_groups',
+        'small_waves', 'device_vgrid'); results agree to round-off."""
         rc = self._lib.hadi_set_tuning(self._h, key.encode(), int(value))
+        if rc != nat.HADI_OK:
+            self._raise(rc)
+
+    def get_tuning(self, key):
+        v = C.c_int()
+        rc = self._lib.hadi_get_tuning(self._h, key.encode(), C.byref(v))
+        if rc != nat.HADI_OK:
+            raise HadiError(rc, "unknown tuning key %r" % key)
+        return v.value
+
+    def wait_stream(self, stream=None):
+        """Orders the handle's stream after everything enqueued so far on `stream` (a torch.cuda.Stream; None = torch's
+        current stream on this handle's device).  Called by every launcher that receives CUDA tensors, so a tensor
+        written by an earlier torch op (copy_, fill_ ...) is complete before the library reads it."""
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(torch.device("cuda", self.device_id))
+        rc = self._lib.hadi_wait_stream(self._h, C.c_void_p(stream.cuda_stream))
         if rc != nat.HADI_OK:
             self._raise(rc)
 
@@ -130,7 +149,7 @@ class HestonADI:
     # ---- problem assembly ---------------------------------------------------------------------
     def _problem(self, variant, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids,
                  U=None, U_0=None, lambda_bar=None, dividends=None, per_instance=None, need_vgrid=True, scheme=0,
-                 state_precision=0):
+                 state_precision=0, option_type=CALL, strikes=None):
         n = grids.Vec_s.shape[0]
         m = (m1 + 1) * (m2 + 1)
         p = nat.Problem()
@@ -163,6 +182,17 @@ class HestonADI:
         if len(set(spaces)) > 1:
             raise ValueError("array arguments mix host and device memory")
         p.memspace = nat.MEM_DEVICE if spaces and spaces[0] else nat.MEM_HOST
+        if p.memspace == nat.MEM_DEVICE:
+            self.wait_stream()  # input ordering: the library's stream does not wait for torch's by itself (hadi.h)
+        p.option_type = int(option_type)
+        if strikes is not None:
+            a = _host_f64(strikes).reshape(-1)
+            if a.size != n:
+                raise ValueError("strikes must have n_instances entries")
+            keep.append(a)
+            p.strike_i = a.ctypes.data_as(_dp)
+        elif option_type == PUT:
+            raise ValueError("option_type=PUT needs the strikes (boundary value K e^{-r_d t})")
         if dividends is not None and len(dividends):
             p.num_dividends = len(dividends)
             p.dividend_dates = dividends.dates.ctypes.data_as(_dp)
@@ -170,7 +200,7 @@ class HestonADI:
             p.dividend_percentages = dividends.percentages.ctypes.data_as(_dp)
             keep.append(dividends)
         if per_instance:
-            for key in ("rho_i", "sigma_i", "kappa_i", "eta_i", "delta_t_i"):
+            for key in ("rho_i", "sigma_i", "kappa_i", "eta_i", "delta_t_i", "V_0_i"):
                 if per_instance.get(key) is not None:
                     a = _host_f64(per_instance[key])
                     if a.size != n:
@@ -186,6 +216,14 @@ class HestonADI:
         p._keep = keep
         return p
 
+    @staticmethod
+    def _option(per_instance):
+        """The launchers keep the reference's argument lists; the put extension travels in `per_instance`
+        ({'option_type': PUT, 'strikes': [...]}) next to the other per-instance overrides."""
+        if not per_instance:
+            return CALL, None
+        return per_instance.get("option_type", CALL), per_instance.get("strikes")
+
     def _out(self, n, cols, like):
         if _is_device(like):
             import torch
@@ -198,17 +236,38 @@ class HestonADI:
     # ---- device_DO_timestepping* (src/device_solver.hpp:194-942) -------------------------------
     def DO_timestepping(self, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids, U,
                         variant=EU, U_0=None, lambda_bar=None, dividends=None, per_instance=None, scheme=0,
-                        state_precision=0):
+                        state_precision=0, option_type=CALL, strikes=None):
         """Boundary init + operator build + N Douglas steps on the caller's grids; U is updated in
         place (initial condition in, solution at T out).  scheme=1 runs Craig-Sneyd (European only);
         state_precision=1 keeps the state between the two passes in fp32 (European Douglas only, arithmetic stays fp64)."""
         p = self._problem(variant, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids,
                           U=U, U_0=U_0, lambda_bar=lambda_bar, dividends=dividends, per_instance=per_instance,
-                          scheme=scheme, state_precision=state_precision)
+                          scheme=scheme, state_precision=state_precision, option_type=option_type, strikes=strikes)
         rc = self._lib.hadi_DO_timestepping(self._h, C.byref(p))
         if rc != nat.HADI_OK:
             self._raise(rc)
         return U
+
+    # ---- diagnostics: the two directional passes of one Douglas step as operators (hadi.h) -------------------------
+    def debug_row_pass(self, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids, U, step=1, variant=EU,
+                       U_0=None, option_type=CALL, strikes=None):
+        """Right-hand side of the A2 solve after the row pass of time step `step` started from U (not modified)."""
+        p = self._problem(variant, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids, U=U, U_0=U_0,
+                          option_type=option_type, strikes=strikes)
+        out, optr = self._out(grids.Vec_s.shape[0], (m1 + 1) * (m2 + 1), U)
+        rc = self._lib.hadi_debug_row_pass(self._h, C.byref(p), int(step), optr)
+        if rc != nat.HADI_OK:
+            self._raise(rc)
+        return out
+
+    def debug_col_solve(self, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids, rhs):
+        """(I - theta dt A2)^{-1} rhs through the product's column pass (rhs not modified)."""
+        p = self._problem(EU, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids, U=rhs)
+        out, optr = self._out(grids.Vec_s.shape[0], (m1 + 1) * (m2 + 1), rhs)
+        rc = self._lib.hadi_debug_col_solve(self._h, C.byref(p), optr)
+        if rc != nat.HADI_OK:
+            self._raise(rc)
+        return out
 
     # ---- CS_scheme_shuffled (src/solver.hpp:781-907), batched on the device -----------------------
     def CS_scheme(self, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids, U, per_instance=None):
@@ -239,13 +298,14 @@ class HestonADI:
     def _base_prices(self, variant, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N,
                      theta, delta_t, num_strikes, deviceGrids, workspace, U_0=None, dividends=None,
                      per_instance=None):
+        option_type, strikes = self._option(per_instance)
         if total_size != (m1 + 1) * (m2 + 1):
             raise ValueError("total_size != (m1+1)*(m2+1)")
         if deviceGrids.Vec_s.shape[0] != num_strikes:
             raise ValueError("num_strikes does not match the grid batch")
         p = self._problem(variant, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, deviceGrids,
                           U=workspace.U, U_0=U_0, lambda_bar=None, dividends=dividends,
-                          per_instance=per_instance, need_vgrid=False)
+                          per_instance=per_instance, need_vgrid=False, option_type=option_type, strikes=strikes)
         out, optr = self._out(num_strikes, 1, workspace.U)
         rc = self._lib.hadi_compute_base_prices(self._h, C.byref(p), float(S_0), float(V_0), optr)
         if rc != nat.HADI_OK:
@@ -281,8 +341,10 @@ class HestonADI:
                   delta_t, num_strikes, deviceGrids, U_0, eps, dividends=None, per_instance=None):
         if total_size != (m1 + 1) * (m2 + 1):
             raise ValueError("total_size != (m1+1)*(m2+1)")
+        option_type, strikes = self._option(per_instance)
         p = self._problem(variant, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, deviceGrids,
-                          U=None, U_0=U_0, dividends=dividends, per_instance=per_instance, need_vgrid=False)
+                          U=None, U_0=U_0, dividends=dividends, per_instance=per_instance, need_vgrid=False,
+                          option_type=option_type, strikes=strikes)
         J, jptr = self._out(num_strikes, 5, U_0)
         base, bptr = self._out(num_strikes, 1, U_0)
         rc = self._lib.hadi_compute_jacobian(self._h, C.byref(p), float(S_0), float(V_0), float(eps), jptr, bptr)
@@ -364,6 +426,23 @@ def lm_partials(J, residuals):
     rc = nat.lib().hadi_lm_partials(J.shape[0], J.ctypes.data_as(_dp), r.ctypes.data_as(_dp), out.ctypes.data_as(_dp))
     if rc != nat.HADI_OK:
         raise HadiError(rc, "hadi_lm_partials")
+    return out
+
+
+def lm_partials_device(solver, J, model_prices, market_prices):
+    """The same 31 doubles reduced on the GPU from device-resident J [n][5], model prices [n] and market prices [n]
+    (CUDA tensors): only 31 doubles leave the device per LM iteration (hadi_lm_partials_device)."""
+    n = int(J.shape[0])
+    for t, name, cnt in ((J, "J", 5 * n), (model_prices, "model_prices", n), (market_prices, "market_prices", n)):
+        _check_array(t, name, cnt)
+        if not _is_device(t):
+            raise ValueError("%s must be a CUDA tensor" % name)
+    solver.wait_stream()
+    out = np.empty(31)
+    rc = solver._lib.hadi_lm_partials_device(solver._h, n, C.c_void_p(J.data_ptr()), C.c_void_p(model_prices.data_ptr()),
+                                             C.c_void_p(market_prices.data_ptr()), out.ctypes.data_as(_dp))
+    if rc != nat.HADI_OK:
+        solver._raise(rc)
     return out
 
 

@@ -24,10 +24,17 @@ def oracle_grids(m1, m2, strikes, V0=V_0):
     return vs, vv, ds, dv, U0
 
 
-def oracle_params(m1, m2, N, variant, r_f=R_F, rho=RHO, sigma=SIGMA, kappa=KAPPA, eta=ETA, T_=T):
+def oracle_params(m1, m2, N, variant, r_f=R_F, rho=RHO, sigma=SIGMA, kappa=KAPPA, eta=ETA, T_=T, option_type=O.CALL,
+                  strikes=None):
     v = VARIANT[variant] if isinstance(variant, str) else variant
     return O.make_params(m1, m2, N, T_ / N, THETA, R_D, r_f, rho, sigma, kappa, eta, v,
-                         DIVS if v in (O.DIV, O.AM_DIV) else None)
+                         DIVS if v in (O.DIV, O.AM_DIV) else None, option_type=option_type, strikes=strikes)
+
+
+def put_payoff(vec_s, strikes, m2):
+    """U_0 = max(K - s, 0) on every v-row; [n][m]."""
+    k = np.asarray(strikes, dtype=np.float64).reshape(-1, 1)
+    return np.ascontiguousarray(np.tile(np.maximum(k - vec_s, 0.0), (1, m2 + 1)))
 
 
 def strikes_for(n):

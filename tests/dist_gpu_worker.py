@@ -31,7 +31,12 @@ def main():
     U0 = grids.call_payoff(ks)
     market = np.array([H.market.call_price(Cm.S_0, p.strike, Cm.R_D, 0.2, p.maturity) for p in mine])
     solver = H.HestonADI(0)
-    comm = H.Communicator()
+    if "--device-arrays" in sys.argv:
+        # HBM-resident shard: Jacobian rows and prices stay on the GPU, hadi_lm_partials_device reduces them there and only
+        # the 31 doubles of the all-reduce leave it
+        dev = torch.device("cuda", 0)
+        grids, U0 = grids.to(dev), torch.from_numpy(U0).to(dev)
+    comm = H.Communicator(group=dist.new_group(backend="gloo") if "--subgroup" in sys.argv else None)
     res = H.calibrate_european_multi_maturity(solver, Cm.S_0, Cm.R_D, Cm.R_F, Cm.KAPPA, Cm.ETA, Cm.SIGMA, Cm.RHO, Cm.V_0, m1, m2,
                                               Cm.THETA, mine, grids, U0, market, comm=comm, n_total=len(pts), max_iter=6)
     counts = [H.shard_range(len(pts), world, r, costs)[1] - H.shard_range(len(pts), world, r, costs)[0] for r in range(world)]

@@ -5,12 +5,27 @@
 #include "hadi_kernels.h"
 #include "hadi_plan.h"
 
+#include <string>
+#include <vector>
+
 namespace emu {
 thread_local emu_dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 thread_local BlockState *t_block;
 thread_local WaveState *t_wave;
 thread_local int t_lane;
 }  // namespace emu
+
+// kernel-selection overrides, the emulator's stand-in for hadi_set_tuning
+static HadiTuning g_tune;
+extern "C" int emu_set_tuning(const char *key, int value) {
+    const std::string k(key);
+    if (k == "strip") g_tune.strip = value < 0 ? -1 : (value ? 1 : 0);
+    else if (k == "row_tile") g_tune.row_tile = value > 0 ? value : 0;
+    else if (k == "col_groups") g_tune.col_groups = value > 0 ? value : 0;
+    else if (k == "reset") g_tune = HadiTuning();
+    else return 1;
+    return 0;
+}
 
 template <int B, int G, int NG, int PD>
 static void run_pass_a(const HadiPlan &pl, const HadiSweepArgs &a, int n, int mode) {
@@ -108,7 +123,7 @@ static void run_col_pass(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
 
 extern "C" int emu_plan(int m1, int m2, int n_inst, int target_waves, int *out /*B,rowp,P,R,ntiles,ctiles*/) {
     HadiPlan pl;
-    if (hadi_make_plan(m1, m2, n_inst, target_waves, &pl)) return 1;
+    if (hadi_make_plan(m1, m2, n_inst, target_waves, &pl, g_tune)) return 1;
     out[0] = pl.L.B; out[1] = pl.L.rowp; out[2] = pl.L.P; out[3] = pl.R; out[4] = pl.ntiles; out[5] = pl.L.G;
     return 0;
 }
@@ -116,7 +131,7 @@ extern "C" int emu_plan(int m1, int m2, int n_inst, int target_waves, int *out /
 // every launch-geometry field of the plan, for the host-logic invariants test
 extern "C" int emu_plan_full(int m1, int m2, int n_inst, int target_waves, long long *o /*[24]*/) {
     HadiPlan pl;
-    if (hadi_make_plan(m1, m2, n_inst, target_waves, &pl)) return 1;
+    if (hadi_make_plan(m1, m2, n_inst, target_waves, &pl, g_tune)) return 1;
     const HadiLayout &L = pl.L;
     o[0] = L.B; o[1] = L.G; o[2] = L.rowp; o[3] = L.P; o[4] = L.nrows; o[5] = L.nrows_pad; o[6] = L.inst_stride;
     o[7] = pl.W; o[8] = pl.NG; o[9] = pl.PD; o[10] = pl.R; o[11] = pl.ntiles; o[12] = pl.grid_a; o[13] = (long long)pl.smem_a;
@@ -130,9 +145,10 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
                          const double *par /*[n][4] rho sigma kappa eta*/, int variant, const double *vec_s,
                          const double *vec_v, const double *delta_s, const double *delta_v, double *U,
                          const double *U0, double *lam_out, int target_waves, int ndiv, const double *ddates,
-                         const double *damounts, const double *dpcts, int setup_threads, int use_small, int scheme) {
+                         const double *damounts, const double *dpcts, int setup_threads, int use_small, int scheme,
+                         const double *put_strikes /* NULL = call boundary data */) {
     HadiPlan pl;
-    if (hadi_make_plan(m1, m2, n_inst, target_waves, &pl)) return 1;
+    if (hadi_make_plan(m1, m2, n_inst, target_waves, &pl, g_tune)) return 1;
     const HadiLayout &L = pl.L;
     const int american = variant & 1, dividend = (variant >> 1) & 1;
     const size_t st = (size_t)L.inst_stride * n_inst;
@@ -149,6 +165,8 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
         for (int z = 0; z < 4; z++) par8[(size_t)k * 8 + z] = par[(size_t)k * 4 + z];
         par8[(size_t)k * 8 + 4] = dt;
         par8[(size_t)k * 8 + 5] = (double)N;
+        par8[(size_t)k * 8 + 6] = put_strikes ? put_strikes[k] : 0.0;
+        par8[(size_t)k * 8 + 7] = put_strikes ? 1.0 : 0.0;
     }
     HadiSetupArgs s;
     s.L = L; s.n_inst = n_inst;
@@ -224,7 +242,7 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
         if (dividend && flags[n - 1] >= 0) {  // device_solver.hpp:426-517 (host builds the step table, kernel applies)
             dUT = dU;
             emu::launch(8, 64, [&]() {
-                hadi_dividend_kernel(L, n_inst, vec_s, dUT.data(), dU.data(), flags.data(), 0, n, damounts, dpcts);
+                hadi_dividend_kernel(L, n_inst, ipar.data(), vec_s, dUT.data(), dU.data(), flags.data(), 0, n, damounts, dpcts);
             });
         }
         if (run_row_pass(pl, a, n, cs ? 1 : 0)) return 2;
@@ -249,7 +267,7 @@ extern "C" int emu_tables(int m1, int m2, int N, double dt, double theta, double
                           const double *delta_s, const double *delta_v, int target_waves, double *scoef,
                           double *b2row, double *rowc, double *a2i, double *pb, double *rinv) {
     HadiPlan pl;
-    if (hadi_make_plan(m1, m2, 1, target_waves, &pl)) return 1;
+    if (hadi_make_plan(m1, m2, 1, target_waves, &pl, g_tune)) return 1;
     HadiSetupIn in;
     in.vec_s = vec_s; in.vec_v = vec_v; in.delta_s = delta_s; in.delta_v = delta_v;
     in.r_d = r_d; in.r_f = r_f; in.rho = rho; in.sigma = sigma; in.kappa = kappa; in.eta = eta;

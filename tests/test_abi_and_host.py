@@ -25,7 +25,14 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
     assert declared == set(nat.EXPORTS), declared ^ set(nat.EXPORTS)
-    assert lib.hadi_version() == 1
+    assert lib.hadi_version() == 2
+
+
+def test_library_reads_no_environment_variables():
+    """Kernel selection is hadi_set_tuning's business: the product sources contain no getenv (round-1 review item)."""
+    csrc = os.path.join(ROOT, "pde_based_heston_solver_gpu_accelerated_amd", "csrc")
+    for f in os.listdir(csrc):
+        assert "getenv" not in open(os.path.join(csrc, f)).read(), f
 
 
 def test_problem_struct_matches_header_field_order():

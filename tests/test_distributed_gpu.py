@@ -11,9 +11,9 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(nproc, port):
+def _run(nproc, port, *flags):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(HERE, "dist_gpu_worker.py")]
+           "127.0.0.1", "--master-port", str(port), os.path.join(HERE, "dist_gpu_worker.py")] + list(flags)
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     lines = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")]
     assert out.returncode == 0 and lines, out.stdout[-2000:] + out.stderr[-3000:]
@@ -30,3 +30,32 @@ def test_two_rank_calibration_equals_single_rank():
         assert abs(one[k] - two[k]) <= 1e-3 * max(1e-2, abs(one[k]))
     assert abs(one["kappa"] - two["kappa"]) <= 1e-2 * abs(one["kappa"])
     assert max(abs(x - y) for x, y in zip(one["prices"], two["prices"])) <= 1e-4
+
+
+def test_two_rank_calibration_with_device_resident_shards():
+    """The same two-rank run with HBM-resident shards: J and the prices never leave the GPU, J^T J / J^T r / sum r^2 are
+    reduced by hadi_lm_partials_device and only the 31 doubles cross to the all-reduce (here over a gloo subgroup --
+    the code path bench.py drives over an RCCL group on a real node).  Same trajectory as the host-array run."""
+    host, devr = _run(2, 29633), _run(2, 29634, "--device-arrays", "--subgroup")
+    assert host["iterations"] == devr["iterations"] and host["pde_solves"] == devr["pde_solves"]
+    for a, b in zip(host["errors"], devr["errors"]):
+        assert abs(a - b) <= 1e-6 * max(1.0, a)
+    for k in ("eta", "sigma", "rho", "v0"):
+        assert abs(host[k] - devr[k]) <= 1e-3 * max(1e-2, abs(host[k]))
+    assert max(abs(x - y) for x, y in zip(host["prices"], devr["prices"])) <= 1e-4
+
+
+def test_bench_refuses_gloo_for_a_multi_gpu_number():
+    """bench.py --gpus 2 on a one-GPU box: RCCL cannot bring up two ranks on one device -> every rank exits non-zero
+    instead of silently timing over gloo; with --allow-gloo (rehearsal) the line says which collective it used."""
+    bench = os.path.join(os.path.dirname(HERE), "bench.py")
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
+    tail = [bench, "--gpus", "2", "--steps", "1", "--warmup", "0", "--share-device", "--workload", "c4", "--no-cpu-baseline"]
+    out = subprocess.run(base + ["--master-port", "29635"] + tail, capture_output=True, text=True, timeout=900)
+    assert out.returncode != 0 and "refusing to report a multi-GPU number over gloo" in out.stderr
+    out = subprocess.run(base + ["--master-port", "29636"] + tail + ["--allow-gloo"], capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and lines, out.stdout[-2000:] + out.stderr[-3000:]
+    rec = json.loads(lines[-1])
+    assert rec["n_gpus"] == 2 and rec["config"]["timing_collective"].startswith("gloo") and rec["value"] > 0
+    assert rec["scaling"] == "strong" and rec["config"]["instances_total"] == 500

@@ -35,12 +35,15 @@ def emu():
     return C.CDLL(EMU_SO)
 
 
-def _run(emu, m1, m2, N, strikes, variant, target_waves, r_f=0.0, small=0, scheme=0):
+def _run(emu, m1, m2, N, strikes, variant, target_waves, r_f=0.0, small=0, scheme=0, put=False):
     """scheme: 0 Douglas, 1 Craig-Sneyd, 2 Douglas with the state kept in fp32 between the passes, 3 Douglas with the
     American P representation (no lambda_bar array; explicit pair on step 1 and on dividend steps)."""
     n = len(strikes)
     vs, vv, ds, dv, U0 = Cm.oracle_grids(m1, m2, strikes)
-    p = Cm.oracle_params(m1, m2, N, variant, r_f=r_f)
+    ks = np.array(strikes, dtype=np.float64)
+    if put:
+        U0 = np.ascontiguousarray(np.tile(np.maximum(ks[:, None] - vs, 0.0), (1, m2 + 1)))
+    p = Cm.oracle_params(m1, m2, N, variant, r_f=r_f, option_type=O.PUT if put else O.CALL, strikes=ks if put else None)
     p.scheme = 1 if scheme == 1 else 0
     p.state_fp32 = 1 if scheme == 2 else 0
     Uo, lamo, _ = O.solve_batch(p, vs, vv, ds, dv, U0, U0, want_lambda=True)
@@ -49,7 +52,7 @@ def _run(emu, m1, m2, N, strikes, variant, target_waves, r_f=0.0, small=0, schem
     dd = [np.array(x, dtype=np.float64) for x in Cm.DIVS]
     rc = emu.emu_solve(n, m1, m2, N, C.c_double(Cm.T / N), C.c_double(Cm.THETA), C.c_double(Cm.R_D),
                        C.c_double(r_f), _P(par), variant, _P(vs), _P(vv), _P(ds), _P(dv), _P(U), _P(U0), _P(lam),
-                       target_waves, len(dd[0]), _P(dd[0]), _P(dd[1]), _P(dd[2]), 64, small, scheme)
+                       target_waves, len(dd[0]), _P(dd[0]), _P(dd[1]), _P(dd[2]), 64, small, scheme, _P(ks) if put else None)
     assert rc == 0
     scale = np.abs(Uo).max()
     # fp32 state: an fp64 last-bit difference before a store can flip the float rounding (6e-8 relative), per step
@@ -82,17 +85,39 @@ def test_single_buffer_column_pass_for_more_than_8_chunks(emu):
     _run(emu, 280, 265, 2, [97.0], O.AM, 1, r_f=0.01)
 
 
-def test_strip_row_pass(emu, monkeypatch):
+def test_strip_row_pass(emu):
     # 8 nodes per lane: every wavefront walks a strip of v-rows alone (register window + private LDS ring, no barrier).
     # 151 rows -> 8 strips of 19; r_f != 0 exercises the boundary terms, the last strip carries the b2 row
     _run(emu, 300, 150, 2, [100.0], O.EU, 1, r_f=0.01)
     # forced short strips (6 rows: prologue / halo / ring wrap-around on every strip), American adds lambda_bar
-    monkeypatch.setenv("HADI_TUNE_STRIP", "1")
-    _run(emu, 280, 40, 3, [95.0], O.AM, 1)
-    _run(emu, 512, 20, 2, [104.0], O.EU, 1)
-    # 4 and 2 nodes per lane
-    _run(emu, 200, 60, 3, [100.0], O.AM_DIV, 1, r_f=0.01)
-    _run(emu, 100, 70, 2, [100.0, 92.0], O.EU, 1)
+    emu.emu_set_tuning(b"strip", 1)
+    try:
+        _run(emu, 280, 40, 3, [95.0], O.AM, 1)
+        _run(emu, 512, 20, 2, [104.0], O.EU, 1)
+        # 4 and 2 nodes per lane
+        _run(emu, 200, 60, 3, [100.0], O.AM_DIV, 1, r_f=0.01)
+        _run(emu, 100, 70, 2, [100.0, 92.0], O.EU, 1)
+        # put boundary data on strips (i = 0 column with its reaction term, b1 == 0, time factor e^{-r_d t})
+        _run(emu, 300, 40, 3, [100.0], O.AM, 1, put=True)
+    finally:
+        emu.emu_set_tuning(b"reset", 0)
+
+
+def test_put_boundary_data(emu):
+    # not a reference feature (hadi.h, enum hadi_option_type): shared-ring kernel at 1 and 4 nodes per lane, the LDS-resident
+    # small-grid kernel, dividends (ex-dividend spot <= 0 takes the s = 0 value), American projection, two waves per row
+    _run(emu, 40, 12, 3, [90.0, 110.0], O.EU, 8, put=True)
+    _run(emu, 40, 12, 4, [100.0], O.AM_DIV, 8, small=1, put=True)
+    _run(emu, 200, 60, 12, [100.0], O.AM_DIV, 8, put=True)
+    _run(emu, 600, 12, 2, [100.0], O.EU, 8, put=True)
+    _run(emu, 200, 60, 12, [100.0], O.AM_DIV, 8, scheme=3, put=True)  # P representation
+
+
+def test_more_v_nodes_than_s_nodes(emu):
+    # m2 > m1: the b1 quirk index m1*(j+1) then puts TWO entries on the v-rows k*m1 (columns 0 and m1)
+    _run(emu, 20, 50, 3, [100.0], O.EU, 8, r_f=0.01)
+    _run(emu, 40, 70, 2, [100.0, 95.0], O.AM, 8, r_f=0.01)
+    _run(emu, 70, 100, 2, [100.0], O.EU, 1, r_f=0.01)   # 2 nodes per lane; chunked column pass
 
 
 def test_fp32_state_sweep(emu):
@@ -162,7 +187,7 @@ def test_plan_invariants_over_shapes_and_batch_sizes(emu):
                 assert R % W == 0 and R * ntiles >= nrows and grid_a * NG >= n * ntiles
                 assert smem_a + rowp * 8 <= LDS
                 nwv = 8 if B == 8 else 4
-                if B >= 2 and G == 1:  # strips can be forced for any of these (HADI_TUNE_STRIP), so check them all
+                if B >= 2 and G == 1:  # strips can be forced for any of these (hadi_set_tuning "strip"), so check them all
                     assert RS * nwv * sblocks >= nrows and grid_as >= n * sblocks
                     assert smem_as + rowp * 8 <= LDS
                 else:
@@ -173,7 +198,8 @@ def test_plan_invariants_over_shapes_and_batch_sizes(emu):
                 assert btpw * bgroups >= ctiles and (btpw - 1) * bgroups < ctiles + bgroups and ctiles * 64 >= rowp
                 assert grid_b == n * bgroups and smem_b <= LDS and P <= 16
     assert seen_strip == {2, 8}
-    assert emu.emu_plan_full(100, 101, 1, 8, o) != 0 and emu.emu_plan_full(1025, 100, 1, 8, o) != 0  # m2 > m1, m1 too wide
+    assert emu.emu_plan_full(100, 101, 1, 8, o) == 0  # m2 > m1 is covered (two b1 entries on the v-rows k*m1)
+    assert emu.emu_plan_full(1025, 100, 1, 8, o) != 0  # m1 too wide
     assert emu.emu_plan_full(600, 528, 1, 8, o) != 0  # more than 16 chunks
 
 

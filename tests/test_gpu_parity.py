@@ -27,6 +27,15 @@ FIELD_RTOL = 1e-10
 PRICE_ATOL = 1e-9
 
 
+@pytest.fixture
+def forced_strips(solver):
+    """The strip row pass forced through hadi_set_tuning for the duration of one test (the plan picks it by itself for
+    large batches only)."""
+    solver.set_tuning("strip", 1)
+    yield solver
+    solver.set_tuning("strip", -1)
+
+
 def _batch(m1, m2, strikes):
     grids = H.GridViewsBatch.for_strikes(m1, m2, Cm.S_0, Cm.V_0, strikes)
     return grids, grids.call_payoff(strikes)
@@ -417,10 +426,20 @@ def test_error_conventions(solver):
         solver.parallel_DO_solve(1, 101.2345, Cm.V_0, m1, m2, N, Cm.T, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO,
                                  Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, ws)
     assert e.value.status == 4
-    g2, U2 = _batch(20, 30, [100.0])  # m2 > m1
+    g2, U2 = _batch(600, 528, [100.0])  # more than 16 chunks of 33 v-rows
     with pytest.raises(H.HadiError) as e:
-        solver.DO_timestepping(20, 30, N, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, g2, U2)
+        solver.DO_timestepping(600, 528, N, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, g2, U2)
     assert e.value.status == 2
+    for bad in ({"N_i": [0], "delta_t_i": [0.1]}, {"N_i": [3], "delta_t_i": [-0.1]}, {"N_i": [3], "delta_t_i": [float("nan")]}):
+        with pytest.raises(H.HadiError) as e:  # per-instance overrides are validated entry by entry
+            solver.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids,
+                                   U0.copy(), per_instance=bad)
+        assert e.value.status == 1
+    with pytest.raises(ValueError):  # puts need their strikes
+        solver.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids,
+                               U0.copy(), option_type=H.PUT)
+    with pytest.raises(H.HadiError):
+        solver.set_tuning("no_such_key", 1)
     with pytest.raises(H.HadiError) as e:
         solver.DO_timestepping(m1, m2, 0, Cm.T, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U0.copy())
     assert e.value.status == 1
@@ -545,10 +564,9 @@ def test_multi_maturity_calibration_drivers_vs_oracle_driven_loop(solver):
 @pytest.mark.parametrize("variant,name", [(H.EU, "EU"), (H.AM, "AM"), (H.AM_DIV, "AM_DIV")])
 @pytest.mark.parametrize("m1,m2,N,n", [(512, 256, 8, 2), (300, 140, 5, 1), (260, 200, 4, 3), (400, 33, 6, 2),
                                       (256, 128, 6, 2), (200, 100, 5, 2), (100, 50, 4, 3)])
-def test_strip_row_pass_vs_oracle(solver, monkeypatch, variant, name, m1, m2, N, n):
+def test_strip_row_pass_vs_oracle(solver, forced_strips, variant, name, m1, m2, N, n):
     """The barrier-free strip row pass (2, 4 or 8 nodes per lane) is only chosen for large batches; force it on small ones so
     that every strip geometry (short strips, ragged last strip, one block or several per instance) meets the oracle."""
-    monkeypatch.setenv("HADI_TUNE_STRIP", "1")
     strikes = Cm.strikes_for(n)
     solver.set_tuning("american_p", 0)  # the P representation runs on the shared-ring kernel; here: the strips' explicit path
     try:
@@ -565,11 +583,10 @@ def test_strip_row_pass_vs_oracle(solver, monkeypatch, variant, name, m1, m2, N,
 
 @pytest.mark.parametrize("variant,name", [(H.AM, "AM"), (H.AM_DIV, "AM_DIV")])
 @pytest.mark.parametrize("m1,m2,N,n", [(512, 256, 12, 2), (300, 140, 25, 2), (256, 128, 25, 3), (128, 64, 10, 2)])
-def test_strip_row_pass_with_the_p_representation(solver, monkeypatch, variant, name, m1, m2, N, n):
+def test_strip_row_pass_with_the_p_representation(solver, forced_strips, variant, name, m1, m2, N, n):
     """American sweeps in the P representation on the barrier-free strips (chosen by itself for large batches at 8 and 2
     nodes per lane; forced here): U = max(P, U_0) rebuilt on the register window and the ring rows, lambda_bar from the
     raw P of row j, payoff row in LDS.  N = 25 puts dividend steps (explicit pair, materialise / dematerialise) in between."""
-    monkeypatch.setenv("HADI_TUNE_STRIP", "1")
     strikes = Cm.strikes_for(n)
     grids, U0, U, lam = _hadi_solve(solver, m1, m2, N, strikes, variant, r_f=0.01, want_lambda=True)
     d = solver.describe_last_sweep()
@@ -581,11 +598,10 @@ def test_strip_row_pass_with_the_p_representation(solver, monkeypatch, variant, 
 
 
 @pytest.mark.parametrize("theta", [0.0, 0.5, 1.0])
-def test_strip_row_pass_theta_range(solver, monkeypatch, theta):
+def test_strip_row_pass_theta_range(solver, forced_strips, theta):
     """The strip kernel forms I - theta dt A1 directly and rebuilds the explicit A1 action from it with the factor
     (1 - theta) / theta: theta = 1 (factor 0) and theta = 0.5 must meet the oracle, and theta = 0 -- where that factor does
     not exist -- must be kept off the strip kernel by the host even when strips are forced."""
-    monkeypatch.setenv("HADI_TUNE_STRIP", "1")
     m1, m2, N, n = 300, 140, 6, 2
     strikes = Cm.strikes_for(n)
     grids, U0 = _batch(m1, m2, strikes)
@@ -610,10 +626,9 @@ def test_strips_chosen_by_themselves_at_two_nodes_per_lane(solver):
     _assert_field(U, Uo)
 
 
-def test_forced_strips_leave_the_fp32_state_of_narrow_grids_on_the_ring_kernel(solver, monkeypatch):
+def test_forced_strips_leave_the_fp32_state_of_narrow_grids_on_the_ring_kernel(solver, forced_strips):
     """The float strip kernel exists at 8 nodes per lane only: with strips forced (or auto-selected at 2 nodes per lane) a
     narrower grid with the fp32 state must take the shared-ring float kernel, not a mismatched strip launch."""
-    monkeypatch.setenv("HADI_TUNE_STRIP", "1")
     m1, m2, N, n = 128, 64, 6, 3
     strikes = Cm.strikes_for(n)
     grids, U0 = _batch(m1, m2, strikes)
@@ -629,7 +644,7 @@ def test_forced_strips_leave_the_fp32_state_of_narrow_grids_on_the_ring_kernel(s
 
 @pytest.mark.parametrize("m1,m2,N,n", [(50, 25, 20, 3), (128, 64, 10, 2), (256, 128, 12, 3), (512, 256, 8, 2),
                                       (1024, 512, 4, 1), (700, 300, 4, 2)])
-def test_fp32_state_sweep_vs_oracle(solver, monkeypatch, m1, m2, N, n):
+def test_fp32_state_sweep_vs_oracle(solver, m1, m2, N, n):
     """BASELINE config 5 ("mixed-precision fp32 ADI sweep with fp64 tridiag pivots"): U and the A2 right-hand side are
     stored as fp32 between the passes, all arithmetic is fp64.  Not a reference feature -- the checker is the oracle
     with the same two roundings per step; an fp64 last-bit difference before a store can flip a float rounding
@@ -638,9 +653,12 @@ def test_fp32_state_sweep_vs_oracle(solver, monkeypatch, m1, m2, N, n):
     grids, U0 = _batch(m1, m2, strikes)
     U = U0.copy()
     if m1 == 512:
-        monkeypatch.setenv("HADI_TUNE_STRIP", "1")  # the strip row pass with a ring of floats (chosen by itself for large batches)
-    solver.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U,
-                           state_precision=H.STATE_FP32)
+        solver.set_tuning("strip", 1)  # the strip row pass with a ring of floats (chosen by itself for large batches)
+    try:
+        solver.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U,
+                               state_precision=H.STATE_FP32)
+    finally:
+        solver.set_tuning("strip", -1)
     assert "float" in solver.describe_last_sweep() and (("strip" in solver.describe_last_sweep()) == (m1 == 512))
     p = Cm.oracle_params(m1, m2, N, "EU", r_f=0.01)
     p.state_fp32 = 1

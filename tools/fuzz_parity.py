@@ -27,13 +27,13 @@ for c in range(cases):
     U, lam = U0.copy(), np.zeros_like(U0)
     div = H.Dividends(*Cm.DIVS) if variant in (H.DIV, H.AM_DIV) else None
     if rng.random() < 0.3: s.set_tuning("american_p", 0)
-    if rng.random() < 0.3: os.environ["HADI_TUNE_STRIP"] = "1"
+    if rng.random() < 0.3: s.set_tuning("strip", 1)
     try:
         s.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, r_f, *model, grids, U, variant=variant, U_0=U0,
                           lambda_bar=lam if variant in (H.AM, H.AM_DIV) else None, dividends=div)
         path = s.describe_last_sweep()
     finally:
-        s.set_tuning("american_p", 1); os.environ.pop("HADI_TUNE_STRIP", None)
+        s.set_tuning("american_p", 1); s.set_tuning("strip", -1)
     p = O.make_params(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, r_f, *model, variant, Cm.DIVS if div is not None else None)
     Uo, lo, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0, want_lambda=True)
     err = np.abs(U - Uo).max() / np.abs(Uo).max()

@@ -15,5 +15,3 @@ for prof in (False, True, False):
         best = min(best, time.perf_counter() - t)
     tm = s.timing()
     print("profiling" if prof else "plain", "wall %.2f ms" % (best * 1e3), {k: round(v, 3) for k, v in tm.items() if k.endswith("_ms")}, s.describe_last_sweep())
-for env in ("HADI_NO_GRAPH",):
-    pass
