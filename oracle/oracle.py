@@ -93,7 +93,7 @@ def make_params(m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, var
         p.strike_i = _p(ks)
     if dividends is not None:
         dates, amounts, pcts = (_f64(x) for x in dividends)
-        keep = [dates, amounts, pcts]
+        keep += [dates, amounts, pcts]
         p.num_dividends = len(dates)
         p.div_dates, p.div_amounts, p.div_percentages = _p(dates), _p(amounts), _p(pcts)
     else:
