@@ -38,8 +38,11 @@ def test_two_rank_calibration_with_device_resident_shards():
     the code path bench.py drives over an RCCL group on a real node).  Same trajectory as the host-array run."""
     host, devr = _run(2, 29633), _run(2, 29634, "--device-arrays", "--subgroup")
     assert host["iterations"] == devr["iterations"] and host["pde_solves"] == devr["pde_solves"]
+    # same start -> same first error; afterwards the re-associated sums of the tree reduction move the step through the
+    # cond ~1e9 normal equations in the 6th digit (same bound as the libhadi-vs-oracle trajectories in test_gpu_parity)
+    assert abs(host["errors"][0] - devr["errors"][0]) <= 1e-9 * host["errors"][0]
     for a, b in zip(host["errors"], devr["errors"]):
-        assert abs(a - b) <= 1e-6 * max(1.0, a)
+        assert abs(a - b) <= 1e-4 * max(1.0, a)
     for k in ("eta", "sigma", "rho", "v0"):
         assert abs(host[k] - devr[k]) <= 1e-3 * max(1e-2, abs(host[k]))
     assert max(abs(x - y) for x, y in zip(host["prices"], devr["prices"])) <= 1e-4
