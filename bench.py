@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--skip-single", action="store_true", help="skip the 1-instance latency run and the batch sweep (profiling)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the timed collectives (nccl = RCCL)")
     ap.add_argument("--allow-gloo", action="store_true", help="rehearsal: fall back to gloo when RCCL cannot come up")
+    ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
+                    help="hadi_set_tuning override (diagnostics), e.g. --tuning strip=1")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (a 1-GPU box cannot host one GPU per rank)")
     args = ap.parse_args()
@@ -123,8 +125,8 @@ def main():
     m1, m2, N = args.m1 or m1, args.m2 or m2, args.timesteps or N
     n_loc = args.instances or n_loc
     state = args.state or ("fp32" if wl == "c5" else "fp64")
-    if wl != "c5" and state == "fp32":
-        BA, BB = 8.0, 8.0
+    if wl in ("c2", "c5"):
+        BA, BB = (8.0, 8.0) if state == "fp32" else (16.0, 16.0)
     STATE = H.STATE_FP32 if state == "fp32" else H.STATE_FP64
     B_STEP = BA + BB
 
@@ -142,6 +144,8 @@ def main():
     comm = H.Communicator(device=coll_dev, group=group)
     m = (m1 + 1) * (m2 + 1)
     solver = H.HestonADI(dev_index)
+    for kv in args.tuning:
+        solver.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
 
     # ---- this rank's shard of the workload ---------------------------------------------------------------------------
     if wl == "c4":

@@ -31,11 +31,18 @@ HADI_DEV HADI_FORCEINLINE double hadi_rcp(double x) {
 #if defined(HADI_EMU)
     return 1.0 / x;
 #else
-    // v_rcp_f64 delivers ~2^-26; one third-order step r (1 + e + e^2), e = 1 - x r, leaves e^3 -- below the rounding of
-    // the result -- in three FMAs (two Newton steps take four, and a longer dependent chain)
+    // v_rcp_f64 delivers ~2^-26; ONE Newton step r (1 + e), e = 1 - x r, leaves e^2 ~ 2^-52: the result is within ~1.5 ulp
+    // (two FMAs; the third-order step r (1 + e + e^2) used before cost a third FMA on each of the 15 reciprocals of a
+    // row -- 3 % of the row pass -- for digits far below the 1e-10 parity tolerance)
+#if defined(HADI_RCP_THIRD_ORDER)
     const double r = __builtin_amdgcn_rcp(x);
     const double e = fma(-x, r, 1.0);
     const double t = fma(e, e, e);
     return fma(r, t, r);
+#else
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+#endif
 #endif
 }

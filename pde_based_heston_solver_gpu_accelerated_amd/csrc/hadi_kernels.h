@@ -337,6 +337,42 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_to_lds(const T *__restrict__ grow, T *lr
             for (int e = 0; e < EPV; e++) lrow[EPV * v + e] = (T)0;
     }
 }
+// The same copy for a pitch known at compile time (rowp = 64 B G + 8): NFULL unmasked 1 KiB pieces and one
+// partial piece, fully unrolled -- no loop counters, compares or exec-mask juggling in the row loop.
+template <int B, class T, int G = 1>
+HADI_DEV HADI_FORCEINLINE void hadi_row_to_lds_fixed(const T *__restrict__ grow, T *lrow, int lane, bool exists) {
+    constexpr int EPV = 16 / (int)sizeof(T), ROWP = 64 * B * G + 8, NVEC = ROWP / EPV, NFULL = NVEC / 64, REM = NVEC - 64 * NFULL;
+    static_assert(ROWP % EPV == 0, "row pitch must be a whole number of 16-byte vectors");
+    if (exists) {
+#if defined(HADI_EMU)
+        for (int v = lane; v < NVEC; v += 64)
+            for (int e = 0; e < EPV; e++) lrow[EPV * v + e] = grow[EPV * v + e];
+#else
+        const T *gsrc = grow + EPV * lane;
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)lrow);
+#pragma unroll
+        for (int q = 0; q < NFULL; q++) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" HADI_DMA_POLICY "\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(gsrc + EPV * 64 * q), "s"(lds0 + 1024u * q)
+                         : "memory");
+        }
+        if constexpr (REM > 0) {
+            if (lane < REM) {
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" HADI_DMA_POLICY "\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(gsrc + EPV * 64 * NFULL), "s"(lds0 + 1024u * NFULL)
+                             : "memory");
+            }
+        }
+#endif
+    } else {
+        for (int v = lane; v < NVEC; v += 64)
+            for (int e = 0; e < EPV; e++) lrow[EPV * v + e] = (T)0;
+    }
+}
 // number of vector-memory instructions hadi_row_to_lds issues for an existing row
 template <class T>
 HADI_DEV HADI_FORCEINLINE int hadi_row_dma_count(int rowp) {
@@ -798,7 +834,12 @@ HADI_DEV HADI_FORCEINLINE void hadi_wait_vmcnt(int n) {
 // (two 4-wave blocks per CU), 2 below.  Large batches at 8 nodes per lane use hadi_pass_a_strip instead.
 // T = float: fp32-state sweep (a.U / a.Y then point to float arrays of the same element layout; European Douglas only).
 template <int B, int G, int W, int NG, int PD, int AMER, int MODE = 0, class T = double>
-__global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : 4)) hadi_pass_a(HadiSweepArgs a, int n) {
+// Minimum blocks per CU of the shared-ring kernel at 4 nodes per lane: 3 (170 VGPRs) -- at 4 (128 VGPRs) the American
+// variants spill into scratch inside the row loop (measured, 256x128 x512 American puts: 0.0966 -> 0.0942 ms per launch)
+#ifndef HADI_RING_OCC_B4
+#define HADI_RING_OCC_B4 3
+#endif
+__global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : B == 4 ? HADI_RING_OCC_B4 : 4)) hadi_pass_a(HadiSweepArgs a, int n) {
     static_assert(sizeof(T) == 8 || (!AMER && MODE == 0), "the fp32-state sweep covers the European Douglas step only");
     HADI_DYN_SMEM(double, smem);
     constexpr int RING = (PD + 1) * W + 4;
@@ -885,7 +926,10 @@ __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : 4)) hadi_pass_a
     // fetch returns the number of vector-memory instructions it issued
     auto fetch = [&](int jj) -> int {
         const bool exists = jj >= 0 && jj < npad;
-        hadi_row_to_lds(Ub + (size_t)jj * rowp, slot(jj), rowp, lane, exists);
+        if constexpr ((64 * B * G + 8) % (16 / (int)sizeof(T)) == 0)
+            hadi_row_to_lds_fixed<B, T, G>(Ub + (ptrdiff_t)jj * rowp, slot(jj), lane, exists);
+        else
+            hadi_row_to_lds(Ub + (size_t)jj * rowp, slot(jj), rowp, lane, exists);
         return exists ? hadi_row_dma_count<T>(rowp) : 0;
     };
     // prologue: rows of iterations 0 .. PD-1
@@ -1072,7 +1116,8 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
         if constexpr (AMER) S += lam[r];
         double y = fma(dt, S, u0[r]);
         y = fma(kap, T1, y);
-        y = fma(b1l, (r == b1r) ? 1.0 : 0.0, y);  // wave-uniform selector: one FMA with a scalar operand
+        y = fma(b1l, (r == b1r) ? 1.0 : 0.0, y);  // wave-uniform selector: one FMA with a scalar operand (a scalar branch
+                                                  // around a single add measured slower: 0.1108 vs 0.1099 ms per launch)
         if (r == 0 && lane == 0) {  // x_0 is known: move it to the right-hand side
             y -= il * x0;
             il = 0.0;
@@ -1232,7 +1277,7 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 4 ? 2 : 4)) ha
     // returns the number of vector-memory instructions issued (rows outside the allocation are zero-filled)
     auto fetch = [&](int jj) -> int {
         const bool exists = jj >= 0 && jj < npad;
-        hadi_row_to_lds(Ub + (size_t)jj * rowp, slot(jj), rowp, lane, exists);
+        hadi_row_to_lds_fixed<B, T>(Ub + (ptrdiff_t)jj * rowp, slot(jj), lane, exists);
         return exists ? hadi_row_dma_count<T>(rowp) : 0;
     };
     // Direction of the walk: even strips go up (j0 -> j1-1), odd strips come down (j1-1 -> j0).  Neighbouring strips
@@ -1399,6 +1444,7 @@ struct HadiPassBCtx {
                         // coefficients of (left-neighbour last two, right-neighbour first two)
     double *zsh;        // LDS exchange, 2 buffers of P*4*64
     int lane, wave, P, ja, rowp, american, pos_m1;
+    int nrows;          // real v-rows (m2 + 1); rows nrows .. P*HADI_LC-1 are identity padding
     double dt;
     HADI_STAMP_ACC
 };
@@ -1428,15 +1474,23 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_load_table(HadiPassBCtx &c, const double 
     hadi_wave_rendezvous();
 }
 
+// Storage row of chunk row k.  Identity padding rows (>= nrows; only the last chunk has any) are all mapped to the FIRST
+// padding row: they hold zeros in Y (the row pass never writes them) and receive zeros in U, so one cached row serves
+// every padded load and store and the padding costs no HBM traffic (scalar min + multiply per row, no VALU).
+HADI_DEV HADI_FORCEINLINE unsigned hadi_pb_row(const HadiPassBCtx &c, int k) {
+    const int r = c.ja + k;
+    return (unsigned)(r < c.nrows ? r : c.nrows);
+}
+
 template <class T = double>
 HADI_DEV HADI_FORCEINLINE void hadi_pb_load(const HadiPassBCtx &c, int ctile, double (&y)[HADI_LC]) {
     constexpr unsigned ES = (unsigned)sizeof(T);
     const int col = ctile * 64 + c.lane;
     const int colc = col < c.rowp ? col : c.rowp - 1;  // lanes past the pitch read a valid address, never store
     const unsigned voff = (unsigned)colc * ES;
-    const unsigned row0 = (unsigned)c.ja * (unsigned)c.rowp * ES, rstride = (unsigned)c.rowp * ES;
+    const unsigned rstride = (unsigned)c.rowp * ES;
 #pragma unroll
-    for (int k = 0; k < HADI_LC; k++) y[k] = hadi_buf_load_t<T>(c.Yb, voff, row0 + (unsigned)k * rstride);
+    for (int k = 0; k < HADI_LC; k++) y[k] = hadi_buf_load_t<T>(c.Yb, voff, hadi_pb_row(c, k) * rstride);
 }
 
 // Chunk-local solve + interface exchange + spike correction of one 64-column tile held in y (no memory traffic).
@@ -1519,17 +1573,18 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_store(const HadiPassBCtx &c, int ctile, d
     const size_t base = (size_t)c.ja * c.rowp + colc;
     if constexpr (AMER == 0) {
         const unsigned voff = (unsigned)colc * ES;
-        const unsigned row0 = (unsigned)c.ja * (unsigned)c.rowp * ES, rstride = (unsigned)c.rowp * ES;
+        const unsigned rstride = (unsigned)c.rowp * ES;
         if constexpr (RELOAD) {
             const unsigned voffs = valid ? voff : HADI_BUF_DROP;
 #pragma unroll
             for (int k = 0; k < HADI_LC; k++) {
-                hadi_buf_store_t<T>(c.Ub, voffs, row0 + (unsigned)k * rstride, y[k]);
-                y[k] = hadi_buf_load_t<T>(c.Yb, voffn, row0 + (unsigned)k * rstride);
+                const unsigned ro = hadi_pb_row(c, k) * rstride;
+                hadi_buf_store_t<T>(c.Ub, voffs, ro, y[k]);
+                y[k] = hadi_buf_load_t<T>(c.Yb, voffn, ro);
             }
         } else if (valid) {
 #pragma unroll
-            for (int k = 0; k < HADI_LC; k++) hadi_buf_store_t<T>(c.Ub, voff, row0 + (unsigned)k * rstride, y[k]);
+            for (int k = 0; k < HADI_LC; k++) hadi_buf_store_t<T>(c.Ub, voff, hadi_pb_row(c, k) * rstride, y[k]);
         }
     } else {
         const unsigned row0 = (unsigned)c.ja * (unsigned)c.rowp * 8u, rstride = (unsigned)c.rowp * 8u;
@@ -1584,9 +1639,9 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_load_old(const HadiPassBCtx &c, int ctile
     const int col = ctile * 64 + c.lane;
     const int colc = col < c.rowp ? col : c.rowp - 1;
     const unsigned voff = (unsigned)colc * 8u;
-    const unsigned row0 = (unsigned)c.ja * (unsigned)c.rowp * 8u, rstride = (unsigned)c.rowp * 8u;
+    const unsigned rstride = (unsigned)c.rowp * 8u;
 #pragma unroll
-    for (int k = 0; k < HADI_LC; k++) po[k] = hadi_buf_load(AMER == 2 ? c.Ub : c.Lb, voff, row0 + (unsigned)k * rstride);
+    for (int k = 0; k < HADI_LC; k++) po[k] = hadi_buf_load(AMER == 2 ? c.Ub : c.Lb, voff, hadi_pb_row(c, k) * rstride);
 }
 // Ikonen-Toivanen projection (device_solver.hpp:358-372) of the solved tile with the prefetched old values; payoff that
 // depends on s only (one value per column).  Raw buffer stores; lanes past the pitch are dropped by the range check.
@@ -1602,6 +1657,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_store_am(const HadiPassBCtx &c, int ctile
     const double dt = c.dt;
     const bool is_smax = (col == c.pos_m1);
     const double pay = c.P0i[colc];
+    // (the projection writes the payoff, not zeros, to padding rows: they keep their own storage rows here)
 #pragma unroll
     for (int k = 0; k < HADI_LC; k++) {
         const double U_bar = y[k];
@@ -1642,12 +1698,17 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
     c.zsh = smem;
     double *__restrict__ tsh = smem + (size_t)c.P * 2 * 4 * 64;
     // blocks walk the instances in DESCENDING order: the row pass writes Y ascending, so the column pass starts on the
-    // part of Y that is still in the memory-side cache (and leaves the low instances of U there for the next row pass)
-    const int binst = blockIdx.x / a.bgroups, grp = blockIdx.x - binst * a.bgroups;
+    // part of Y that is still in the memory-side cache (and leaves the low instances of U there for the next row pass).
+    // XCD-aware: the blocks of one instance (they read the same chunk tables and reduced-inverse rows) get consecutive
+    // logical ids on ONE XCD, so the second and third reader find the tables in that XCD's L2.
+    const int logical = hadi_xcd_remap(blockIdx.x, gridDim.x);
+    if (logical >= a.n_inst * a.bgroups) return;  // grid padded to a multiple of 8 (whole block: uniform)
+    const int binst = logical / a.bgroups, grp = logical - binst * a.bgroups;
     const int inst = a.n_inst - 1 - binst;
     const HadiInstPar ip = a.ipar[inst];
     if (n > ip.N) return;  // whole block: uniform
     const int nrows = a.L.nrows_pad;
+    c.nrows = a.L.nrows;
     c.rowp = a.L.rowp;
     c.ja = c.wave * HADI_LC;
     c.Yi = a.Y + (size_t)inst * a.L.inst_stride;  // (pointer-based accesses: American, T = double only)
@@ -1755,12 +1816,17 @@ __global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, in
     c.zsh = smem;
     double *__restrict__ tsh = smem + (size_t)c.P * 2 * 4 * 64;
     // blocks walk the instances in DESCENDING order: the row pass writes Y ascending, so the column pass starts on the
-    // part of Y that is still in the memory-side cache (and leaves the low instances of U there for the next row pass)
-    const int binst = blockIdx.x / a.bgroups, grp = blockIdx.x - binst * a.bgroups;
+    // part of Y that is still in the memory-side cache (and leaves the low instances of U there for the next row pass).
+    // XCD-aware: the blocks of one instance (they read the same chunk tables and reduced-inverse rows) get consecutive
+    // logical ids on ONE XCD, so the second and third reader find the tables in that XCD's L2.
+    const int logical = hadi_xcd_remap(blockIdx.x, gridDim.x);
+    if (logical >= a.n_inst * a.bgroups) return;  // grid padded to a multiple of 8 (whole block: uniform)
+    const int binst = logical / a.bgroups, grp = logical - binst * a.bgroups;
     const int inst = a.n_inst - 1 - binst;
     const HadiInstPar ip = a.ipar[inst];
     if (n > ip.N) return;  // whole block: uniform
     const int nrows = a.L.nrows_pad;
+    c.nrows = a.L.nrows;
     c.rowp = a.L.rowp;
     c.ja = c.wave * HADI_LC;
     c.Yi = a.Y + (size_t)inst * a.L.inst_stride;  // (pointer-based accesses: American, T = double only)

@@ -138,7 +138,7 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
         p.btpw = (p.ctiles + groups - 1) / groups;
         p.bgroups = (p.ctiles + p.btpw - 1) / p.btpw;
     }
-    p.grid_b = n_inst * p.bgroups;
+    p.grid_b = (n_inst * p.bgroups + 7) / 8 * 8;  // padded to a multiple of 8 for the XCD remap
     p.block_b = 64 * L.P;
     // two interface-exchange buffers + each wavefront's four rows of the reduced inverse
     p.smem_b = (size_t)L.P * (2 * 4 * 64 + 16 * L.P) * sizeof(double);

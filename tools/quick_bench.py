@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Kernel-level A/B numbers on the GPU box: python tools/quick_bench.py [c2 c3 c5 c5f64 am512 ...]
+Prints per workload the row-pass / column-pass mean launch time (HIP events, profiled step) and the whole-sweep rate."""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = {
+    "c2": ["--workload", "c2"], "c2_64": ["--workload", "c2", "--instances", "64"], "c2_160": ["--workload", "c2", "--instances", "160"],
+    "c2_512": ["--workload", "c2", "--instances", "512"],
+    "c3": ["--workload", "c3"], "c3strip": ["--workload", "c3", "--tuning", "strip=1"],
+    "c2ring": ["--workload", "c2", "--tuning", "strip=0"], "c2am": ["--workload", "c3", "--m1", "512", "--m2", "256", "--timesteps", "1000", "--instances", "256"], "c5": ["--workload", "c5"], "c5f64": ["--workload", "c5", "--state", "fp64"], "c4": ["--workload", "c4"],
+}
+argv = sys.argv[1:]
+libs = [None]
+if "--lib" in argv:  # --lib a.so,b.so : every case is timed with each library in turn (same box, interleaved)
+    k = argv.index("--lib"); libs = argv[k + 1].split(","); del argv[k:k + 2]
+reps = 1
+if "--reps" in argv:
+    k = argv.index("--reps"); reps = int(argv[k + 1]); del argv[k:k + 2]
+for name, lib in [(n, l) for n in (argv or ["c2"]) for _ in range(reps) for l in libs]:
+    head = [sys.executable, os.path.join(ROOT, "bench.py")] if lib in (None, "head") else \
+           [sys.executable, os.path.join(ROOT, "tools", "bench_variant.py"), os.path.join(ROOT, lib)]
+    out = subprocess.run(head + ["--steps", "2", "--warmup", "1", "--skip-single", "--no-cpu-baseline"] + CASES[name],
+                         capture_output=True, text=True)
+    name = name if lib in (None,) else "%s[%s]" % (name, os.path.basename(lib).replace("_var_", "").replace(".so", ""))
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    if not line:
+        print(name, "FAILED", out.stderr[-800:]); continue
+    d = json.loads(line[-1]); r = d["roofline"]
+    pb = r.get("pass_b") or {}; sw = r.get("sweep") or {}
+    print("%-16s value %.4e  row %.5f ms (%.3f)  col %.5f ms (%.3f)  sweep %.3f | %s" % (
+        name, d["value"], r.get("avg_launch_ms") or 0, r["frac"], pb.get("avg_launch_ms") or 0, pb.get("frac") or 0, sw.get("frac") or 0,
+        r["kernel"][:60]), flush=True)
