@@ -168,6 +168,8 @@ int hadi_get_timing(const hadi_ctx *ctx, hadi_timing *out);
  *   "row_tile"    shared-ring row pass: v-rows per block tile (0 = automatic)
  *   "col_groups"  column pass: blocks per instance (0 = automatic)
  *   "small_waves" small-grid kernel: wavefronts per instance, 4 or 8 (0 = automatic)
+ *   "sub_batch"   batches of several rounds of one instance per CU on grids whose round exceeds the 256 MB memory-side
+ *                 cache run sub-batch by sub-batch through the time loop (default 1; instances are independent)
  *   "device_vgrid" v-grids of compute_base_prices / compute_jacobian rebuilt per instance on the device (default 1;
  *                 0 = built once on the host with glibc sinh/asinh and broadcast -- bit-identical to the reference's
  *                 host-side Grid, needs one shared V_0) */

@@ -49,6 +49,8 @@ struct Ctx {
     int use_small = 1;  // LDS-resident one-launch path for small grids
     int use_amp = 1;    // American sweeps without the lambda_bar array when the payoff depends on s only
     int device_vgrid = 1;  // compute_base_prices / compute_jacobian: v-grids rebuilt per instance on the device
+    int sub_batch = 1;     // large batches run sub-batch by sub-batch (run_sweep)
+    int last_nsub = 1;
     HadiTuning tune;    // kernel-selection overrides (hadi_set_tuning)
     hipEvent_t wait_ev = nullptr;  // hadi_wait_stream
     DevBuf lm31;
@@ -243,6 +245,17 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     if (hadi_make_plan(d.m1, d.m2, d.n, 8 * c->cu_count, &pl, c->tune))
         return fail(c, HADI_ERR_UNSUPPORTED, "grid %dx%d not supported (need 2 <= m1 <= 1024, 3 <= m2 <= %d)", d.m1, d.m2,
                     HADI_MAX_P * HADI_LC - 1);
+    // Large batches on grids where ONE round of the one-block-per-CU kernels (cu_count instances) already moves more than
+    // the 256 MB memory-side cache holds: the two passes of a step then re-use each other's data only while the batch is
+    // one round deep (measured at 512x256: 512 instances at once ran the column pass 6 % slower per instance than 256).
+    // Instances are independent, so the time loop runs sub-batch by sub-batch, each with the one-round geometry.
+    int nsub = 1;
+    if (d.scheme == HADI_SCHEME_DOUGLAS && !d.debug && c->sub_batch && d.n > c->cu_count && d.n % c->cu_count == 0 &&
+        2ll * c->cu_count * pl.L.inst_stride * (long long)sizeof(double) >= (256ll << 20)) {
+        nsub = d.n / c->cu_count;
+        if (hadi_make_plan(d.m1, d.m2, d.n / nsub, 8 * c->cu_count, &pl, c->tune)) return fail(c, HADI_ERR_UNSUPPORTED, "plan failed");
+    }
+    const int nsb = d.n / nsub;
     if (!(d.theta > 0.0)) pl.use_strip = 0;  // the strip kernel scales the A1 action by (1 - theta) / theta
     const HadiLayout &L = pl.L;
     const bool american = d.variant == HADI_AM || d.variant == HADI_AM_DIV;
@@ -350,7 +363,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     a.pay_mis = american ? ptr<int>(c->pay_mis) : nullptr;
     a.scoef = ptr<double>(c->scoef); a.b2row = ptr<double>(c->b2row); a.rowc = ptr<double>(c->rowc);
     a.pb = ptr<double>(c->pb); a.rinv = ptr<double>(c->rinv); a.ipar = ptr<HadiInstPar>(c->ipar);
-    a.L = L; a.n_inst = d.n; a.R = pl.R; a.ntiles = pl.ntiles; a.ctiles = pl.ctiles; a.btpw = pl.btpw; a.bgroups = pl.bgroups;
+    a.L = L; a.n_inst = nsb; a.R = pl.R; a.ntiles = pl.ntiles; a.ctiles = pl.ctiles; a.btpw = pl.btpw; a.bgroups = pl.bgroups;
     a.american = american ? 1 : 0; a.pos_m1 = pl.pos_m1;
     a.RS = pl.RS; a.sblocks = pl.sblocks;
     a.R1 = cs ? ptr<double>(c->R1) : nullptr;
@@ -361,7 +374,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
 
     const bool prof = c->profiling != 0 && !d.debug;
     if (prof) {
-        const size_t need = (size_t)4 * d.Nmax;
+        const size_t need = (size_t)4 * d.Nmax * nsub;
         while (c->kev.size() < need) {
             hipEvent_t e;
             HIP_TRY(c, hipEventCreate(&e));
@@ -369,23 +382,50 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         }
     }
     // The whole time loop as a function of the stream, so it can be enqueued directly or captured.
+    // Instance offset `o` applied to every per-instance array of the sweep arguments (sub-batches, see nsub above).
+    auto shift = [&](HadiSweepArgs x, int o) {
+        const size_t so = (size_t)o * L.inst_stride;
+        if (f32) {
+            x.U = reinterpret_cast<double *>(reinterpret_cast<float *>(x.U) + so);
+            x.Y = reinterpret_cast<double *>(reinterpret_cast<float *>(x.Y) + so);
+        } else {
+            x.U += so;
+            x.Y += so;
+        }
+        if (x.LAM) x.LAM += so;
+        if (x.U0) x.U0 += so;
+        if (x.pay_mis) x.pay_mis += o;
+        if (x.R1) x.R1 += so;
+        if (x.C2) x.C2 += so;
+        x.scoef += (size_t)o * pl.n_scoef; x.b2row += (size_t)o * pl.n_b2row; x.rowc += (size_t)o * pl.n_rowc;
+        x.pb += (size_t)o * pl.n_pb; x.rinv += (size_t)o * pl.n_rinv; x.ipar += o;
+        return x;
+    };
+    const HadiSweepArgs a_all = a, av_all = av;
     auto enqueue_loop = [&](hipStream_t q) -> int {
-        const int n_first = d.debug ? d.debug_step : 1, n_last = d.debug ? d.debug_step : d.Nmax;
+      const int n_first = d.debug ? d.debug_step : 1, n_last = d.debug ? d.debug_step : d.Nmax;
+      for (int sb = 0; sb < nsub; sb++) {  // one sub-batch after the other, each through its whole time loop
+        const int o = sb * nsb;
+        const size_t so = (size_t)o * L.inst_stride;
+        const HadiSweepArgs a = shift(a_all, o), av = shift(av_all, o);
+        const size_t tot = (size_t)L.inst_stride * nsb, st = tot * sizeof(double);  // (shadow the whole-batch sizes)
+        double *const Ub = ptr<double>(c->U) + so, *const LAMb = american ? ptr<double>(c->LAM) + so : nullptr;
+        double *const U0b = american ? ptr<double>(c->U0) + so : nullptr, *const UTb = dividend ? ptr<double>(c->UT) + so : nullptr;
+        const int ev0 = 4 * sb * d.Nmax;  // profiling events of this sub-batch
         for (int nstep = n_first; nstep <= n_last; nstep++) {
             // P representation: the first step (the caller's initial U need not dominate the payoff) and dividend steps
             // (the jump acts on U alone) run on the explicit (U, lambda_bar) pair, converted on the way in and out
             const bool xstep = amp && (nstep == 1 || (have_div && div_step[nstep]));
             if (xstep && nstep > 1)
-                hipLaunchKernelGGL(hadi_am_materialise_kernel, dim3(grid1d(tot)), dim3(256), 0, q, L, d.n, ptr<HadiInstPar>(c->ipar),
-                                   ptr<double>(c->U0), ptr<double>(c->U), ptr<double>(c->LAM), pl.pos_m1);
+                hipLaunchKernelGGL(hadi_am_materialise_kernel, dim3(grid1d(tot)), dim3(256), 0, q, L, nsb, a.ipar, U0b, Ub, LAMb, pl.pos_m1);
             if (have_div && div_step[nstep]) {  // device_solver.hpp:426-517: U_temp <- U, U <- interpolated jump
-                HIP_TRY(c, hipMemcpyAsync(c->UT.p, c->U.p, st, hipMemcpyDeviceToDevice, q));
-                const size_t npts = (size_t)d.n * L.nrows * (L.m1 + 1);
-                hipLaunchKernelGGL(hadi_dividend_kernel, dim3(grid1d(npts)), dim3(256), 0, q, L, d.n, ptr<HadiInstPar>(c->ipar), d.d_vec_s,
-                                   ptr<double>(c->UT), ptr<double>(c->U), ptr<int>(c->div_flag), flag_stride, nstep,
-                                   ptr<double>(c->div_amt), ptr<double>(c->div_pct));
+                HIP_TRY(c, hipMemcpyAsync(UTb, Ub, st, hipMemcpyDeviceToDevice, q));
+                const size_t npts = (size_t)nsb * L.nrows * (L.m1 + 1);
+                hipLaunchKernelGGL(hadi_dividend_kernel, dim3(grid1d(npts)), dim3(256), 0, q, L, nsb, a.ipar,
+                                   d.d_vec_s + (size_t)o * (L.m1 + 1), UTb, Ub, ptr<int>(c->div_flag) + (size_t)o * flag_stride,
+                                   flag_stride, nstep, ptr<double>(c->div_amt), ptr<double>(c->div_pct));
             }
-            if (prof) HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 0], q));
+            if (prof) HIP_TRY(c, hipEventRecord(c->kev[ev0 + 4 * (nstep - 1) + 0], q));
             auto row_pass = [&](const HadiSweepArgs &ar, int mode) {
                 if (amp && !xstep && pl.use_strip && mode == 0) {  // P representation on barrier-free strips
                     const dim3 g(pl.grid_as), b(64 * HADI_STRIP_WAVES(L.B));
@@ -466,30 +506,29 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                 }
             };
             if (d.debug == 2) {  // diagnostics: one column solve of the packed input (moved to Y), nothing else
-                HIP_TRY(c, hipMemcpyAsync(f32 ? c->Yf.p : c->Y.p, f32 ? c->Uf.p : c->U.p, f32 ? st / 2 : st, hipMemcpyDeviceToDevice, q));
+                HIP_TRY(c, hipMemcpyAsync(a.Y, a.U, f32 ? st / 2 : st, hipMemcpyDeviceToDevice, q));
                 col_pass(a);
                 break;
             }
             row_pass(a, cs ? 1 : 0);
             if (d.debug == 1) break;  // diagnostics: Y now holds the right-hand side of the A2 solve
             if (prof) {
-                HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 1], q));
-                HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 2], q));
+                HIP_TRY(c, hipEventRecord(c->kev[ev0 + 4 * (nstep - 1) + 1], q));
+                HIP_TRY(c, hipEventRecord(c->kev[ev0 + 4 * (nstep - 1) + 2], q));
             }
             col_pass(cs ? av : a);
-            if (prof) HIP_TRY(c, hipEventRecord(c->kev[4 * (nstep - 1) + 3], q));
+            if (prof) HIP_TRY(c, hipEventRecord(c->kev[ev0 + 4 * (nstep - 1) + 3], q));
             if (cs) {  // corrector (profiling events cover the predictor's two passes only)
                 row_pass(av, 2);
                 col_pass(a);
             }
             if (xstep)
-                hipLaunchKernelGGL(hadi_am_dematerialise_kernel, dim3(grid1d(tot)), dim3(256), 0, q, L, d.n, ptr<HadiInstPar>(c->ipar),
-                                   ptr<double>(c->U0), ptr<double>(c->U), ptr<double>(c->LAM));
+                hipLaunchKernelGGL(hadi_am_dematerialise_kernel, dim3(grid1d(tot)), dim3(256), 0, q, L, nsb, a.ipar, U0b, Ub, LAMb);
         }
         if (amp)  // explicit U and lambda_bar for the outputs
-            hipLaunchKernelGGL(hadi_am_materialise_kernel, dim3(grid1d(tot)), dim3(256), 0, q, L, d.n, ptr<HadiInstPar>(c->ipar),
-                               ptr<double>(c->U0), ptr<double>(c->U), ptr<double>(c->LAM), pl.pos_m1);
-        return HADI_OK;
+            hipLaunchKernelGGL(hadi_am_materialise_kernel, dim3(grid1d(tot)), dim3(256), 0, q, L, nsb, a.ipar, U0b, Ub, LAMb, pl.pos_m1);
+      }
+      return HADI_OK;
     };
 
     // ---- small grids: the whole instance fits in LDS -> one launch runs the entire time loop ----------
@@ -557,7 +596,9 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         std::snprintf(buf, sizeof buf, "row pass %s; column pass %s<%d,%s> (%d chunks of %d rows, %d column tiles per block)", rowk,
                       L.P <= 8 ? "hadi_pass_b" : "hadi_pass_b1", L.P <= 8 ? 8 : 16, amp ? "AM-P" : american ? "AM" : "EU", L.P, HADI_LC, pl.btpw);
         c->last_path = buf;
+        if (nsub > 1) c->last_path += "; " + std::to_string(nsub) + " sub-batches of " + std::to_string(nsb) + " instances";
     }
+    c->last_nsub = nsub;
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     // Small batches are launch-bound (2*N dependent launches of a few microseconds each): replay the loop
     // from a cached hipGraph.  Every kernel argument is baked into the nodes, so the key is everything they
@@ -633,13 +674,13 @@ int finish_timing(Ctx *c, const SweepDesc &d, const HadiPlan &pl) {
     const long long m = (long long)(d.m1 + 1) * (d.m2 + 1);
     for (int k = 0; k < d.n; k++) ps += m * (long long)d.par8[(size_t)k * 8 + 5];
     t.point_steps = ps;
-    if (c->profiling && !d.debug) {
-        for (int k = 0; k < d.Nmax; k++) {
+    if (c->profiling && !d.debug && (int)c->kev.size() >= 4 * d.Nmax * c->last_nsub) {
+        for (int k = 0; k < d.Nmax * c->last_nsub; k++) {
             HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[4 * k], c->kev[4 * k + 1])); t.pass_a_ms += ms;
             HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[4 * k + 2], c->kev[4 * k + 3])); t.pass_b_ms += ms;
         }
-        t.pass_a_launches = d.Nmax;
-        t.pass_b_launches = d.Nmax;
+        t.pass_a_launches = (long long)d.Nmax * c->last_nsub;
+        t.pass_b_launches = (long long)d.Nmax * c->last_nsub;
     }
     (void)pl;
     return HADI_OK;
@@ -1065,6 +1106,7 @@ int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value) {
     else if (!std::strcmp(key, "small_grid")) c->use_small = value ? 1 : 0;
     else if (!std::strcmp(key, "american_p")) c->use_amp = value ? 1 : 0;
     else if (!std::strcmp(key, "device_vgrid")) c->device_vgrid = value ? 1 : 0;
+    else if (!std::strcmp(key, "sub_batch")) c->sub_batch = value ? 1 : 0;
     else if (!std::strcmp(key, "strip")) c->tune.strip = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "row_tile")) c->tune.row_tile = value > 0 ? value : 0;
     else if (!std::strcmp(key, "col_groups")) c->tune.col_groups = value > 0 ? value : 0;
@@ -1082,6 +1124,7 @@ int hadi_get_tuning(const hadi_ctx *ctx, const char *key, int *value) {
     else if (!std::strcmp(key, "small_grid")) *value = c->use_small;
     else if (!std::strcmp(key, "american_p")) *value = c->use_amp;
     else if (!std::strcmp(key, "device_vgrid")) *value = c->device_vgrid;
+    else if (!std::strcmp(key, "sub_batch")) *value = c->sub_batch;
     else if (!std::strcmp(key, "strip")) *value = c->tune.strip;
     else if (!std::strcmp(key, "row_tile")) *value = c->tune.row_tile;
     else if (!std::strcmp(key, "col_groups")) *value = c->tune.col_groups;

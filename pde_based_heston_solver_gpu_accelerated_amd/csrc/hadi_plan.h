@@ -89,9 +89,8 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
         p.RS = (L.nrows + nwv * p.sblocks - 1) / (nwv * p.sblocks);
         p.grid_as = (int)(((long long)n_inst * p.sblocks + 7) / 8 * 8);
         p.smem_as = ((size_t)nwv * 4 * L.rowp + (size_t)4 * 64 * L.B) * sizeof(double);
-        // Chosen automatically at 8 nodes per lane only: measured on MI355X, 512x256 x256: 0.156 -> 0.141 ms/launch; at 4
-        // nodes per lane (256x128 x1024) the shared-ring kernel, which fits four wavefronts per SIMD there, stays
-        // ahead (0.190 vs 0.203 ms).  hadi_set_tuning("strip", 1) forces strips for 2 and 4 nodes per lane too (tests).
+        // 8 nodes per lane: measured on MI355X, 512x256 x256: 0.156 -> 0.141 ms/launch when introduced (0.110 now).
+        // hadi_set_tuning("strip", 1) forces strips wherever the geometry allows them (tests).
         // One strip block occupies a CU: the launch runs in ceil(blocks / CUs) rounds.  When the last round is mostly
         // empty (e.g. 160 instances -> 320 blocks on 256 CUs) the shared-ring kernel, whose small blocks fill the tail,
         // is faster (measured: 160 instances 0.142 ms with strips, ~0.127 ms with the ring).
@@ -102,6 +101,10 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
         // 2 nodes per lane (64 < m1 <= 128), batches of several blocks per CU: 4-strip blocks beat the shared ring
         // (128x64 x2000: 0.130 -> 0.108 ms per launch); at 4 nodes per lane the two are level (0.165 vs 0.167).
         if (L.B == 2 && p.RS >= 16 && p.RS <= 64 && sblk >= 4 * (long long)cus) p.use_strip = 1;
+        // 4 nodes per lane (128 < m1 <= 256): with the unrolled LDS-DMA fetch the strips are level with the shared ring
+        // at 1024 instances (0.159 ms per launch both) and ahead below that (256x128 x300: 0.063 -> 0.053; 200x100 x700:
+        // 0.094 -> 0.076; 512 American puts in the P representation: 0.094 -> 0.084)
+        if (L.B == 4 && p.RS >= 16 && p.RS <= 64 && sblk >= (long long)cus) p.use_strip = 1;
         if (tu.strip >= 0) p.use_strip = (tu.strip && p.RS >= 1 && p.RS <= 64) ? 1 : 0;
     }
     p.ctiles = (L.rowp + 63) / 64;

@@ -193,11 +193,11 @@ def test_plan_invariants_over_shapes_and_batch_sizes(emu):
                 else:
                     assert not use_strip
                 if use_strip:
-                    assert B in (2, 8) and 16 <= RS <= 64
+                    assert B in (2, 4, 8) and 16 <= RS <= 64
                     seen_strip.add(B)
                 assert btpw * bgroups >= ctiles and (btpw - 1) * bgroups < ctiles + bgroups and ctiles * 64 >= rowp
                 assert grid_b == (n * bgroups + 7) // 8 * 8 and smem_b <= LDS and P <= 16
-    assert seen_strip == {2, 8}
+    assert seen_strip == {2, 4, 8}
     assert emu.emu_plan_full(100, 101, 1, 8, o) == 0  # m2 > m1 is covered (two b1 entries on the v-rows k*m1)
     assert emu.emu_plan_full(1025, 100, 1, 8, o) != 0  # m1 too wide
     assert emu.emu_plan_full(600, 528, 1, 8, o) != 0  # more than 16 chunks

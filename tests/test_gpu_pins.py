@@ -174,10 +174,36 @@ def test_headline_batch_geometry_field_vs_oracle(solver, n):
     d = solver.describe_last_sweep()
     if n in (256, 512):
         assert "hadi_pass_a_strip<8,EU>" in d
+    assert ("2 sub-batches of 256 instances" in d) == (n == 512)
     p = O.make_params(m1, m2, N, Cm.T / 1000, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, O.EU)
     Uo, _, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0)
     errs = np.abs(U - Uo).max(axis=1) / np.abs(Uo).max(axis=1)
     assert errs.max() < FIELD_RTOL, (errs.argmax(), errs.max())
+
+
+def test_sub_batches_do_not_change_results(solver):
+    """512 instances of 512x256 run as two sub-batches of 256 (each round of one block per CU keeps its memory-side cache
+    reuse); instances are independent, so the fields are bit-identical to the whole-batch launch, also for American
+    options with dividends (per-sub-batch dividend jumps and representation changes)."""
+    m1, m2, N, n = 512, 256, 12, 512
+    strikes = Cm.strikes_for(n)
+    grids, U0 = _batch(m1, m2, strikes)
+    divs = ([0.002, 0.006], [0.5, 0.3], [0.02, 0.02])
+    out = {}
+    for variant in (H.EU, H.AM_DIV):
+        for sub in (1, 0):
+            solver.set_tuning("sub_batch", sub)
+            try:
+                U, lam = U0.copy(), np.zeros_like(U0)
+                solver.DO_timestepping(m1, m2, N, Cm.T / 1000, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U,
+                                       variant=variant, U_0=U0, lambda_bar=lam if variant == H.AM_DIV else None,
+                                       dividends=H.Dividends(*divs) if variant == H.AM_DIV else None)
+                assert ("sub-batches" in solver.describe_last_sweep()) == bool(sub)
+            finally:
+                solver.set_tuning("sub_batch", 1)
+            out[(variant, sub)] = (U, lam)
+        assert np.array_equal(out[(variant, 1)][0], out[(variant, 0)][0])
+        assert np.array_equal(out[(variant, 1)][1], out[(variant, 0)][1])
 
 
 @pytest.mark.parametrize("put", [False, True], ids=["call", "put"])

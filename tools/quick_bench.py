@@ -7,6 +7,12 @@ CASES = {
     "c2": ["--workload", "c2"], "c2_64": ["--workload", "c2", "--instances", "64"], "c2_160": ["--workload", "c2", "--instances", "160"],
     "c2_512": ["--workload", "c2", "--instances", "512"],
     "c3": ["--workload", "c3"], "c3strip": ["--workload", "c3", "--tuning", "strip=1"],
+    "g256": ["--workload", "c2", "--m1", "256", "--m2", "128", "--timesteps", "500", "--instances", "1024"],
+    "g256s": ["--workload", "c2", "--m1", "256", "--m2", "128", "--timesteps", "500", "--instances", "1024", "--tuning", "strip=1"],
+    "g256_300": ["--workload", "c2", "--m1", "256", "--m2", "128", "--timesteps", "500", "--instances", "300"],
+    "g256_300s": ["--workload", "c2", "--m1", "256", "--m2", "128", "--timesteps", "500", "--instances", "300", "--tuning", "strip=1"],
+    "g200": ["--workload", "c2", "--m1", "200", "--m2", "100", "--timesteps", "400", "--instances", "700"],
+    "g200s": ["--workload", "c2", "--m1", "200", "--m2", "100", "--timesteps", "400", "--instances", "700", "--tuning", "strip=1"],
     "c2ring": ["--workload", "c2", "--tuning", "strip=0"], "c2am": ["--workload", "c3", "--m1", "512", "--m2", "256", "--timesteps", "1000", "--instances", "256"], "c5": ["--workload", "c5"], "c5f64": ["--workload", "c5", "--state", "fp64"], "c4": ["--workload", "c4"],
 }
 argv = sys.argv[1:]
