@@ -317,6 +317,17 @@ def main():
             if (m1, m2, N) == (512, 256, 1000):
                 single.update(reference_price=8.8942192888223310, price_abs_err=abs(price1 - 8.8942192888223310))
 
+        state_err = None
+        if state == "fp32" and n_gpus == 1 and not args.skip_single:
+            # what the fp32 state costs at this step count: the K ~ 100 instance once more with the fp64 state
+            gk = H.GridViewsBatch.for_strikes(m1, m2, S_0, V_0, [strikes[k_mid]])
+            gkd, uk = gk.to(dev), torch.from_numpy(gk.call_payoff([strikes[k_mid]])).to(dev)
+            solver.DO_timestepping(m1, m2, N, T / N, THETA, R_D, R_F, RHO, SIGMA, KAPPA, ETA, gkd, uk)
+            p64 = float(uk[0, g.find_s_index(S_0) + g.find_v0_index(V_0) * (m1 + 1)].item())
+            state_err = {"price_fp64_state": p64, "price_abs_diff": abs(p64 - price_check["price"]),
+                         "note": "two 24-bit roundings per step accumulate like a random walk (price error 1e-7 .. 1.5e-5, erratic in N): "
+                                 "the fp32 state does not guarantee a 1e-6 price tolerance"}
+
         # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores ------------
         if n_gpus == 1 and not args.no_cpu_baseline and wl != "c4":
             from oracle import oracle as O
@@ -361,6 +372,7 @@ def main():
             "cpu_baseline": cpu,
             "batch_sweep": sweep_obj,
             "single_instance": single,
+            "fp32_state_error": state_err,
             "price_check": price_check,
             "device": info,
         }

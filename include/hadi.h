@@ -71,8 +71,12 @@ enum hadi_scheme { HADI_SCHEME_DOUGLAS = 0, HADI_SCHEME_CRAIG_SNEYD = 1 };
 /* Precision of the state arrays BETWEEN the two directional passes.  FP64 is what the reference computes in.  FP32
  * ("mixed-precision fp32 ADI sweep with fp64 tridiag pivots", BASELINE.json config 5): U and the A2 right-hand side are
  * stored as fp32 in HBM (half the traffic: 16 B per point-step), every operator, pivot and line solve is still
- * evaluated in fp64 in registers.  European Douglas sweeps only; the caller's arrays stay fp64.  Not a reference
- * feature: parity is against the oracle run with the same two roundings per step (tests), ~1e-6 relative to fp64. */
+ * evaluated in fp64 in registers.  European Douglas sweeps (HADI_EU, HADI_DIV) only; the caller's arrays stay fp64.
+ * Not a reference feature: parity is against the oracle run with the same two roundings per step (tests).  Each rounding
+ * perturbs the state by 2^-24 relative and the perturbations add up like a random walk over the steps: against the
+ * fp64 sweep the field moves by up to ~1e-6 relative and the price by 1e-7 .. 1.5e-5 (erratic in N: one realisation of
+ * the walk per run; 1.5e-5 at 1024x512x2000) -- a throughput mode for users who accept that; it does NOT guarantee a 1e-6
+ * price tolerance. */
 enum hadi_state_precision { HADI_STATE_FP64 = 0, HADI_STATE_FP32 = 1 };
 /* Boundary data of the option type.  HADI_CALL is the reference's only boundary class (call-specific,
  * src/BoundaryConditions.hpp:7-12, hes_boundary_kernels.hpp:41-75).  HADI_PUT is NOT a reference feature (README.md:26

@@ -506,8 +506,11 @@ static void timestepping(ho_ws *w, const ho_params *p, const double *vec_s,
             const int process = (current_div_idx < p->num_dividends &&
                                  t <= p->div_dates[current_div_idx] &&
                                  p->div_dates[current_div_idx] < (n + 1) * delta_t);
-            if (process)
+            if (process) {
                 dividend_jump(w, vec_s, U, p->div_amounts[current_div_idx], p->div_percentages[current_div_idx], p->option_type == 1);
+                if (p->state_fp32) /* libhadi widens, jumps and rounds the state again */
+                    for (int i = 0; i < m; i++) U[i] = (double)(float)U[i];
+            }
             if (current_div_idx < p->num_dividends && t > p->div_dates[current_div_idx]) current_div_idx++;
         }
         a0_multiply(w, U, w->A0U);
@@ -561,7 +564,7 @@ int ho_solve(const ho_params *p, const double *vec_s, const double *vec_v,
              double *U, const double *U_0, double *lambda_bar, ho_dump *dump) {
     if (p->m1 < 2 || p->m2 < 3) return -1;
     if (p->scheme == 1 && p->variant != HO_EU) return -4; /* the reference has CS for European only */
-    if (p->state_fp32 && (p->variant != HO_EU || p->scheme != 0)) return -5;
+    if (p->state_fp32 && ((p->variant != HO_EU && p->variant != HO_DIV) || p->scheme != 0)) return -5;
     double *lam_own = NULL;
     if (variant_needs_payoff(p->variant)) {
         if (!U_0) return -2;

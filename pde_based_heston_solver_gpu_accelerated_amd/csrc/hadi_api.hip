@@ -270,7 +270,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     }
     if (dividend && (rc = ensure(c, c->UT, st))) return rc;
     const bool cs = d.scheme == HADI_SCHEME_CRAIG_SNEYD;
-    const bool f32 = d.prec == HADI_STATE_FP32;  // European Douglas only (validated)
+    const bool f32 = d.prec == HADI_STATE_FP32;  // European Douglas (with or without dividends) only (validated)
     if (f32 && ((rc = ensure(c, c->Uf, st / 2)) || (rc = ensure(c, c->Yf, st / 2)))) return rc;
     if (cs && ((rc = ensure(c, c->V, st)) || (rc = ensure(c, c->R1, st)) || (rc = ensure(c, c->C2, st)))) return rc;
     const size_t n = d.n;
@@ -419,11 +419,15 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
             if (xstep && nstep > 1)
                 hipLaunchKernelGGL(hadi_am_materialise_kernel, dim3(grid1d(tot)), dim3(256), 0, q, L, nsb, a.ipar, U0b, Ub, LAMb, pl.pos_m1);
             if (have_div && div_step[nstep]) {  // device_solver.hpp:426-517: U_temp <- U, U <- interpolated jump
+                if (f32)  // fp32 state: the jump works on the fp64 packed array -- widen, jump, round again (<= num_dividends steps)
+                    hipLaunchKernelGGL(hadi_widen_kernel, dim3(grid1d(tot)), dim3(256), 0, q, L, reinterpret_cast<const float *>(a.U), Ub, tot);
                 HIP_TRY(c, hipMemcpyAsync(UTb, Ub, st, hipMemcpyDeviceToDevice, q));
                 const size_t npts = (size_t)nsb * L.nrows * (L.m1 + 1);
                 hipLaunchKernelGGL(hadi_dividend_kernel, dim3(grid1d(npts)), dim3(256), 0, q, L, nsb, a.ipar,
                                    d.d_vec_s + (size_t)o * (L.m1 + 1), UTb, Ub, ptr<int>(c->div_flag) + (size_t)o * flag_stride,
                                    flag_stride, nstep, ptr<double>(c->div_amt), ptr<double>(c->div_pct));
+                if (f32)
+                    hipLaunchKernelGGL(hadi_narrow_kernel, dim3(grid1d(tot)), dim3(256), 0, q, L, Ub, reinterpret_cast<float *>(a.U), tot);
             }
             if (prof) HIP_TRY(c, hipEventRecord(c->kev[ev0 + 4 * (nstep - 1) + 0], q));
             auto row_pass = [&](const HadiSweepArgs &ar, int mode) {
@@ -746,8 +750,9 @@ int check_problem(Ctx *c, const hadi_problem *p, bool need_U, bool need_vgrid) {
         return fail(c, HADI_ERR_UNSUPPORTED, "Craig-Sneyd is available for the European variant only (as in the reference)");
     if (p->state_precision != HADI_STATE_FP64 && p->state_precision != HADI_STATE_FP32)
         return fail(c, HADI_ERR_INVALID, "bad state_precision %d", p->state_precision);
-    if (p->state_precision == HADI_STATE_FP32 && (p->variant != HADI_EU || p->scheme != HADI_SCHEME_DOUGLAS))
-        return fail(c, HADI_ERR_UNSUPPORTED, "the fp32-state sweep covers European Douglas steps only");
+    if (p->state_precision == HADI_STATE_FP32 &&
+        ((p->variant != HADI_EU && p->variant != HADI_DIV) || p->scheme != HADI_SCHEME_DOUGLAS))
+        return fail(c, HADI_ERR_UNSUPPORTED, "the fp32-state sweep covers European Douglas steps (with or without dividends) only");
     return HADI_OK;
 }
 

@@ -669,6 +669,50 @@ def test_fp32_state_sweep_vs_oracle(solver, m1, m2, N, n):
     _assert_field(U, U64, rtol=2e-6)
 
 
+@pytest.mark.parametrize("m1,m2,N,n,strip", [(128, 64, 24, 2, -1), (512, 256, 24, 2, 1), (700, 300, 22, 1, -1)])
+def test_fp32_state_with_dividends_vs_oracle(solver, m1, m2, N, n, strip):
+    """fp32 state + discrete dividends: on dividend steps the state is widened, the jump (device_solver.hpp:448-504) runs
+    on the fp64 packed array, and the result is rounded again -- the oracle does the same."""
+    strikes = Cm.strikes_for(n)
+    grids, U0 = _batch(m1, m2, strikes)
+    U = U0.copy()
+    solver.set_tuning("strip", strip)
+    try:
+        solver.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U,
+                               variant=H.DIV, dividends=H.Dividends(*Cm.DIVS), state_precision=H.STATE_FP32)
+    finally:
+        solver.set_tuning("strip", -1)
+    assert "float" in solver.describe_last_sweep()
+    p = O.make_params(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, O.DIV, Cm.DIVS, state_fp32=1)
+    Uo, _, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0)
+    _assert_field(U, Uo, rtol=2e-7 * N)
+
+
+def test_fp32_state_price_error_is_1e_6_to_1e_5(solver):
+    """What the fp32 state costs: every step rounds U and the A2 right-hand side to 24 bits (6e-8 relative); the
+    perturbations add up like a random walk, damped by the diffusion.  Price difference to the fp64 sweep on the 512x256
+    grid for N = 125 .. 2000 (T = 1): one realisation per N, erratic, between 1e-7 and 1.3e-5 (observed 1.3e-5, 3.5e-6,
+    2.1e-6, 1.1e-7, 1.0e-5) -- this mode does NOT guarantee a 1e-6 price tolerance (hadi.h says so)."""
+    m1, m2, K = 512, 256, 100.0
+    Ns = [125, 250, 500, 1000, 2000]
+    grids = H.GridViewsBatch([H.Grid(m1, 8 * K, Cm.S_0, K, K / 5, m2, 5.0, Cm.V_0, 5.0 / 500)] * len(Ns))
+    U0 = grids.call_payoff([K] * len(Ns))
+    per = {"N_i": Ns, "delta_t_i": [Cm.T / N for N in Ns]}
+    out = []
+    for prec in (H.STATE_FP64, H.STATE_FP32):
+        U = U0.copy()
+        solver.DO_timestepping(m1, m2, 1, 1.0, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U,
+                               per_instance=per, state_precision=prec)
+        out.append(U.copy())
+    node = 181 + 78 * (m1 + 1)
+    err = np.abs(out[1][:, node] - out[0][:, node])
+    print("fp32-state price error vs N:", dict(zip(Ns, err)))
+    assert abs(out[0][3, node] - 8.8942192888223310) < 1e-9
+    assert err.max() < 5e-5 and err.max() > 1e-6
+    field = np.abs(out[1] - out[0]).max(axis=1) / np.abs(out[0]).max(axis=1)
+    assert field.max() < 2e-6
+
+
 def test_fp32_state_restrictions(solver):
     m1, m2, N = 64, 32, 4
     grids, U0 = _batch(m1, m2, [100.0])
