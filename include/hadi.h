@@ -74,9 +74,9 @@ enum hadi_scheme { HADI_SCHEME_DOUGLAS = 0, HADI_SCHEME_CRAIG_SNEYD = 1 };
  * evaluated in fp64 in registers.  European Douglas sweeps (HADI_EU, HADI_DIV) only; the caller's arrays stay fp64.
  * Not a reference feature: parity is against the oracle run with the same two roundings per step (tests).  Each rounding
  * perturbs the state by 2^-24 relative and the perturbations add up like a random walk over the steps: against the
- * fp64 sweep the field moves by up to ~1e-6 relative and the price by 1e-7 .. 1.5e-5 (erratic in N: one realisation of
- * the walk per run; 1.5e-5 at 1024x512x2000) -- a throughput mode for users who accept that; it does NOT guarantee a 1e-6
- * price tolerance. */
+ * fp64 sweep the price moves by 1e-7 .. 1.5e-5 (erratic in N: one realisation of the walk per run; 1.5e-5 at
+ * 1024x512x2000) and the field by up to 1.4e-5 of max|U| at N = 2000 (increments below half an fp32 ulp are absorbed by
+ * the rounding) -- a throughput mode for users who accept that; it does NOT guarantee a 1e-6 price tolerance. */
 enum hadi_state_precision { HADI_STATE_FP64 = 0, HADI_STATE_FP32 = 1 };
 /* Boundary data of the option type.  HADI_CALL is the reference's only boundary class (call-specific,
  * src/BoundaryConditions.hpp:7-12, hes_boundary_kernels.hpp:41-75).  HADI_PUT is NOT a reference feature (README.md:26

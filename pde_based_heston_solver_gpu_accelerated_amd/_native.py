@@ -73,13 +73,25 @@ EXPORTS = [
 ]
 
 _lib = None
+_others = {}
 
 
-def lib():
-    """Loads libhadi.so; raises if it has not been built (python __graft_entry__.py build)."""
+def lib(path=None):
+    """Loads libhadi.so; raises if it has not been built (python __graft_entry__.py build).  `path`: another build of
+    the same ABI (tests load the checking build libhadi_strict.so next to the product)."""
     global _lib
+    if path is not None and os.path.abspath(path) != os.path.abspath(LIB_PATH):
+        key = os.path.abspath(path)
+        if key not in _others:
+            _others[key] = _load(key)
+        return _others[key]
     if _lib is not None:
         return _lib
+    _lib = _load(LIB_PATH)
+    return _lib
+
+
+def _load(LIB_PATH):
     if not os.path.exists(LIB_PATH):
         raise HadiError(-1, "libhadi.so not built at %s -- run `python __graft_entry__.py` (hipcc, gfx950); "
                             "this package has no CPU fallback" % LIB_PATH)
@@ -123,5 +135,4 @@ def lib():
     L.hadi_lm_partials.argtypes = [C.c_int, _dp, _dp, _dp]
     L.hadi_lm_solve.argtypes = [_dp, C.c_double, _dp]
     L.hadi_compute_parameter_update.argtypes = [C.c_int, _dp, _dp, C.c_double, _dp]
-    _lib = L
     return L

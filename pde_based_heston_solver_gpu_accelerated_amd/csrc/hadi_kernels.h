@@ -794,7 +794,14 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
 
 // Counted wait: at most `n` of this wavefront's youngest vector-memory operations may still be in flight.
 HADI_DEV HADI_FORCEINLINE void hadi_wait_vmcnt(int n) {
-#if !defined(HADI_EMU)
+#if defined(HADI_STRICT_VMCNT) && !defined(HADI_EMU)
+    // Checking build (libhadi_strict.so, tests only): every counted wait becomes a full drain.  The counted waits rest on
+    // hand-kept instruction counts (DMA pieces per row, stores per row); if a compiler change ever broke that bookkeeping
+    // the product build would read stale ring rows while this build stays right -- tests/test_gpu_parity.py compares the
+    // two bit for bit on every strip / ring shape.
+    (void)n;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#elif !defined(HADI_EMU)
     switch (n) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;

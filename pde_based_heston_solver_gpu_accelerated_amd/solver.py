@@ -72,8 +72,8 @@ class DOWorkspace:
 class HestonADI:
     """One library handle = one GPU + one HIP stream (the reference's single Kokkos device)."""
 
-    def __init__(self, device_id=0):
-        self._lib = nat.lib()
+    def __init__(self, device_id=0, lib_path=None):
+        self._lib = nat.lib(lib_path)
         h = C.c_void_p()
         rc = self._lib.hadi_create(C.byref(h), int(device_id))
         if rc != nat.HADI_OK:
