@@ -272,6 +272,7 @@ extern "C" int emu_tables(int m1, int m2, int N, double dt, double theta, double
     in.vec_s = vec_s; in.vec_v = vec_v; in.delta_s = delta_s; in.delta_v = delta_v;
     in.r_d = r_d; in.r_f = r_f; in.rho = rho; in.sigma = sigma; in.kappa = kappa; in.eta = eta;
     in.theta = theta; in.dt = dt; in.N = N;
+    in.put = 0; in.strike = 0.0;
     std::vector<double> rwork(pl.n_rwork);
     HadiInstPar ip;
     HadiTables t;

@@ -108,9 +108,9 @@ def test_put_boundary_data(emu):
     # small-grid kernel, dividends (ex-dividend spot <= 0 takes the s = 0 value), American projection, two waves per row
     _run(emu, 40, 12, 3, [90.0, 110.0], O.EU, 8, put=True)
     _run(emu, 40, 12, 4, [100.0], O.AM_DIV, 8, small=1, put=True)
-    _run(emu, 200, 60, 12, [100.0], O.AM_DIV, 8, put=True)
+    _run(emu, 200, 40, 6, [100.0], O.AM_DIV, 8, put=True)
     _run(emu, 600, 12, 2, [100.0], O.EU, 8, put=True)
-    _run(emu, 200, 60, 12, [100.0], O.AM_DIV, 8, scheme=3, put=True)  # P representation
+    _run(emu, 200, 40, 6, [100.0], O.AM_DIV, 8, scheme=3, put=True)  # P representation
 
 
 def test_more_v_nodes_than_s_nodes(emu):
@@ -134,14 +134,14 @@ def test_american_p_representation(emu):
     # one node per lane, 4 nodes per lane with dividends (explicit steps in between), two wavefronts per row,
     # the single-buffer column pass
     _run(emu, 40, 12, 4, [100.0, 92.0], O.AM, 4, r_f=0.01, scheme=3)
-    _run(emu, 200, 60, 12, [100.0], O.AM_DIV, 8, scheme=3)
+    _run(emu, 200, 60, 7, [100.0], O.AM_DIV, 8, scheme=3)
     _run(emu, 530, 10, 3, [100.0], O.AM, 8, scheme=3)
     _run(emu, 280, 265, 2, [97.0], O.AM, 1, scheme=3)
     # batches large enough for the strip row pass: 8 nodes per lane (payoff row in LDS), with dividend steps in between,
     # and 4-strip blocks at 2 nodes per lane
     _run(emu, 300, 150, 3, [100.0], O.AM, 1, r_f=0.01, scheme=3)
-    _run(emu, 300, 140, 12, [95.0], O.AM_DIV, 1, scheme=3)
-    _run(emu, 100, 70, 3, [100.0, 95.0, 105.0, 90.0], O.AM, 1, scheme=3)
+    _run(emu, 300, 140, 6, [95.0], O.AM_DIV, 1, scheme=3)
+    _run(emu, 100, 70, 3, [100.0, 95.0], O.AM, 1, scheme=3)
 
 
 def test_two_waves_per_row_split_solve(emu):
