@@ -76,12 +76,22 @@ struct Dividends {  // device_solver.hpp:409-413
     std::vector<double> dates, amounts, percentages;
 };
 
+// Put boundary data (hadi.h, enum hadi_option_type) -- NOT in the reference, whose only boundary class is call-specific
+// (BoundaryConditions.hpp:7-12).  Passing the strikes as the optional last argument of a launcher below switches the batch
+// to the put's boundary values; the caller supplies the put payoff in workspace.U / U_0 as usual.
+using PutStrikes = std::vector<double>;
+
 namespace detail {
 inline hadi_problem make(int variant, int n, int m1, int m2, int N, double delta_t, double theta, double r_d, double r_f,
                          double rho, double sigma, double kappa, double eta, const GridViews &g, double *U,
-                         const double *U_0, const Dividends *div) {
+                         const double *U_0, const Dividends *div, const PutStrikes *put = nullptr) {
     if (g.nInstances != n || g.m1 != m1 || g.m2 != m2) throw std::runtime_error("grid batch does not match (n, m1, m2)");
     hadi_problem p{};
+    if (put) {
+        if ((int)put->size() != n) throw std::runtime_error("put strikes do not match the batch");
+        p.option_type = HADI_PUT;
+        p.strike_i = put->data();
+    }
     p.n_instances = n; p.m1 = m1; p.m2 = m2; p.variant = variant; p.memspace = HADI_MEM_HOST;
     p.N = N; p.delta_t = delta_t; p.theta = theta;
     p.r_d = r_d; p.r_f = r_f; p.rho = rho; p.sigma = sigma; p.kappa = kappa; p.eta = eta;
@@ -102,10 +112,11 @@ inline void check(const Handle &h, int rc) {
 // device_solver.hpp:52-185 (S_0, V_0 are doubles here; the reference declares them int, :56-57)
 inline void parallel_DO_solve(Handle &h, int nInstances, double S_0, double V_0, int m1, int m2, int N, double /*T*/,
                               double delta_t, double theta, double r_d, double r_f, double rho, double sigma, double kappa,
-                              double eta, const GridViews &deviceGrids, DO_Workspace &workspace, std::vector<double> &base_prices) {
+                              double eta, const GridViews &deviceGrids, DO_Workspace &workspace, std::vector<double> &base_prices,
+                              const PutStrikes *put = nullptr) {
     base_prices.resize(nInstances);
     hadi_problem p = detail::make(HADI_EU, nInstances, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, deviceGrids,
-                                  workspace.U.data(), nullptr, nullptr);
+                                  workspace.U.data(), nullptr, nullptr, put);
     detail::check(h, hadi_parallel_DO_solve(h.ctx, &p, S_0, V_0, base_prices.data()));
 }
 
@@ -145,10 +156,10 @@ inline void compute_base_prices_american_dividends(Handle &h, double S_0, double
                                                    int N, double theta, double delta_t, int num_strikes,
                                                    const GridViews &deviceGrids, const std::vector<double> &U_0,
                                                    DO_Workspace &workspace, const Dividends &div,
-                                                   std::vector<double> &base_prices) {
+                                                   std::vector<double> &base_prices, const PutStrikes *put = nullptr) {
     base_prices.resize(num_strikes);
     hadi_problem p = detail::make(HADI_AM_DIV, num_strikes, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta,
-                                  deviceGrids, workspace.U.data(), U_0.data(), &div);
+                                  deviceGrids, workspace.U.data(), U_0.data(), &div, put);
     p.lambda_bar = workspace.lambda_bar.data();
     detail::check(h, hadi_compute_base_prices_american_dividends(h.ctx, &p, S_0, V_0, base_prices.data()));
 }

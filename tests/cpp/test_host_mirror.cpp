@@ -63,6 +63,27 @@ int main() {
                                                delta_t, nInstances, grids, U_0, workspace, div, base_prices);
         expect("compute_base_prices_american_dividends K=100", base_prices[15], 5.4303035460631257, 1e-9);
         expect("compute_base_prices_american_dividends K=95", base_prices[10], 8.5105730742666701, 1e-9);
+        // ---- put boundary data (extension, hadi.h): European put-call parity against the discrete discount factor of
+        // the Douglas step, and the American put with dividends (BASELINE config 3's option type) above the European one
+        std::vector<double> call = base_prices, P_0((size_t)nInstances * total_size);
+        workspace.U = U_0;
+        parallel_DO_solve(h, nInstances, S_0, V_0, m1, m2, N, T, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids, workspace, call);
+        for (int i = 0; i < nInstances; ++i)
+            for (int j = 0; j <= m2; j++)
+                for (int k = 0; k <= m1; k++)
+                    P_0[(size_t)i * total_size + k + j * (m1 + 1)] = std::max(strikes[i] - grids.Vec_s[(size_t)i * (m1 + 1) + k], 0.0);
+        std::vector<double> put, amput;
+        workspace.U = P_0;
+        parallel_DO_solve(h, nInstances, S_0, V_0, m1, m2, N, T, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids, workspace, put,
+                          &strikes);
+        const double hr = 0.5 * r_d * theta * delta_t;
+        const double g = ((1 - delta_t * r_d + hr) / (1 + hr) + hr) / (1 + hr);
+        expect("put-call parity K=100 (discrete forward)", call[15] - put[15], S_0 - 100.0 * std::pow(g, N), 3e-6);
+        workspace.U = P_0;
+        compute_base_prices_american_dividends(h, S_0, V_0, T, r_d, r_f, rho, sigma, kappa, eta, m1, m2, total_size, N, theta,
+                                               delta_t, nInstances, grids, P_0, workspace, div, amput, &strikes);
+        expect("American put with dividends >= payoff K=104", std::min(amput[19] - (104.0 - S_0), 0.0), 0.0, 0.0);
+        expect("American put with dividends > European put K=100", (amput[15] > put[15]) ? 1.0 : 0.0, 1.0, 0.0);
     }
     {   // ---- Jacobian row of test_jacobian_method ----
         const int m1 = 25, m2 = 20, num_strikes = 5, N = 20, total_size = (m1 + 1) * (m2 + 1);
