@@ -89,15 +89,34 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
         p.RS = (L.nrows + nwv * p.sblocks - 1) / (nwv * p.sblocks);
         p.grid_as = (int)(((long long)n_inst * p.sblocks + 7) / 8 * 8);
         p.smem_as = ((size_t)nwv * 4 * L.rowp + (size_t)4 * 64 * L.B) * sizeof(double);
-        // 8 nodes per lane: measured on MI355X, 512x256 x256: 0.156 -> 0.141 ms/launch when introduced (0.110 now).
         // hadi_set_tuning("strip", 1) forces strips wherever the geometry allows them (tests).
-        // One strip block occupies a CU: the launch runs in ceil(blocks / CUs) rounds.  When the last round is mostly
-        // empty (e.g. 160 instances -> 320 blocks on 256 CUs) the shared-ring kernel, whose small blocks fill the tail,
-        // is faster (measured: 160 instances 0.142 ms with strips, ~0.127 ms with the ring).
         const int cus = target_waves / 8 > 0 ? target_waves / 8 : 1;
+        p.use_strip = 0;
+        if (L.B == 8) {
+            // One strip block occupies a CU, so the launch runs in ceil(blocks / CUs) ROUNDS of RS row steps each plus a
+            // fixed cost per round (prologue, 4 halo rows, tail): measured 0.110 / 0.065 / 0.042 ms per round at RS = 33 /
+            // 17 / 11, i.e. ~ (RS + 6) x 2.8 us.  Pick the number of blocks per instance that minimises rounds x (RS + 6):
+            // 64 instances -> 3 blocks of 11-row strips (0.053 -> 0.042 ms per launch), 160 -> 3 blocks (2 rounds instead
+            // of a 320-block launch whose second round is a quarter full), 256 -> 1 block of 33-row strips.  The shared
+            // ring (small blocks, ~2.3 ns per row of the batch + 12 us) keeps the batches too small to fill the CUs.
+            int best_sb = 0;
+            double best_cost = 0.0;
+            for (int sb = 1; sb <= 6; sb++) {
+                const int rs = (L.nrows + nwv * sb - 1) / (nwv * sb);
+                if (rs < 8 || rs > 64) continue;
+                const long long blocks = (long long)n_inst * sb, rounds = (blocks + cus - 1) / cus;
+                const double cost = (double)rounds * (rs + 6);
+                if (!best_sb || cost < best_cost - 1e-9) { best_sb = sb; best_cost = cost; }
+            }
+            if (best_sb) {
+                const double t_strip = best_cost * 2.8e-3, t_ring = 2.33e-6 * (double)n_inst * L.nrows + 0.012;  // ms
+                p.sblocks = best_sb;
+                p.RS = (L.nrows + nwv * best_sb - 1) / (nwv * best_sb);
+                p.grid_as = (int)(((long long)n_inst * p.sblocks + 7) / 8 * 8);
+                p.use_strip = (t_strip < t_ring) ? 1 : 0;
+            }
+        }
         const long long sblk = (long long)n_inst * p.sblocks;
-        const double fill = (double)sblk / (double)(((sblk + cus - 1) / cus) * cus);
-        p.use_strip = (L.B == 8 && p.RS >= 16 && p.RS <= 64 && fill >= 0.7) ? 1 : 0;
         // 2 nodes per lane (64 < m1 <= 128), batches of several blocks per CU: 4-strip blocks beat the shared ring
         // (128x64 x2000: 0.130 -> 0.108 ms per launch); at 4 nodes per lane the two are level (0.165 vs 0.167).
         if (L.B == 2 && p.RS >= 16 && p.RS <= 64 && sblk >= 4 * (long long)cus) p.use_strip = 1;

@@ -193,7 +193,7 @@ def test_plan_invariants_over_shapes_and_batch_sizes(emu):
                 else:
                     assert not use_strip
                 if use_strip:
-                    assert B in (2, 4, 8) and 16 <= RS <= 64
+                    assert B in (2, 4, 8) and (8 if B == 8 else 16) <= RS <= 64
                     seen_strip.add(B)
                 assert btpw * bgroups >= ctiles and (btpw - 1) * bgroups < ctiles + bgroups and ctiles * 64 >= rowp
                 assert grid_b == (n * bgroups + 7) // 8 * 8 and smem_b <= LDS and P <= 16
