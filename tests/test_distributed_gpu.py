@@ -62,3 +62,14 @@ def test_bench_refuses_gloo_for_a_multi_gpu_number():
     rec = json.loads(lines[-1])
     assert rec["n_gpus"] == 2 and rec["config"]["timing_collective"].startswith("gloo") and rec["value"] > 0
     assert rec["scaling"] == "strong" and rec["config"]["instances_total"] == 500
+
+
+def test_rccl_process_group_set_up_with_one_rank():
+    """bench.py's process-group set-up over RCCL (gloo default group for the vote, `nccl` sub-group for the collectives of the
+    timed region) and the Communicator on it -- all-reduce of the 31 doubles as a CUDA tensor, all-gather, barrier -- with the
+    one rank a one-GPU box can host.  (Two RCCL ranks need two GPUs: the driver's scaling run is the first place they meet.)"""
+    env = dict(os.environ, MASTER_PORT="29637", MASTER_ADDR="127.0.0.1", RANK="0", WORLD_SIZE="1")
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "nccl_probe.py")], capture_output=True,
+                         text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "nccl probe ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "collective: nccl" in out.stdout and "communicator device: cuda:0" in out.stdout
