@@ -242,7 +242,8 @@ hipError_t raise_all_lds_limits() {
 }
 
 int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
-    if (hadi_make_plan(d.m1, d.m2, d.n, 8 * c->cu_count, &pl, c->tune))
+    const int state_bytes = d.prec == HADI_STATE_FP32 ? 4 : 8;
+    if (hadi_make_plan(d.m1, d.m2, d.n, 8 * c->cu_count, &pl, c->tune, state_bytes))
         return fail(c, HADI_ERR_UNSUPPORTED, "grid %dx%d not supported (need 2 <= m1 <= 1024, 3 <= m2 <= %d)", d.m1, d.m2,
                     HADI_MAX_P * HADI_LC - 1);
     // Large batches on grids where ONE round of the one-block-per-CU kernels (cu_count instances) already moves more than
@@ -253,7 +254,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     if (d.scheme == HADI_SCHEME_DOUGLAS && !d.debug && c->sub_batch && d.n > c->cu_count && d.n % c->cu_count == 0 &&
         2ll * c->cu_count * pl.L.inst_stride * (long long)sizeof(double) >= (256ll << 20)) {
         nsub = d.n / c->cu_count;
-        if (hadi_make_plan(d.m1, d.m2, d.n / nsub, 8 * c->cu_count, &pl, c->tune)) return fail(c, HADI_ERR_UNSUPPORTED, "plan failed");
+        if (hadi_make_plan(d.m1, d.m2, d.n / nsub, 8 * c->cu_count, &pl, c->tune, state_bytes)) return fail(c, HADI_ERR_UNSUPPORTED, "plan failed");
     }
     const int nsb = d.n / nsub;
     if (!(d.theta > 0.0)) pl.use_strip = 0;  // the strip kernel scales the A1 action by (1 - theta) / theta
@@ -736,7 +737,8 @@ int check_problem(Ctx *c, const hadi_problem *p, bool need_U, bool need_vgrid) {
     if (p->V_0_i && need_vgrid) return fail(c, HADI_ERR_INVALID, "V_0_i applies to hadi_compute_base_prices* / hadi_compute_jacobian* only");
     {  // grid shape, before anything is staged
         HadiPlan tmp;
-        if (p->m1 < 2 || p->m2 < 3 || hadi_make_plan(p->m1, p->m2, p->n_instances, 8 * c->cu_count, &tmp, c->tune))
+        if (p->m1 < 2 || p->m2 < 3 ||
+            hadi_make_plan(p->m1, p->m2, p->n_instances, 8 * c->cu_count, &tmp, c->tune, p->state_precision == HADI_STATE_FP32 ? 4 : 8))
             return fail(c, HADI_ERR_UNSUPPORTED, "grid %dx%d not supported (need 2 <= m1 <= 1024, 3 <= m2 <= %d)", p->m1, p->m2,
                         HADI_MAX_P * HADI_LC - 1);
     }

@@ -341,7 +341,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_to_lds(const T *__restrict__ grow, T *lr
 // partial piece, fully unrolled -- no loop counters, compares or exec-mask juggling in the row loop.
 template <int B, class T, int G = 1>
 HADI_DEV HADI_FORCEINLINE void hadi_row_to_lds_fixed(const T *__restrict__ grow, T *lrow, int lane, bool exists) {
-    constexpr int EPV = 16 / (int)sizeof(T), ROWP = 64 * B * G + 8, NVEC = ROWP / EPV, NFULL = NVEC / 64, REM = NVEC - 64 * NFULL;
+    constexpr int EPV = 16 / (int)sizeof(T), ROWP = 64 * B * G + HADI_ROW_PAD(B, (int)sizeof(T)), NVEC = ROWP / EPV, NFULL = NVEC / 64, REM = NVEC - 64 * NFULL;
     static_assert(ROWP % EPV == 0, "row pitch must be a whole number of 16-byte vectors");
     if (exists) {
 #if defined(HADI_EMU)
@@ -933,7 +933,7 @@ __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : B == 4 ? HADI_R
     // fetch returns the number of vector-memory instructions it issued
     auto fetch = [&](int jj) -> int {
         const bool exists = jj >= 0 && jj < npad;
-        if constexpr ((64 * B * G + 8) % (16 / (int)sizeof(T)) == 0)
+        if constexpr ((64 * B * G + HADI_ROW_PAD(B, (int)sizeof(T))) % (16 / (int)sizeof(T)) == 0)
             hadi_row_to_lds_fixed<B, T, G>(Ub + (ptrdiff_t)jj * rowp, slot(jj), lane, exists);
         else
             hadi_row_to_lds(Ub + (size_t)jj * rowp, slot(jj), rowp, lane, exists);

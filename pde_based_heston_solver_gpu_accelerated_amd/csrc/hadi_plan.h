@@ -36,14 +36,16 @@ struct HadiTuning {
 };
 
 // Returns 0 on success, 1 if the shape is outside what the kernels cover.
-inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan *out, const HadiTuning &tu = HadiTuning()) {
+// state_bytes: element size of the state arrays the sweep streams (8; 4 for the fp32-state sweep) -- it decides the row pitch.
+inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan *out, const HadiTuning &tu = HadiTuning(),
+                          int state_bytes = 8) {
     if (m1 < 2 || m2 < 3 || n_inst < 1) return 1;
     if (m1 > 1024) return 1;         // row pass: 2 waves x 64 lanes x 8 nodes
     HadiPlan p;
     HadiLayout &L = p.L;
     L.m1 = m1; L.m2 = m2; L.nrows = m2 + 1;
     hadi_pick_shape(m1, &L.B, &L.G);
-    L.rowp = 64 * L.B * L.G + 8;
+    L.rowp = 64 * L.B * L.G + HADI_ROW_PAD(L.B, state_bytes);
     L.P = (L.nrows + HADI_LC - 1) / HADI_LC;
     if (L.P > HADI_MAX_P) return 1;
     L.nrows_pad = L.P * HADI_LC;

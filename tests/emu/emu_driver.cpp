@@ -148,7 +148,7 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
                          const double *damounts, const double *dpcts, int setup_threads, int use_small, int scheme,
                          const double *put_strikes /* NULL = call boundary data */) {
     HadiPlan pl;
-    if (hadi_make_plan(m1, m2, n_inst, target_waves, &pl, g_tune)) return 1;
+    if (hadi_make_plan(m1, m2, n_inst, target_waves, &pl, g_tune, scheme == 2 ? 4 : 8)) return 1;
     const HadiLayout &L = pl.L;
     const int american = variant & 1, dividend = (variant >> 1) & 1;
     const size_t st = (size_t)L.inst_stride * n_inst;

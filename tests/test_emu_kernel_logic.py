@@ -183,7 +183,7 @@ def test_plan_invariants_over_shapes_and_batch_sizes(emu):
                 (B, G, rowp, P, nrows, npad, stride, W, NG, PD, R, ntiles, grid_a, smem_a, use_strip, RS, sblocks, grid_as,
                  smem_as, ctiles, btpw, bgroups, grid_b, smem_b) = list(o)
                 assert nrows == m2 + 1 and npad == 33 * P and npad >= nrows and stride == rowp * npad
-                assert 64 * B * G >= m1 and rowp == 64 * B * G + 8 and B in (1, 2, 4, 8) and G in (1, 2)
+                assert 64 * B * G >= m1 and rowp == 64 * B * G + (16 if B >= 4 else 8) and B in (1, 2, 4, 8) and G in (1, 2)
                 assert R % W == 0 and R * ntiles >= nrows and grid_a * NG >= n * ntiles
                 assert smem_a + rowp * 8 <= LDS
                 nwv = 8 if B == 8 else 4
