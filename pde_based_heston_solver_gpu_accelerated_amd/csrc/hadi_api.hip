@@ -248,16 +248,30 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                     HADI_MAX_P * HADI_LC - 1);
     // Large batches on grids where ONE round of the one-block-per-CU kernels (cu_count instances) already moves more than
     // the 256 MB memory-side cache holds: the two passes of a step then re-use each other's data only while the batch is
-    // one round deep (measured at 512x256: 512 instances at once ran the column pass 6 % slower per instance than 256).
-    // Instances are independent, so the time loop runs sub-batch by sub-batch, each with the one-round geometry.
-    int nsub = 1;
-    if (d.scheme == HADI_SCHEME_DOUGLAS && !d.debug && c->sub_batch && d.n > c->cu_count && d.n % c->cu_count == 0 &&
+    // one round deep (measured at 512x256: 512 instances at once ran the column pass 6 % slower per instance than 256;
+    // 384 at once: 0.188 + 0.205 ms per step against 0.173 + 0.177 as 256 + 128).  Instances are independent, so the time
+    // loop runs sub-batch by sub-batch -- whole rounds of cu_count instances plus the remainder (a remainder below a
+    // quarter round rides with the last full round) -- each with the launch geometry of its own size.
+    struct SubBatch { int off, cnt; HadiPlan pl; };
+    std::vector<SubBatch> subs;
+    if (d.scheme == HADI_SCHEME_DOUGLAS && !d.debug && c->sub_batch && d.n > c->cu_count &&
         2ll * c->cu_count * pl.L.inst_stride * (long long)sizeof(double) >= (256ll << 20)) {
-        nsub = d.n / c->cu_count;
-        if (hadi_make_plan(d.m1, d.m2, d.n / nsub, 8 * c->cu_count, &pl, c->tune, state_bytes)) return fail(c, HADI_ERR_UNSUPPORTED, "plan failed");
+        const int cu = c->cu_count, full = d.n / cu, rem = d.n - full * cu;
+        for (int k = 0; k < full; k++) subs.push_back(SubBatch{k * cu, cu, pl});
+        if (rem >= cu / 4) subs.push_back(SubBatch{full * cu, rem, pl});
+        else subs.back().cnt += rem;
+        for (auto &sbt : subs)
+            if (hadi_make_plan(d.m1, d.m2, sbt.cnt, 8 * c->cu_count, &sbt.pl, c->tune, state_bytes))
+                return fail(c, HADI_ERR_UNSUPPORTED, "plan failed");
+        pl = subs[0].pl;  // (what the caller sees: layout and table sizes are the same for every sub-batch)
+    } else {
+        subs.push_back(SubBatch{0, d.n, pl});
     }
-    const int nsb = d.n / nsub;
-    if (!(d.theta > 0.0)) pl.use_strip = 0;  // the strip kernel scales the A1 action by (1 - theta) / theta
+    const int nsub = (int)subs.size();
+    if (!(d.theta > 0.0)) {  // the strip kernel scales the A1 action by (1 - theta) / theta
+        pl.use_strip = 0;
+        for (auto &sbt : subs) sbt.pl.use_strip = 0;
+    }
     const HadiLayout &L = pl.L;
     const bool american = d.variant == HADI_AM || d.variant == HADI_AM_DIV;
     const bool dividend = d.variant == HADI_DIV || d.variant == HADI_AM_DIV;
@@ -364,7 +378,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     a.pay_mis = american ? ptr<int>(c->pay_mis) : nullptr;
     a.scoef = ptr<double>(c->scoef); a.b2row = ptr<double>(c->b2row); a.rowc = ptr<double>(c->rowc);
     a.pb = ptr<double>(c->pb); a.rinv = ptr<double>(c->rinv); a.ipar = ptr<HadiInstPar>(c->ipar);
-    a.L = L; a.n_inst = nsb; a.R = pl.R; a.ntiles = pl.ntiles; a.ctiles = pl.ctiles; a.btpw = pl.btpw; a.bgroups = pl.bgroups;
+    a.L = L; a.n_inst = d.n; a.R = pl.R; a.ntiles = pl.ntiles; a.ctiles = pl.ctiles; a.btpw = pl.btpw; a.bgroups = pl.bgroups;
     a.american = american ? 1 : 0; a.pos_m1 = pl.pos_m1;
     a.RS = pl.RS; a.sblocks = pl.sblocks;
     a.R1 = cs ? ptr<double>(c->R1) : nullptr;
@@ -384,7 +398,9 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     }
     // The whole time loop as a function of the stream, so it can be enqueued directly or captured.
     // Instance offset `o` applied to every per-instance array of the sweep arguments (sub-batches, see nsub above).
-    auto shift = [&](HadiSweepArgs x, int o) {
+    auto shift = [&](HadiSweepArgs x, int o, int cnt, const HadiPlan &sp) {
+        x.n_inst = cnt; x.R = sp.R; x.ntiles = sp.ntiles; x.ctiles = sp.ctiles; x.btpw = sp.btpw; x.bgroups = sp.bgroups;
+        x.RS = sp.RS; x.sblocks = sp.sblocks;
         const size_t so = (size_t)o * L.inst_stride;
         if (f32) {
             x.U = reinterpret_cast<double *>(reinterpret_cast<float *>(x.U) + so);
@@ -406,9 +422,10 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     auto enqueue_loop = [&](hipStream_t q) -> int {
       const int n_first = d.debug ? d.debug_step : 1, n_last = d.debug ? d.debug_step : d.Nmax;
       for (int sb = 0; sb < nsub; sb++) {  // one sub-batch after the other, each through its whole time loop
-        const int o = sb * nsb;
+        const int o = subs[sb].off, nsb = subs[sb].cnt;
+        const HadiPlan &pl = subs[sb].pl;  // (shadows the whole-batch plan: launch geometry of THIS sub-batch)
         const size_t so = (size_t)o * L.inst_stride;
-        const HadiSweepArgs a = shift(a_all, o), av = shift(av_all, o);
+        const HadiSweepArgs a = shift(a_all, o, nsb, pl), av = shift(av_all, o, nsb, pl);
         const size_t tot = (size_t)L.inst_stride * nsb, st = tot * sizeof(double);  // (shadow the whole-batch sizes)
         double *const Ub = ptr<double>(c->U) + so, *const LAMb = american ? ptr<double>(c->LAM) + so : nullptr;
         double *const U0b = american ? ptr<double>(c->U0) + so : nullptr, *const UTb = dividend ? ptr<double>(c->UT) + so : nullptr;
@@ -601,7 +618,16 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         std::snprintf(buf, sizeof buf, "row pass %s; column pass %s<%d,%s> (%d chunks of %d rows, %d column tiles per block)", rowk,
                       L.P <= 8 ? "hadi_pass_b" : "hadi_pass_b1", L.P <= 8 ? 8 : 16, amp ? "AM-P" : american ? "AM" : "EU", L.P, HADI_LC, pl.btpw);
         c->last_path = buf;
-        if (nsub > 1) c->last_path += "; " + std::to_string(nsub) + " sub-batches of " + std::to_string(nsb) + " instances";
+        if (nsub > 1) {
+            bool same = true;
+            for (auto &sbt : subs) same = same && sbt.cnt == subs[0].cnt;
+            if (same) c->last_path += "; " + std::to_string(nsub) + " sub-batches of " + std::to_string(subs[0].cnt) + " instances";
+            else {
+                c->last_path += "; " + std::to_string(nsub) + " sub-batches of";
+                for (auto &sbt : subs) c->last_path += " " + std::to_string(sbt.cnt);
+                c->last_path += " instances (each with the geometry of its own size)";
+            }
+        }
     }
     c->last_nsub = nsub;
     HIP_TRY(c, hipEventRecord(c->ev[1], s));

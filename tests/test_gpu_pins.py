@@ -181,6 +181,33 @@ def test_headline_batch_geometry_field_vs_oracle(solver, n):
     assert errs.max() < FIELD_RTOL, (errs.argmax(), errs.max())
 
 
+@pytest.mark.parametrize("n,label", [(384, "2 sub-batches of 256 128 instances"), (600, "3 sub-batches of 256 256 88 instances"),
+                                     (300, "")])
+def test_unequal_sub_batches_vs_oracle(solver, n, label):
+    """Whole rounds of one instance per CU plus the remainder (a remainder below a quarter round rides with the last full
+    round: 300 stays one launch), each sub-batch with the launch geometry of its own size: fields of the first, last and
+    boundary instances against the oracle, and equal to the single-launch run to round-off (not bit for bit: strips that
+    walk downwards add the v-neighbours in the opposite order, and the strip partition differs between the geometries)."""
+    m1, m2, N = 512, 256, 2
+    strikes = Cm.strikes_for(n)
+    grids, U0 = _batch(m1, m2, strikes)
+    U = U0.copy()
+    solver.DO_timestepping(m1, m2, N, Cm.T / 1000, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U)
+    d = solver.describe_last_sweep()
+    assert (label in d) if label else ("sub-batches" not in d), d
+    solver.set_tuning("sub_batch", 0)
+    try:
+        V = U0.copy()
+        solver.DO_timestepping(m1, m2, N, Cm.T / 1000, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, V)
+    finally:
+        solver.set_tuning("sub_batch", 1)
+    assert np.abs(U - V).max() <= 1e-12 * np.abs(V).max()
+    rows = np.array([0, 1, 255, 256, 257, n - 2, n - 1])
+    p = O.make_params(m1, m2, N, Cm.T / 1000, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, O.EU)
+    Uo, _, _ = O.solve_batch(p, grids.Vec_s[rows], grids.Vec_v[rows], grids.Delta_s[rows], grids.Delta_v[rows], U0[rows])
+    assert _field_err(U[rows], Uo) < FIELD_RTOL
+
+
 def test_sub_batches_do_not_change_results(solver):
     """512 instances of 512x256 run as two sub-batches of 256 (each round of one block per CU keeps its memory-side cache
     reuse); instances are independent, so the fields are bit-identical to the whole-batch launch, also for American
