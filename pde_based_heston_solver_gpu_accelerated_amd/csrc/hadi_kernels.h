@@ -404,7 +404,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_lds_row(const double *lrow, int lane, double
 template <class T>
 struct HadiRowCtxT {
     const double *coef;  // LDS: Bm, Bp, Dm, Dp, each 64*B*G doubles in row layout
-    double *xch;         // LDS: [W][4] boundary exchange between the two waves of a row (G = 2)
+    double *xch;         // LDS: [W][8] boundary exchange between the two waves of a row (G = 2): 4 values + 2 tokens
     T *Yi;               // instance base of Y (T = float: fp32-state sweep)
     const double *Li;    // instance base of lambda_bar (American)
     const double *rowc;  // LDS copy of the row table of this block's tile: entry (j - j0)
@@ -740,26 +740,45 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
             //   low half, lane 63:  x_hi = A - t*Bc              (A = Ysol, Bc = Ssol; x_hi = its own X)
             //   high half, lane 0:  t = C - x_hi*D   (t = its first node = ys0 - XL ps0 - X gs0, XL = x_hi)
             if (edge_hi) {
-                c.xch[4 * c.wrow + 0] = Ysol;
-                c.xch[4 * c.wrow + 1] = Ssol;
+                c.xch[8 * c.wrow + 0] = Ysol;
+                c.xch[8 * c.wrow + 1] = Ssol;
             }
             if (edge_lo) {
                 if constexpr (NB > 0) {
-                    c.xch[4 * c.wrow + 2] = ys[0] - Ysol * gs[0];
-                    c.xch[4 * c.wrow + 3] = ps[0] - Ssol * gs[0];
+                    c.xch[8 * c.wrow + 2] = ys[0] - Ysol * gs[0];
+                    c.xch[8 * c.wrow + 3] = ps[0] - Ssol * gs[0];
                 } else {
-                    c.xch[4 * c.wrow + 2] = Ysol;
-                    c.xch[4 * c.wrow + 3] = Ssol;
+                    c.xch[8 * c.wrow + 2] = Ysol;
+                    c.xch[8 * c.wrow + 3] = Ssol;
                 }
             }
         }
     }
-    if constexpr (G > 1) __syncthreads();
+    if constexpr (G > 1) {
+#if defined(HADI_EMU) || defined(HADI_BLOCK_EXCHANGE)
+        __syncthreads();
+#else
+        // Rendezvous of the TWO wavefronts of this v-row only (the other rows of the block run on): each publishes a token
+        // behind its two values (same lane, so the LDS unit sees data before flag) and polls the partner's.  Both are
+        // resident wavefronts of one block and `active` is the same for both, so the partner always arrives; the loop-top
+        // barrier of the next iteration separates this exchange from the next use of the slots.  The poll is bounded so
+        // that a logic error can never hang the GPU (it would fail parity instead).
+        if (active) {
+            int *flags = reinterpret_cast<int *>(c.xch + 8 * c.wrow + 4);
+            const int token = j + 1;
+            const bool publisher = (!last_half && lane == 63) || (!first_half && lane == 0);  // the lanes that wrote the values
+            if (publisher) __hip_atomic_store(flags + half, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            int guard = 0;
+            while (__hip_atomic_load(flags + (1 - half), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != token && ++guard < (1 << 22))
+                __builtin_amdgcn_s_sleep(1);
+        }
+#endif
+    }
     if (active) {
         double X = Ysol, XL;
         if constexpr (G > 1) {
-            const double A = c.xch[4 * c.wrow + 0], Bc = c.xch[4 * c.wrow + 1];
-            const double Cc = c.xch[4 * c.wrow + 2], Dd = c.xch[4 * c.wrow + 3];
+            const double A = c.xch[8 * c.wrow + 0], Bc = c.xch[8 * c.wrow + 1];
+            const double Cc = c.xch[8 * c.wrow + 2], Dd = c.xch[8 * c.wrow + 3];
             const double xhi = (A - Bc * Cc) / (1.0 - Bc * Dd);  // last node of the low half
             const double tlo = Cc - Dd * xhi;                    // first node of the high half
             X = Ysol - (first_half ? tlo : xhi) * Ssol;
@@ -897,7 +916,7 @@ __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : B == 4 ? HADI_R
         }
     }
 
-    // LDS: [NG rings of RING rows of T] [4 coefficient arrays of 64*B*G] [NG*W*4 exchange] [NG compact row tables]
+    // LDS: [NG rings of RING rows of T] [4 coefficient arrays of 64*B*G] [NG*W*8 exchange] [NG compact row tables]
     T *ring = reinterpret_cast<T *>(smem) + (size_t)grp * RING * rowp;
     double *coef = reinterpret_cast<double *>(reinterpret_cast<T *>(smem) + (size_t)NG * RING * rowp);
     {
@@ -905,16 +924,17 @@ __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : B == 4 ? HADI_R
         for (int e = threadIdx.x; e < 4 * 64 * B * G; e += NT) coef[e] = sc[e];
     }
     c.coef = coef;
-    c.xch = coef + 4 * 64 * B * G + grp * 4 * W;
+    c.xch = coef + 4 * 64 * B * G + grp * 8 * W;  // per v-row: 4 exchange values + the two rendezvous tokens
+    if (threadIdx.x < 8 * W * NG) coef[4 * 64 * B * G + threadIdx.x] = 0.0;  // (tokens start at 0; the first loop barrier publishes this)
     {
-        double *rtab = coef + 4 * 64 * B * G + NG * 4 * W + (size_t)grp * a.R * HADI_RCL;
+        double *rtab = coef + 4 * 64 * B * G + NG * 8 * W + (size_t)grp * a.R * HADI_RCL;
         const double *__restrict__ rg = a.rowc + ((size_t)inst * nrows + j0) * HADI_RC;
         const int tl = threadIdx.x - grp * 64 * W * G;
         for (int e = tl; e < (j1 - j0) * HADI_RCL; e += 64 * W * G) rtab[e] = rg[(e / HADI_RCL) * HADI_RC + e % HADI_RCL];
         c.rowc = rtab;
         c.payrow = nullptr; c.inv_dt = 0.0; c.m1_lane = -1; c.m1_r = -1;
         if constexpr (AMER == 2) {  // payoff row (v-row 0 of the packed payoff; it depends on s only) after the tables
-            double *prow = coef + 4 * 64 * B * G + NG * 4 * W + (size_t)NG * a.R * HADI_RCL;
+            double *prow = coef + 4 * 64 * B * G + NG * 8 * W + (size_t)NG * a.R * HADI_RCL;
             const double *__restrict__ pg = a.U0 + (size_t)inst * a.L.inst_stride;
             for (int e = threadIdx.x; e < rowp; e += NT) prow[e] = pg[e];
             c.payrow = prow;

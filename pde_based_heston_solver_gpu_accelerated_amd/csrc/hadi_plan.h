@@ -74,7 +74,7 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
     if (tu.row_tile > 0) { R = tu.row_tile; if (R < W) R = W; R = (R + W - 1) / W * W; if (R > Rmax) R = Rmax; ntiles = (L.nrows + R - 1) / R; }
     p.R = R;
     p.ntiles = ntiles;
-    p.smem_a = ((size_t)p.NG * ((p.PD + 1) * W + 4) * L.rowp + (size_t)4 * 64 * L.B * L.G + (size_t)p.NG * 4 * W +
+    p.smem_a = ((size_t)p.NG * ((p.PD + 1) * W + 4) * L.rowp + (size_t)4 * 64 * L.B * L.G + (size_t)p.NG * 8 * W +
                 (size_t)p.NG * R * HADI_RCL) * sizeof(double);
     const long long total = (long long)n_inst * ((ntiles + p.NG - 1) / p.NG);
     p.grid_a = (int)((total + 7) / 8 * 8);

@@ -17,6 +17,10 @@ CASES = {
     "c2_128": ["--workload", "c2", "--instances", "128"], "c2_128s": ["--workload", "c2", "--instances", "128", "--tuning", "strip=1"],
     "c2_320": ["--workload", "c2", "--instances", "320"], "c2_384": ["--workload", "c2", "--instances", "384"],
     "c2_600": ["--workload", "c2", "--instances", "600"], "c2_768": ["--workload", "c2", "--instances", "768"],
+    "c5f64_g6": ["--workload", "c5", "--state", "fp64", "--tuning", "col_groups=6"], "c5f64_g9": ["--workload", "c5", "--state", "fp64", "--tuning", "col_groups=9"],
+    "c5f64_g17": ["--workload", "c5", "--state", "fp64", "--tuning", "col_groups=17"], "c5f64_g3": ["--workload", "c5", "--state", "fp64", "--tuning", "col_groups=3"],
+    "c5f64_r24": ["--workload", "c5", "--state", "fp64", "--tuning", "row_tile=24"], "c5f64_r64": ["--workload", "c5", "--state", "fp64", "--tuning", "row_tile=64"],
+    "c5f64_r32": ["--workload", "c5", "--state", "fp64", "--tuning", "row_tile=32"],
     "c2ring": ["--workload", "c2", "--tuning", "strip=0"], "c2am": ["--workload", "c3", "--m1", "512", "--m2", "256", "--timesteps", "1000", "--instances", "256"], "c5": ["--workload", "c5"], "c5f64": ["--workload", "c5", "--state", "fp64"], "c4": ["--workload", "c4"],
 }
 argv = sys.argv[1:]
