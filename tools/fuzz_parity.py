@@ -15,31 +15,43 @@ s = H.HestonADI(0)
 worst = 0.0
 for c in range(cases):
     m1 = rng.choice([rng.randint(20, 64), rng.randint(65, 128), rng.randint(129, 256), rng.randint(257, 512), rng.randint(513, 800)])
-    m2 = rng.randint(8, min(m1, 300))
+    m2 = rng.randint(8, 300) if rng.random() < 0.2 else rng.randint(8, min(m1, 300))  # (m2 > m1 now and then)
     N = rng.randint(2, 12)
-    n = rng.choice([1, 2, 3, 5, 9])
+    n = rng.choice([1, 2, 3, 5, 9, 40, 130, 300]) if m1 * m2 < 40000 else rng.choice([1, 2, 3, 5, 9, 70])
     variant = rng.choice([H.EU, H.AM, H.DIV, H.AM_DIV])
     name = {H.EU: "EU", H.AM: "AM", H.DIV: "DIV", H.AM_DIV: "AM_DIV"}[variant]
     r_f = rng.choice([0.0, 0.01, 0.03])
     model = (rng.uniform(-0.95, 0.5), rng.uniform(0.1, 0.8), rng.uniform(0.3, 4.0), rng.uniform(0.01, 0.2))
     strikes = [rng.uniform(80, 120) for _ in range(n)]
-    grids = H.GridViewsBatch.for_strikes(m1, m2, Cm.S_0, Cm.V_0, strikes); U0 = grids.call_payoff(strikes)
+    put = rng.random() < 0.35
+    f32 = variant in (H.EU, H.DIV) and rng.random() < 0.2
+    grids = H.GridViewsBatch.for_strikes(m1, m2, Cm.S_0, Cm.V_0, strikes)
+    U0 = grids.put_payoff(strikes) if put else grids.call_payoff(strikes)
     U, lam = U0.copy(), np.zeros_like(U0)
     div = H.Dividends(*Cm.DIVS) if variant in (H.DIV, H.AM_DIV) else None
     if rng.random() < 0.3: s.set_tuning("american_p", 0)
     if rng.random() < 0.3: s.set_tuning("strip", 1)
     try:
         s.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, r_f, *model, grids, U, variant=variant, U_0=U0,
-                          lambda_bar=lam if variant in (H.AM, H.AM_DIV) else None, dividends=div)
+                          lambda_bar=lam if variant in (H.AM, H.AM_DIV) else None, dividends=div,
+                          option_type=H.PUT if put else H.CALL, strikes=strikes if put else None,
+                          state_precision=H.STATE_FP32 if f32 else H.STATE_FP64)
         path = s.describe_last_sweep()
     finally:
         s.set_tuning("american_p", 1); s.set_tuning("strip", -1)
-    p = O.make_params(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, r_f, *model, variant, Cm.DIVS if div is not None else None)
+    p = O.make_params(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, r_f, *model, variant, Cm.DIVS if div is not None else None,
+                      option_type=O.PUT if put else O.CALL, strikes=np.array(strikes) if put else None, state_fp32=1 if f32 else 0)
     Uo, lo, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0, want_lambda=True)
-    err = np.abs(U - Uo).max() / np.abs(Uo).max()
+    # an s-grid where S_0 lands right beside a node has a tiny interval next to a wide one: 1/ds^2 coefficients of 1e6+ make
+    # BOTH solvers carry ~1e-10 of round-off on that instance (cf. the K = 94 row of the Jacobian test) -- judged at 1e-8
+    ds = np.asarray(grids.Delta_s); ratio = np.maximum(ds[:, 1:] / ds[:, :-1], ds[:, :-1] / ds[:, 1:]).max(axis=1)
+    per = np.abs(U - Uo).max(axis=1) / np.abs(Uo).max()
+    err = per[ratio <= 30].max() if (ratio <= 30).any() else 0.0
+    err_ill = per[ratio > 30].max() if (ratio > 30).any() else 0.0
     lerr = 0.0 if lo is None else np.abs(lam - lo).max() / max(1.0, np.abs(lo).max())
-    worst = max(worst, err)
-    ok = np.isfinite(err) and err < 1e-10 and lerr < 1e-8
-    print("%s %3d %s m1=%d m2=%d N=%d n=%d r_f=%.2f err=%.2e lam_err=%.2e | %s" % ("ok " if ok else "BAD", c, name, m1, m2, N, n, r_f, err, lerr, path[:70]))
-    if not ok: sys.exit(1)
-print("all ok, worst field error %.2e" % worst)
+    ok = np.isfinite(err) and np.isfinite(err_ill) and err < (2e-7 * N if f32 else 1e-10) and err_ill < (1e-4 if f32 else 1e-8) and lerr < 1e-7
+    if not f32: worst = max(worst, err)
+    print("%s %3d %s%s%s m1=%d m2=%d N=%d n=%d r_f=%.2f err=%.2e ill=%.2e lam_err=%.2e | %s" % ("ok " if ok else "BAD", c, name, " put" if put else "", " f32" if f32 else "", m1, m2, N, n, r_f, err, err_ill, lerr, path[:70]), flush=True)
+    bad = globals().get("bad", 0) + (0 if ok else 1); globals()["bad"] = bad
+print("%d bad of %d, worst fp64 field error %.2e" % (globals().get("bad", 0), cases, worst))
+sys.exit(1 if globals().get("bad", 0) else 0)
