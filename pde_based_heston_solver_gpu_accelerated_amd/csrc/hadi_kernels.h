@@ -1236,6 +1236,12 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
         else corr = -thdt * A2U[r];
         yo[r] = x + corr;
     }
+    // Plain global stores on purpose.  Raw BUFFER stores here (SGPR row offset, one 32-bit lane offset: two VGPRs and the
+    // 64-bit address arithmetic saved, 0.5 % faster) were tried in round 2 and are WRONG for this kernel: the counted vmcnt
+    // waits rely on vector-memory operations retiring in issue order, which holds among GLOBAL operations (the LDS-DMA loads
+    // and these stores) but not between MUBUF and GLOBAL ones -- with buffer stores the counter reached its target while a
+    // DMA piece was still in flight and the next step read a stale ring row (caught by the libhadi_strict.so comparison
+    // and the oracle tests at 2 and 8 nodes per lane).
     hadi_put_block<B, 1, T>(c.Yi + (size_t)j * rowp, 0, lane, yo);
     if (lane == 0) c.Yi[(size_t)j * rowp + c0slot] = (T)yout_c0;
     HADI_STAMPC(29);  // final correction + store issue
