@@ -1250,7 +1250,10 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
 // LDS: [HADI_STRIP_WAVES wavefronts][4 ring slots][rowp] + the 4 s-coefficient arrays.  Grid = n_inst * sblocks blocks.
 // T = float: fp32-state sweep (European only), as in hadi_pass_a.
 template <int B, int AMER, class T = double>
-__global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 4 ? 2 : 4)) hadi_pass_a_strip(HadiSweepArgs a, int n) {
+#ifndef HADI_STRIP_OCC_B4
+#define HADI_STRIP_OCC_B4 2
+#endif
+__global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4 ? HADI_STRIP_OCC_B4 : 4)) hadi_pass_a_strip(HadiSweepArgs a, int n) {
     static_assert(sizeof(T) == 8 || AMER == 0, "the fp32-state sweep is European only");
     HADI_DYN_SMEM(double, smem);
     constexpr int NS = 4, NWV = HADI_STRIP_WAVES(B), c0slot = 64 * B;
