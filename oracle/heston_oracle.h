@@ -8,8 +8,14 @@
  * load it; the product library (libhadi) never links or calls it.
  *
  * Parity pin: see oracle/README.md -- the reference needs Kokkos and cannot be
- * built here, so the oracle is pinned at price / Jacobian level against the
- * reference outputs recorded in SURVEY.md section 8(c) (tests/golden/).
+ * built here (no oracle/_ref).  The oracle is pinned (A) against data the reference
+ * holds in its own sources: the test_convergence sweep and its semi-analytic target
+ * (src/solver.cpp:1653-1692), the hard-coded print targets, the per-operator
+ * acceptance drivers (tests/test_reference_pins.py); and (B) at price / Jacobian /
+ * calibration level against the reference outputs recorded in SURVEY.md section 8(c)
+ * (tests/golden/, survey-recorded: that build cannot be repeated).  Full fields, the
+ * put boundary data and the fp32 state have no reference counterpart: unpinned,
+ * validated on their own (oracle/README.md).
  */
 #ifndef HESTON_ORACLE_H
 #define HESTON_ORACLE_H
