@@ -180,7 +180,9 @@ typedef unsigned hadi_u32x2 __attribute__((ext_vector_type(2)));
 // the 256 MB memory-side cache, which the next pass (walking the instances the other way round) then hits.
 // Measured on MI355X, 256 instances of 512x256: step 0.303 -> 0.284 ms; tools/mallbench.hip shows the effect on a
 // plain ping-pong copy (512 MB working set: 5.4 -> 7.3 TB/s).
+#ifndef HADI_AUX_NT
 #define HADI_AUX_NT 2
+#endif
 struct HadiBuf { __amdgpu_buffer_rsrc_t r; };
 HADI_DEV HADI_FORCEINLINE HadiBuf hadi_make_buf(const void *base, size_t bytes) {
     return HadiBuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000)};
@@ -1612,12 +1614,12 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_store(const HadiPassBCtx &c, int ctile, d
         const unsigned rstride = (unsigned)c.rowp * ES;
         if constexpr (RELOAD) {
             const unsigned voffs = valid ? voff : HADI_BUF_DROP;
+            // all stores first, then all loads: issued pairwise (store k, load k) the 1024x512 column pass ran 0.142 ms per
+            // launch against 0.133 -- the memory pipe turns round between writes and reads 33 times per wavefront and tile
 #pragma unroll
-            for (int k = 0; k < HADI_LC; k++) {
-                const unsigned ro = hadi_pb_row(c, k) * rstride;
-                hadi_buf_store_t<T>(c.Ub, voffs, ro, y[k]);
-                y[k] = hadi_buf_load_t<T>(c.Yb, voffn, ro);
-            }
+            for (int k = 0; k < HADI_LC; k++) hadi_buf_store_t<T>(c.Ub, voffs, hadi_pb_row(c, k) * rstride, y[k]);
+#pragma unroll
+            for (int k = 0; k < HADI_LC; k++) y[k] = hadi_buf_load_t<T>(c.Yb, voffn, hadi_pb_row(c, k) * rstride);
         } else if (valid) {
 #pragma unroll
             for (int k = 0; k < HADI_LC; k++) hadi_buf_store_t<T>(c.Ub, voff, hadi_pb_row(c, k) * rstride, y[k]);
@@ -1721,6 +1723,18 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ct
     hadi_pb_store<AMER, false, T>(c, ctile, y);
 }
 
+// Column tiles [t0, t1) of block `grp` of an instance.  The pitch is 64*B*G + pad, so the last tile is always a SHORT one
+// (8..32 columns: little traffic, but a full solve).  The full tiles are dealt out btpw per block and the short tile rides
+// with the last block, which is the one that may hold fewer full tiles (1024x512: 16 full tiles on 4 blocks = 4,4,4,4+short
+// instead of 5,5,5,2 -- the launch takes 4.3 tile times instead of 5).  With btpw = 1 and one block more than full tiles the
+// short tile gets a block of its own (the one-tile-per-block geometry of the small-chunk grids).
+HADI_DEV HADI_FORCEINLINE void hadi_pb_tile_range(const HadiSweepArgs &a, int grp, int &t0, int &t1) {
+    const int nfull = a.L.rowp >> 6;
+    t0 = grp * a.btpw;
+    if (t0 > nfull) t0 = nfull;
+    t1 = (grp == a.bgroups - 1) ? a.ctiles : (t0 + a.btpw < nfull ? t0 + a.btpw : nfull);
+}
+
 // Dynamic LDS: P * (2*4*64 + 16*P) doubles (two interface-exchange buffers, each wavefront's four rows of the reduced
 // inverse); the chunk tables live in registers (HADI_PB_T).
 // MAXP only sets the launch bound (register budget): 8 -> 512 threads, 16 -> 1024 threads.
@@ -1759,8 +1773,8 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
     c.american = a.american;
     c.pos_m1 = a.pos_m1;
     c.dt = ip.dt;
-    const int t0 = grp * a.btpw;
-    const int t1 = (t0 + a.btpw < a.ctiles) ? t0 + a.btpw : a.ctiles;
+    int t0, t1;
+    hadi_pb_tile_range(a, grp, t0, t1);
 
 #if defined(HADI_STAMPS) && !defined(HADI_EMU)
     unsigned long long stamp_store_[32] = {0};
@@ -1877,8 +1891,8 @@ __global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, in
     c.american = a.american;
     c.pos_m1 = a.pos_m1;
     c.dt = ip.dt;
-    const int t0 = grp * a.btpw;
-    const int t1 = (t0 + a.btpw < a.ctiles) ? t0 + a.btpw : a.ctiles;
+    int t0, t1;
+    hadi_pb_tile_range(a, grp, t0, t1);
 
 #if defined(HADI_STAMPS) && !defined(HADI_EMU)
     unsigned long long stamp_store_[32] = {0};
@@ -1903,6 +1917,9 @@ __global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, in
         c.Ri = rw;
     }
     __syncthreads();
+    // (fp32 state: holding the NEXT tile in 33 float registers so that its loads fly during the solve was tried -- 66 + 33 +
+    // 10 table registers leave too few of the 128 for the reduced-system loop, the kernel spills 18 registers and the
+    // scratch reloads drain the prefetch: 0.088 -> 0.099 ms per launch at 1024x512 x64.)
     for (int t = t0; t < t1; t++) {
         hadi_pb_solve(c, (t - t0) & 1, y, 0);
         if (t + 1 < t1) hadi_pb_store<AMER, true, T>(c, t, y);

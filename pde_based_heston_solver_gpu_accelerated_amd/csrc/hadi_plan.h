@@ -129,38 +129,49 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
         if (tu.strip >= 0) p.use_strip = (tu.strip && p.RS >= 1 && p.RS <= 64) ? 1 : 0;
     }
     p.ctiles = (L.rowp + 63) / 64;
-    // Each block walks over btpw column tiles (loads of the next tile overlap the solve of the current
-    // one); keep >= ~3 blocks per CU in the launch so that tails stay short.
+    // Column tiles per block.  The pitch is 64*B*G + pad, so an instance has nfull = B*G full tiles and one SHORT tile
+    // (the pad columns: little traffic, but a whole solve -- about 0.3 of a full tile's time).  The full tiles are dealt
+    // out btpw per block and the short tile rides with the last block (hadi_pb_tile_range).  A block keeps a CU to itself
+    // above four chunks, so a launch takes ceil(blocks / CUs) rounds of its heaviest block; blocks of a single tile lose
+    // the register double-buffering (+30 % measured, hence the 0.6).
     {
+        const int nfull = L.rowp / 64, nshort = p.ctiles - nfull;
+        const int cus = target_waves / 8 > 0 ? target_waves / 8 : 1;
+        auto gfull_of = [&](int b) { return nfull > 0 ? (nfull + b - 1) / b : 1; };
+        auto cost = [&](int b) {
+            const int gf = gfull_of(b);
+            const double w_last = (double)(nfull - (gf - 1) * b) + 0.3 * nshort;
+            const double w = (gf > 1 && (double)b > w_last) ? (double)b : w_last;
+            const long long rounds = ((long long)n_inst * gf + cus - 1) / cus;
+            // up to eight chunks the kernel holds three tiles in registers, all loaded up front; a fourth tile waits for a
+            // free buffer (512x256 x256: 2 blocks of 4 and 4+short tiles 0.129 ms against 0.109 for 3 blocks of 3,3,2+short)
+            const double late = (L.P <= 8 && b > 3) ? 1.0 * (b - 3) : 0.0;
+            return (double)rounds * (w + (b < 2 ? 0.6 : 0.0) + late);
+        };
+        // start from "about three blocks per CU in the launch" and move only to a split that needs fewer tile-rounds
         const int want_blocks = (3 * target_waves) / 8;  // target_waves = 8 per CU
         int groups = (want_blocks + n_inst - 1) / n_inst;
         if (groups < 1) groups = 1;
         if (groups > p.ctiles) groups = p.ctiles;
-        // One block per CU (two register buffers): the launch takes ceil(blocks / CUs) rounds of btpw tiles each.
-        // Keep the "about three blocks per CU" choice unless another split needs fewer tile-rounds (batch sizes that
-        // are not a multiple of the CU count); blocks of a single tile lose the double buffering (+30 % measured).
-        {
-            const int cus = target_waves / 8 > 0 ? target_waves / 8 : 1;
-            auto cost = [&](int g) {
-                const int tiles = (p.ctiles + g - 1) / g;
-                const int gg = (p.ctiles + tiles - 1) / tiles;
-                const long long rounds = ((long long)n_inst * gg + cus - 1) / cus;
-                return (double)rounds * (tiles + (tiles < 2 ? 0.6 : 0.0));
-            };
-            int best = groups;
-            for (int g = p.ctiles; g >= 1; g--)
-                if (cost(g) < cost(best) - 1e-9) best = g;
-            groups = best;
-        }
+        int btpw = (p.ctiles + groups - 1) / groups;
+        if (btpw > nfull && nfull > 0) btpw = nfull;
+        for (int b = 1; b <= nfull; b++)
+            if (cost(b) < cost(btpw) - 1e-9) btpw = b;
+        bool own_short = false;
         // Up to four chunks (m2 <= 131) a block is at most 256 threads and two or more of them share a CU: blocks of ONE
         // tile then overlap each other better than tiles pipeline inside a block (measured, 256x128 x512 American:
-        // 0.094 -> 0.083 ms per launch; 200x100 x700: 0.087 -> 0.084; 128x64 x2000: 0.070 -> 0.068).
-        if (L.P <= 4) groups = p.ctiles;
-        if (tu.col_groups > 0) groups = tu.col_groups;
-        if (groups < 1) groups = 1;
-        if (groups > p.ctiles) groups = p.ctiles;
-        p.btpw = (p.ctiles + groups - 1) / groups;
-        p.bgroups = (p.ctiles + p.btpw - 1) / p.btpw;
+        // 0.094 -> 0.083 ms per launch; 200x100 x700: 0.087 -> 0.084; 128x64 x2000: 0.070 -> 0.068); the short tile gets
+        // a block of its own there.
+        if (L.P <= 4) { btpw = 1; own_short = nshort > 0; }
+        if (tu.col_groups > 0) {
+            int g = tu.col_groups < p.ctiles ? tu.col_groups : p.ctiles;
+            own_short = (g == p.ctiles && nshort > 0 && nfull > 0);
+            if (own_short) g = nfull;
+            btpw = nfull > 0 ? (nfull + g - 1) / g : 1;
+        }
+        if (btpw < 1) btpw = 1;
+        p.btpw = btpw;
+        p.bgroups = gfull_of(btpw) + (own_short ? 1 : 0);
     }
     p.grid_b = (n_inst * p.bgroups + 7) / 8 * 8;  // padded to a multiple of 8 for the XCD remap
     p.block_b = 64 * L.P;

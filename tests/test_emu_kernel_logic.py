@@ -195,7 +195,17 @@ def test_plan_invariants_over_shapes_and_batch_sizes(emu):
                 if use_strip:
                     assert B in (2, 4, 8) and (8 if B == 8 else 16) <= RS <= 64
                     seen_strip.add(B)
-                assert btpw * bgroups >= ctiles and (btpw - 1) * bgroups < ctiles + bgroups and ctiles * 64 >= rowp
+                # column tiles: the blocks' ranges (hadi_pb_tile_range) partition [0, ctiles), none is empty
+                assert ctiles * 64 >= rowp and btpw >= 1
+                nfull, nxt = rowp // 64, 0
+                for grp in range(bgroups):
+                    t0 = min(grp * btpw, nfull)
+                    t1 = ctiles if grp == bgroups - 1 else min(t0 + btpw, nfull)
+                    assert t0 == nxt and t1 > t0, (m1, m2, n, btpw, bgroups, grp)
+                    nxt = t1
+                assert nxt == ctiles
+                if (m1, m2, n, tw) == (1024, 512, 64, 2048):  # config 5: 16 full tiles on 4 blocks, the short one appended
+                    assert (btpw, bgroups) == (4, 4)
                 assert grid_b == (n * bgroups + 7) // 8 * 8 and smem_b <= LDS and P <= 16
     assert seen_strip == {2, 4, 8}
     assert emu.emu_plan_full(100, 101, 1, 8, o) == 0  # m2 > m1 is covered (two b1 entries on the v-rows k*m1)

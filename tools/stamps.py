@@ -12,7 +12,8 @@ import pde_based_heston_solver_gpu_accelerated_amd._native as nat
 nat.LIB_PATH = lib
 import pde_based_heston_solver_gpu_accelerated_amd as H
 import numpy as np, torch
-n, m1, m2, N = int(sys.argv[1]) if len(sys.argv) > 1 else 256, 512, 256, 20
+n, N = int(sys.argv[1]) if len(sys.argv) > 1 else 256, 20
+m1, m2 = int(os.environ.get("M1", "512")), int(os.environ.get("M2", "256"))
 strikes = [85 + 30 * k / (n - 1) for k in range(n)]
 g = H.GridViewsBatch.for_strikes(m1, m2, 100.0, 0.04, strikes); U0 = g.call_payoff(strikes)
 dev = torch.device("cuda:0"); gd = g.to(dev); U = torch.from_numpy(U0).to(dev)
@@ -28,7 +29,8 @@ names = {0: "row scalars + col0", 1: "LDS rows -> tt,A2U", 2: "coef + Y0 + fwd T
 if os.environ.get("STAMP_LEVEL") == "3":
     bn = {16: "wait for the tile's loads", 17: "forward", 18: "backward", 19: "exchange + barrier", 20: "reduced system",
           21: "spike correction", 22: "store issue"}
-    tiles = n * 8 * 9 * N  # P chunks x ceil(520/64) column tiles
+    P = (m2 + 1 + 32) // 33; BG = 8 * (2 if m1 > 512 else 1) if m1 > 256 else (4 if m1 > 128 else 2 if m1 > 64 else 1)
+    tiles = n * P * (BG + 1) * N  # P chunks x column tiles (full + the short one)
     tb = sum(buf[k] for k in bn)
     print("sweep_ms", s.timing()["sweep_ms"])
     for k, nm in bn.items():
@@ -37,13 +39,13 @@ if os.environ.get("STAMP_LEVEL") == "3":
 if os.environ.get("STAMP_LEVEL") == "4":
     cn = {24: "wait for the DMA (row j+2)", 31: "DMA issue (row j+4)", 25: "LDS reads + table entry", 26: "explicit ops + Y0 + fwd Thomas",
           27: "bwd Thomas + reduced row", 28: "PCR", 29: "final + store issue", 30: "carry + loop"}
-    rows = n * 257 * N
+    rows = n * (m2 + 1) * N
     tc = sum(buf[k] for k in cn)
     print("sweep_ms", s.timing()["sweep_ms"])
     for k, nm in cn.items():
         print("%-40s %8.0f cycles/row  %5.1f %%" % (nm, buf[k] / rows, 100.0 * buf[k] / tc))
     sys.exit(0)
-rows = n * 257 * N
+rows = n * (m2 + 1) * N
 tot = sum(buf[k] for k in (8, 9, 10))
 print("sweep_ms", s.timing()["sweep_ms"])
 for k, nm in names.items():
