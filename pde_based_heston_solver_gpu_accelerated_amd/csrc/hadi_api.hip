@@ -231,6 +231,8 @@ hipError_t raise_all_lds_limits() {
     if ((e = raise_lds_limit(hadi_pass_a<8, 1, 4, 1, 1, 2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_a<8, 2, 4, 1, 1, 2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_a_strip<8, false, float>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a_strip<8, false, float, 2>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a_strip<8, false, double, 2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b<8, false, float>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b1<16, false, float>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_a<1, 1, 4, 1, 2, false, 0, float>)) != hipSuccess) return e;
@@ -268,7 +270,8 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         subs.push_back(SubBatch{0, d.n, pl});
     }
     const int nsub = (int)subs.size();
-    if (!(d.theta > 0.0)) {  // the strip kernel scales the A1 action by (1 - theta) / theta
+    if (!(d.theta > 0.0) ||  // the strip kernel scales the A1 action by (1 - theta) / theta
+        (pl.L.G == 2 && (d.variant == HADI_AM || d.variant == HADI_AM_DIV))) {  // paired strips: European step only
         pl.use_strip = 0;
         for (auto &sbt : subs) sbt.pl.use_strip = 0;
     }
@@ -469,6 +472,10 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                     }
                     return;
                 }
+                if (f32 && pl.use_strip && L.B == 8 && L.G == 2) {  // fp32 state, 512 < m1 <= 1024: paired strips
+                    hipLaunchKernelGGL((hadi_pass_a_strip<8, false, float, 2>), dim3(pl.grid_as), dim3(512), pl.smem_as, q, ar, nstep);
+                    return;
+                }
                 if (f32 && pl.use_strip && L.B == 8) {  // fp32 state, 8 nodes per lane, large batch: strips with a ring of floats
                     const size_t smem = (size_t)8 * 4 * L.rowp * sizeof(float) + (size_t)4 * 64 * L.B * sizeof(double);
                     hipLaunchKernelGGL((hadi_pass_a_strip<8, false, float>), dim3(pl.grid_as), dim3(512), smem, q, ar, nstep);
@@ -482,6 +489,10 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                         case 81: launch_pass_a_f32<8, 1, 1, 1>(pl, ar, nstep, q); break;
                         default: launch_pass_a_f32<8, 2, 1, 1>(pl, ar, nstep, q); break;
                     }
+                    return;
+                }
+                if (pl.use_strip && mode == 0 && L.G == 2) {  // paired strips (European Douglas step, two wavefronts per row)
+                    hipLaunchKernelGGL((hadi_pass_a_strip<8, false, double, 2>), dim3(pl.grid_as), dim3(512), pl.smem_as, q, ar, nstep);
                     return;
                 }
                 if (pl.use_strip && mode == 0) {  // barrier-free strips (Douglas step, one wavefront per row)
@@ -610,8 +621,10 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         char rowk[96];
         if (amp && pl.use_strip && !cs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<%d,AM-P> (strips of %d rows, no lambda_bar array)", L.B, pl.RS);
         else if (amp) std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,AM-P> (tiles of %d rows, no lambda_bar array)", L.B, L.G, pl.W, pl.NG, pl.PD, pl.R);
+        else if (f32 && pl.use_strip && L.B == 8 && L.G == 2) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,EU,float,2> (paired strips of %d rows, fp32 state)", pl.RS);
         else if (f32 && pl.use_strip && L.B == 8) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,EU,float> (strips of %d rows, fp32 state)", pl.RS);
         else if (f32) std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,EU,float> (tiles of %d rows, fp32 state)", L.B, L.G, pl.W, pl.NG, pl.PD, pl.R);
+        else if (pl.use_strip && !cs && L.G == 2) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,EU,double,2> (paired strips of %d rows)", pl.RS);
         else if (pl.use_strip && !cs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<%d,%s> (strips of %d rows)", L.B, american ? "AM" : "EU", pl.RS);
         else std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,%s%s> (tiles of %d rows)", L.B, L.G, pl.W, pl.NG, pl.PD,
                            american ? "AM" : "EU", cs ? ",CS" : "", pl.R);

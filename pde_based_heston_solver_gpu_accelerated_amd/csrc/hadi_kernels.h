@@ -375,6 +375,50 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_to_lds_fixed(const T *__restrict__ grow,
             for (int e = 0; e < EPV; e++) lrow[EPV * v + e] = (T)0;
     }
 }
+// G = 2 strips: the copy of ONE HALF of a row -- the pieces of 1 KiB that hold this wavefront's nodes (pairs, or quads
+// with an fp32 state: piece q of half h starts at element q*PW*2 + PW*h, PW = 128 resp. 256) and, for the low half, the
+// 128-byte pad piece with the i = 0 slot.  Returns the number of vector-memory instructions issued (wave-uniform).
+template <int B, class T>
+HADI_DEV HADI_FORCEINLINE int hadi_half_row_to_lds(const T *__restrict__ grow, T *lrow, int half, int lane, bool exists) {
+    constexpr int EPV = 16 / (int)sizeof(T), PW = 64 * EPV, NP = B / EPV, PAD = HADI_ROW_PAD(B, (int)sizeof(T));
+    constexpr int PADV = PAD / EPV;  // 16-byte vectors of the pad piece
+    static_assert(B % EPV == 0 && PAD % EPV == 0 && PADV <= 64, "row layout");
+    if (exists) {
+#if defined(HADI_EMU)
+        for (int q = 0; q < NP; q++)
+            for (int e = 0; e < EPV; e++) lrow[q * PW * 2 + PW * half + EPV * lane + e] = grow[q * PW * 2 + PW * half + EPV * lane + e];
+        if (half == 0 && lane < PADV)
+            for (int e = 0; e < EPV; e++) lrow[64 * B * 2 + EPV * lane + e] = grow[64 * B * 2 + EPV * lane + e];
+#else
+        const T *gsrc = grow + PW * half + EPV * lane;
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)(lrow + PW * half));
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" HADI_DMA_POLICY "\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(gsrc + q * PW * 2), "s"(lds0 + 2048u * q)
+                         : "memory");
+        }
+        if (half == 0) {  // wave-uniform
+            if (lane < PADV) {
+                unsigned keep;
+                const unsigned ldsp = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)(lrow + 64 * B * 2));
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" HADI_DMA_POLICY "\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(grow + 64 * B * 2 + EPV * lane), "s"(ldsp)
+                             : "memory");
+            }
+        }
+#endif
+        return NP + (half == 0 ? 1 : 0);
+    }
+    for (int q = 0; q < NP; q++)
+        for (int e = 0; e < EPV; e++) lrow[q * PW * 2 + PW * half + EPV * lane + e] = (T)0;
+    if (half == 0 && lane < PADV)
+        for (int e = 0; e < EPV; e++) lrow[64 * B * 2 + EPV * lane + e] = (T)0;
+    return 0;
+}
 // number of vector-memory instructions hadi_row_to_lds issues for an existing row
 template <class T>
 HADI_DEV HADI_FORCEINLINE int hadi_row_dma_count(int rowp) {
@@ -470,6 +514,14 @@ HADI_DEV HADI_FORCEINLINE void hadi_put_block(T *row, int half, int lane, const 
             *reinterpret_cast<typename HadiPair<T>::type *>(row + q * 128 * G + 128 * half + 2 * lane) = t;
         }
     }
+}
+
+// Vector stores hadi_put_block issues per lane for one row block: the counted vmcnt waits add this as the LOWER bound of
+// the operations a row step puts behind a DMA batch (too high a count would let the wait pass with a DMA piece still in
+// flight).  fp32 state at 4 or 8 nodes per lane stores QUADS (B/4 instructions), everything else pairs.
+template <int B, class T>
+HADI_DEV constexpr int hadi_put_block_stores() {
+    return B == 1 ? 1 : (sizeof(T) == 4 && B >= 4) ? B / 4 : B / 2;
 }
 
 // One v-row: explicit stage, Y0, A1 line solve, A2 right-hand side.  LAST = this is the v-row that
@@ -999,7 +1051,7 @@ __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : B == 4 ? HADI_R
             hadi_row_step<B, G, AMER, false, MODE, T>(c, active, j, slot(j - 2), slot(j - 1), slot(j), slot(j + 1), slot(j + 2));
         if (active) {  // B/2 (one for B = 1) vector stores of the block; the i = 0 store is not counted (lower bound)
 #pragma unroll
-            for (int k = 0; k < PD; k++) ya[k] += (B == 1 ? 1 : B / 2);
+            for (int k = 0; k < PD; k++) ya[k] += hadi_put_block_stores<B, T>();
         }
         HADI_STAMP(10);  // whole row step (+ fetch issue)
     }
@@ -1031,21 +1083,47 @@ struct HadiStripCtxT {
     double hr0, inv0;         // i = 0 row of A1: reaction term (0 for the call) and 1 / (1 + theta dt hr0)
     double inv_dt;            // P representation: 1 / dt and the (lane, slot) of the s_max node
     int m1_lane, m1_r;
+    int half;                 // G = 2: which half of the row this wavefront owns (0: nodes 1..64B, 1: the rest)
+    double *xch;              // G = 2: LDS exchange of the wavefront pair, [2 row parities][4 values + 2 tokens + 2 spare]
     HADI_STAMP_ACC
 };
+
+// Pair rendezvous flags in LDS (G = 2 strips and the shared ring): release store / acquire load at workgroup scope.
+HADI_DEV HADI_FORCEINLINE void hadi_flag_store(int *f, int v) {
+#if defined(HADI_EMU)
+    __atomic_store_n(f, v, __ATOMIC_RELEASE);
+#else
+    __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+HADI_DEV HADI_FORCEINLINE int hadi_flag_load(int *f) {
+#if defined(HADI_EMU)
+    return __atomic_load_n(f, __ATOMIC_ACQUIRE);
+#else
+    return __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
 
 // AMER: 0 European, 1 American with the explicit (U, lambda_bar) pair (lambda_bar loaded here), 2 American in the P
 // representation: the caller rebuilt U = max(P, U_0) on the five rows and hands over the raw P of row j (p_raw) and
 // lambda_bar of the i = 0 column; lambda_bar = max(0, (U_0 - P)/dt) = (U - P)/dt is formed here, right before the sweep
 // that consumes it (formed by the caller it stayed live across the explicit operators and the kernel spilled).
-template <int B, int AMER, bool LAST, class T = double>
+// G = 2 (512 < m1 <= 1024, European): the row is shared by a PAIR of wavefronts, each owning one half.  eb / e0 / ea are
+// the values, on the rows behind / at / ahead of j, of the one node next to this half that belongs to the partner; the
+// tridiagonal system is split at the boundary exactly as in hadi_row_step (second right-hand side through the cyclic
+// reduction, 2x2 system exchanged through LDS), with a rendezvous of the two wavefronts only.
+template <int B, int AMER, bool LAST, class T = double, int G = 1>
 HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j, const double (&rt)[HADI_RCL],
                                                const double (&um2)[B], const double (&um1)[B], const double (&u0)[B],
                                                const double (&up1)[B], const double (&up2)[B], double c0m2, double c0m1,
                                                double c00, double c0p1, double c0p2, const double (&p_raw)[B],
-                                               double lamc0_in, const T *next_row, double (&u_next)[B]) {
+                                               double lamc0_in, const T *next_row, double (&u_next)[B],
+                                               double eb = 0.0, double e0 = 0.0, double ea = 0.0) {
+    static_assert(G == 1 || (G == 2 && AMER == 0), "paired strips cover the European step");
     const int lane = c.lane, rowp = c.rowp;
-    constexpr int c0slot = 64 * B;
+    const int half = (G > 1) ? c.half : 0;
+    const bool first_half = (half == 0), last_half = (half == G - 1);
+    constexpr int c0slot = 64 * B * G;
     constexpr int NB = B - 1;
     HADI_STAMP_DECL(c.stamp_acc_)
     const double dt = c.dt, thdt = c.thdt, qth = c.qth, c1 = c.c1, c2 = c.c2, kap = c.kap, e_nm1 = c.e_nm1, e_n = c.e_n;
@@ -1057,8 +1135,10 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
     const bool b1_at0 = b1raw == 0 || b1raw >= HADI_B1_BOTH;  // (two entries on one v-row: m2 > m1 only)
     const int b1col = b1raw >= HADI_B1_BOTH ? b1raw - HADI_B1_BOTH : b1raw;
     const int b1e = b1col - 1;
-    const int b1lane = (b1col >= 1) ? b1e / B : -1;
-    const int b1r = b1e - (b1e / B) * B;
+    const int b1half = (G > 1 && b1col >= 1) ? b1e / (64 * B) : 0;  // which wavefront of the pair holds the b1 node
+    const int b1el = b1e - b1half * 64 * B;
+    const int b1lane = (b1col >= 1 && b1half == half) ? b1el / B : -1;
+    const int b1r = b1el - (b1el / B) * B;
 
     // ---- column i = 0 (A0 and A1 rows are zero there; only A2 and the boundary act) ----------------
     const double a2c0 = a2l2 * c0m2 + a2l1 * c0m1 + a2m * c00 + a2u1 * c0p1 + a2u2 * c0p2;
@@ -1086,11 +1166,16 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
     // s-neighbours of the block: last node of lane-1, first node of lane+1; lane 0 borders i = 0, lane 63 the pad (0)
     double u0L = hadi_lane_prev(u0[B - 1]), tL = hadi_lane_prev(tt[B - 1]);
     double u0R = hadi_lane_next(u0[0]), tR = hadi_lane_next(tt[0]);
-    if (lane == 0) {
+    if (lane == 0 && first_half) {
         u0L = c00;
         tL = wm * c0m1 + wz * c00 + wp * c0p1;
     }
-    // (lane 63: hadi_lane_next delivered the pad's zeros already)
+    if constexpr (G > 1) {  // the node across the pair boundary
+        const double te = wm * eb + wz * e0 + wp * ea;
+        if (lane == 0 && !first_half) { u0L = e0; tL = te; }
+        if (lane == 63 && !last_half) { u0R = e0; tR = te; }
+    }
+    // (lane 63 of the last half: hadi_lane_next delivered the pad's zeros already)
     const double cb1 = dt * e_nm1 + thdt * (e_n - e_nm1);
     const double b1l = (lane == b1lane) ? b1val * cb1 : 0.0;  // this row's b1 entry, in the lane that owns its node
 
@@ -1103,7 +1188,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
             if (lane == c.m1_lane && r == c.m1_r) lam[r] = 0.0;  // s_max keeps lambda_bar = 0, as in hadi_row_step
         }
     }
-    if constexpr (LAST) hadi_get_block<B, 1>(c.b2r, 0, lane, b2v);
+    if constexpr (LAST) hadi_get_block<B, G>(c.b2r, half, lane, b2v);
 
     // ---- Y0 (device_solver.hpp:236-250) fused with the forward sweep of the in-lane Thomas ----------
     // The s-coefficients are read pair by pair inside the sweep (a compiler barrier keeps hipcc from hoisting all 16
@@ -1119,10 +1204,11 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
             asm volatile("" ::: "memory");
 #endif
             const int q = r >> 1;
-            const double2 t0 = *reinterpret_cast<const double2 *>(c.coef + 0 * 64 * B + q * 128 + 2 * lane);
-            const double2 t1 = *reinterpret_cast<const double2 *>(c.coef + 1 * 64 * B + q * 128 + 2 * lane);
-            const double2 t2 = *reinterpret_cast<const double2 *>(c.coef + 2 * 64 * B + q * 128 + 2 * lane);
-            const double2 t3 = *reinterpret_cast<const double2 *>(c.coef + 3 * 64 * B + q * 128 + 2 * lane);
+            const int co = q * 128 * G + 128 * half + 2 * lane;
+            const double2 t0 = *reinterpret_cast<const double2 *>(c.coef + 0 * 64 * B * G + co);
+            const double2 t1 = *reinterpret_cast<const double2 *>(c.coef + 1 * 64 * B * G + co);
+            const double2 t2 = *reinterpret_cast<const double2 *>(c.coef + 2 * 64 * B * G + co);
+            const double2 t3 = *reinterpret_cast<const double2 *>(c.coef + 3 * 64 * B * G + co);
             Bm[r] = t0.x; Bm[r + 1] = t0.y;
             Bp[r] = t1.x; Bp[r + 1] = t1.y;
             Dm[r] = t2.x; Dm[r + 1] = t2.y;
@@ -1147,7 +1233,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
         y = fma(kap, T1, y);
         y = fma(b1l, (r == b1r) ? 1.0 : 0.0, y);  // wave-uniform selector: one FMA with a scalar operand (a scalar branch
                                                   // around a single add measured slower: 0.1108 vs 0.1099 ms per launch)
-        if (r == 0 && lane == 0) {  // x_0 is known: move it to the right-hand side
+        if (r == 0 && lane == 0 && first_half) {  // x_0 is known: move it to the right-hand side
             y -= il * x0;
             il = 0.0;
         }
@@ -1172,7 +1258,9 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
     }
     HADI_STAMPC(26);  // explicit operators + Y0 + forward Thomas
     // reduced (interface) row of this lane
-    double ra, rb, rcc, rf;
+    double ra, rb, rcc, rf, rs = 0.0;
+    const bool edge_hi = (G > 1) && !last_half && lane == 63;  // next node belongs to the partner wavefront
+    const bool edge_lo = (G > 1) && !first_half && lane == 0;  // previous node belongs to the partner wavefront
     {
         gs[NB - 1] = cp[NB - 1];
 #pragma unroll
@@ -1181,11 +1269,18 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
             ps[r] = fma(-cp[r], ps[r + 1], ps[r]);
             gs[r] = -cp[r] * gs[r + 1];
         }
-        const double p0n = hadi_lane_next(ps[0]), g0n = hadi_lane_next(gs[0]), y0n = hadi_lane_next(ys[0]);
+        double p0n = hadi_lane_next(ps[0]), g0n = hadi_lane_next(gs[0]), y0n = hadi_lane_next(ys[0]);
+        if constexpr (G > 1) {
+            if (edge_hi) { p0n = 0.0; g0n = 0.0; y0n = 0.0; }
+        }
         ra = -il_last * ps[NB - 1];
         rb = im_last - il_last * gs[NB - 1] - iu[B - 1] * p0n;
         rcc = -iu[B - 1] * g0n;
         rf = d_last - il_last * ys[NB - 1] - iu[B - 1] * y0n;
+        if constexpr (G > 1) {
+            if (edge_hi) { rs = iu[B - 1]; rcc = 0.0; }  // couples to t = first node of the partner's half
+            if (edge_lo) { rs = ra; ra = 0.0; }          // couples to the last node of the partner's half
+        }
     }
     HADI_STAMPC(27);  // backward Thomas + reduced row
     // ---- parallel cyclic reduction over the 64 interface unknowns (normalised rows, see hadi_row_step) ----
@@ -1195,6 +1290,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
         ra *= rinv0;
         rcc *= rinv0;
         rf *= rinv0;
+        if constexpr (G > 1) rs *= rinv0;
 #pragma unroll
         for (int s = 1; s < 64; s <<= 1) {
             const int up_lane = (lane - s) & 63, dn_lane = (lane + s) & 63;
@@ -1211,6 +1307,11 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
             const double bn = fma(-rcc, aR, fma(-ra, cL, 1.0));
             const double rn = hadi_rcp(bn);
             rf = fma(-rcc, fR, fma(-ra, fL, rf)) * rn;
+            if constexpr (G > 1) {  // the second right-hand side (coupling to the partner's boundary node)
+                const double sL = (s == 1) ? hadi_lane_prev(rs) : hadi_lane_get(rs, up_lane);
+                const double sR = (s == 1) ? hadi_lane_next(rs) : (s == 32) ? sL : hadi_lane_get(rs, dn_lane);
+                rs = fma(-rcc, sR, fma(-ra, sL, rs)) * rn;
+            }
             if (s < 32) {
                 const double an = -(ra * aL) * rn;
                 const double cn = -(rcc * cR) * rn;
@@ -1223,9 +1324,46 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
     hadi_set_prio(0);
     // the next row (this step's "row ahead") again from its ring slot, intact until the next step: issued here so that the
     // read flies during the final combination and the stores instead of being waited for at the end of the step
-    hadi_get_block<B, 1, T>(next_row, 0, lane, u_next);
-    const double X = rf;
-    const double XL = hadi_lane_prev(X);
+    hadi_get_block<B, G, T>(next_row, half, lane, u_next);
+    double X = rf, XL;
+    if constexpr (G > 1) {
+        // X(l) = rf - bv rs with bv the partner's boundary node.  Publish what the 2x2 system needs (hadi_row_step):
+        //   low half, lane 63:  x_hi = A - t Bc   (A = rf, Bc = rs; x_hi = its own X)
+        //   high half, lane 0:  t = C - x_hi D    (t = its first node = ys0 - XL ps0 - X gs0, XL = x_hi)
+        // into the buffer of this row's parity, then the token behind the values (same lane: the LDS unit sees data before
+        // flag).  The partner walks the same strip in the same direction, so it always arrives; it can be at most one row
+        // away, hence two buffers are enough.  The poll is bounded: a logic error fails parity instead of hanging the GPU.
+        double *xb = c.xch + 8 * (j & 1);
+        int *flags = reinterpret_cast<int *>(xb + 4);
+        const int token = j + 1;
+        if (edge_hi) {
+            xb[0] = rf;
+            xb[1] = rs;
+            hadi_flag_store(flags + 0, token);
+        }
+        if (edge_lo) {
+            xb[2] = ys[0] - rf * gs[0];
+            xb[3] = ps[0] - rs * gs[0];
+            hadi_flag_store(flags + 1, token);
+        }
+        hadi_wave_rendezvous();  // (emulator: this wavefront's own publisher lane has written)
+        int guard = 0;
+        while (hadi_flag_load(flags + (1 - half)) != token && ++guard < (1 << 22)) {
+#if defined(HADI_EMU)
+            sched_yield();
+#else
+            __builtin_amdgcn_s_sleep(1);
+#endif
+        }
+        const double A = xb[0], Bc = xb[1], Cc = xb[2], Dd = xb[3];
+        const double xhi = (A - Bc * Cc) / (1.0 - Bc * Dd);  // last node of the low half
+        const double tlo = Cc - Dd * xhi;                    // first node of the high half
+        X = rf - (first_half ? tlo : xhi) * rs;
+        XL = hadi_lane_prev(X);
+        if (lane == 0 && !first_half) XL = xhi;
+    } else {
+        XL = hadi_lane_prev(X);
+    }
     // ---- Y1 -> right-hand side of the A2 solve (device_solver.hpp:254-260) and store ----------
     double yo[B];
 #pragma unroll
@@ -1244,23 +1382,30 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
     // and these stores) but not between MUBUF and GLOBAL ones -- with buffer stores the counter reached its target while a
     // DMA piece was still in flight and the next step read a stale ring row (caught by the libhadi_strict.so comparison
     // and the oracle tests at 2 and 8 nodes per lane).
-    hadi_put_block<B, 1, T>(c.Yi + (size_t)j * rowp, 0, lane, yo);
-    if (lane == 0) c.Yi[(size_t)j * rowp + c0slot] = (T)yout_c0;
+    hadi_put_block<B, G, T>(c.Yi + (size_t)j * rowp, half, lane, yo);
+    if (lane == 0 && first_half) c.Yi[(size_t)j * rowp + c0slot] = (T)yout_c0;
     HADI_STAMPC(29);  // final correction + store issue
 }
 
 // LDS: [HADI_STRIP_WAVES wavefronts][4 ring slots][rowp] + the 4 s-coefficient arrays.  Grid = n_inst * sblocks blocks.
 // T = float: fp32-state sweep (European only), as in hadi_pass_a.
-template <int B, int AMER, class T = double>
+// G = 2 (512 < m1 <= 1024, European): the 8 wavefronts form 4 PAIRS, each pair walks one strip, wavefront h of the pair owns
+// half h of every row (its own pieces of the pair's ring slot, fetched by its own LDS-DMA and retired by its own counted
+// wait -- no wavefront ever reads ring data its partner fetched, except the one boundary node, see below).  LDS:
+// [4 pairs][NS slots][rowp] + 4 coefficient arrays of 1024 + the pairs' exchange buffers; with an fp64 state only NS = 3
+// slots fit the 160 KB (rows j+1, j+2 landed, j+3 in flight), with an fp32 state 4 as above.
+template <int B, int AMER, class T = double, int G = 1>
 #ifndef HADI_STRIP_OCC_B4
 #define HADI_STRIP_OCC_B4 2
 #endif
 __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4 ? HADI_STRIP_OCC_B4 : 4)) hadi_pass_a_strip(HadiSweepArgs a, int n) {
     static_assert(sizeof(T) == 8 || AMER == 0, "the fp32-state sweep is European only");
+    static_assert(G == 1 || (G == 2 && B == 8 && AMER == 0), "paired strips: 8 nodes per lane, European");
     HADI_DYN_SMEM(double, smem);
-    constexpr int NS = 4, NWV = HADI_STRIP_WAVES(B), c0slot = 64 * B;
+    constexpr int NS = (G == 2 && sizeof(T) == 8) ? 3 : 4, NWV = HADI_STRIP_WAVES(B), NPAIR = NWV / G, c0slot = 64 * B * G;
     const int lane = threadIdx.x & 63;
     const int wave = HADI_UNIFORM((int)(threadIdx.x >> 6));
+    const int pair = wave / G, half = wave - pair * G;  // (G = 1: pair = wave, half = 0)
     const int total = a.n_inst * a.sblocks;
     const int logical = hadi_xcd_remap(blockIdx.x, gridDim.x);
     if (logical >= total) return;
@@ -1268,21 +1413,24 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     const HadiInstPar ip = a.ipar[inst];
     if (n > ip.N) return;
     const int nrows = a.L.nrows, npad = a.L.nrows_pad, rowp = a.L.rowp;
-    double *coef = reinterpret_cast<double *>(reinterpret_cast<T *>(smem) + (size_t)NWV * NS * rowp);
+    double *coef = reinterpret_cast<double *>(reinterpret_cast<T *>(smem) + (size_t)NPAIR * NS * rowp);
     {
-        const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B;
-        for (int e = threadIdx.x; e < 4 * 64 * B; e += 64 * NWV) coef[e] = sc[e];
+        const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B * G;
+        for (int e = threadIdx.x; e < 4 * 64 * B * G; e += 64 * NWV) coef[e] = sc[e];
     }
     // P representation: the payoff row (it depends on s only: v-row 0 of the packed payoff) behind the coefficient arrays;
     // re-read from LDS every row rather than held in 2 B registers per lane (that version spilled)
-    const double *payl = coef + 4 * 64 * B;
+    const double *payl = coef + 4 * 64 * B * G;
     if constexpr (AMER == 2) {
         const double *__restrict__ pg = a.U0 + (size_t)inst * a.L.inst_stride;
-        double *pw = coef + 4 * 64 * B;
+        double *pw = coef + 4 * 64 * B * G;
         for (int e = threadIdx.x; e < rowp; e += 64 * NWV) pw[e] = pg[e];
     }
+    if constexpr (G > 1) {  // the pairs' exchange buffers (values + rendezvous tokens, all zero: no row has token 0)
+        if (threadIdx.x < NPAIR * 16) coef[4 * 64 * B * G + threadIdx.x] = 0.0;
+    }
     __syncthreads();  // the only block-wide barrier: the coefficient arrays are shared
-    const int j0 = (sb * NWV + wave) * a.RS;
+    const int j0 = (sb * NPAIR + pair) * a.RS;
     if (j0 >= nrows) return;
     const int j1 = (j0 + a.RS < nrows) ? j0 + a.RS : nrows;
 
@@ -1290,6 +1438,8 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     c.lane = lane;
     c.rowp = rowp;
     c.coef = coef;
+    c.half = half;
+    c.xch = coef + 4 * 64 * B * G + pair * 16;
     c.dt = hadi_uniform_d(ip.dt); c.thdt = hadi_uniform_d(ip.thdt);
     c.qth = hadi_uniform_d(ip.thdt * ip.q);
     c.c2 = hadi_uniform_d(ip.thdt * ip.half_rd);
@@ -1310,41 +1460,58 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
         c.m1_r = (a.L.m1 - 1) - c.m1_lane * B;
     }
 
-    T *ring = reinterpret_cast<T *>(smem) + (size_t)wave * NS * rowp;
-    auto slot = [&](int jj) { return ring + (size_t)(jj & (NS - 1)) * rowp; };
+    T *ring = reinterpret_cast<T *>(smem) + (size_t)pair * NS * rowp;
+    auto slot = [&](int jj) { return ring + (size_t)(NS == 4 ? (jj & 3) : (jj + 12) % NS) * rowp; };  // (jj >= -4)
     // returns the number of vector-memory instructions issued (rows outside the allocation are zero-filled)
     auto fetch = [&](int jj) -> int {
         const bool exists = jj >= 0 && jj < npad;
-        hadi_row_to_lds_fixed<B, T>(Ub + (ptrdiff_t)jj * rowp, slot(jj), lane, exists);
-        return exists ? hadi_row_dma_count<T>(rowp) : 0;
+        if constexpr (G > 1) {
+            return hadi_half_row_to_lds<B, T>(Ub + (ptrdiff_t)jj * rowp, slot(jj), half, lane, exists);
+        } else {
+            hadi_row_to_lds_fixed<B, T>(Ub + (ptrdiff_t)jj * rowp, slot(jj), lane, exists);
+            return exists ? hadi_row_dma_count<T>(rowp) : 0;
+        }
     };
     // Direction of the walk: even strips go up (j0 -> j1-1), odd strips come down (j1-1 -> j0).  Neighbouring strips
     // then touch their shared halo rows at the same time -- both start there or both end there -- so the second reader
     // finds them in L2 instead of fetching them again ~100 us later (HBM reads of this pass 9.8 -> ~9 B per node).
     // Below, "behind" = rows already passed (registers), "ahead" = rows still to come (LDS ring / in flight); for a
     // descending strip the row-table scalars of the +1/+2 and -1/-2 neighbours simply swap roles.
-    const int dir = (((sb * NWV + wave) & 1) == 0) ? 1 : -1;
+    const int dir = (((sb * NPAIR + pair) & 1) == 0) ? 1 : -1;
     const int cnt = j1 - j0;
     const int js = dir > 0 ? j0 : j1 - 1;
     auto row_ok = [&](int jj) { return jj >= 0 && jj < npad; };
-    // ---- prologue: the next three rows ahead to the ring, the two rows behind and the first row to registers ----
+    // ---- prologue: the next rows ahead to the ring, the two rows behind and the first row to registers ----
+    // after0 = vector-memory instructions issued after the DMA of the row needed next (two ahead), after1 = ... after the
+    // DMA of the row after that (4-slot ring only: with 3 slots the row two ahead is the youngest DMA)
+    int after0 = 0, after1 = 0;
     fetch(js + dir);
-    fetch(js + 2 * dir);
-    int after0 = fetch(js + 3 * dir);  // vector-memory instructions issued after the DMA of the row needed next
-    int after1 = 0;                    // ... after the DMA of the row after that
+    if constexpr (NS == 4) {
+        fetch(js + 2 * dir);
+        after0 = fetch(js + 3 * dir);
+    } else {
+        fetch(js + 2 * dir);
+    }
     // rows behind by 2, behind by 1 (carried in the state's own type: with an fp32 state they are exact floats and cost
     // half the registers), current row (double: used throughout the step)
     T um2[B], um1[B];
     double u0[B];
     // The i = 0 column of the five stencil rows is wave-uniform: ONE register pair carries it, spread over the lanes
     // (lane k = row j - 2 + k in walking order), read with v_readlane where needed and shifted by a DPP move per step.
-    double c0vec;
+    // G = 2: the low half owns the i = 0 column; `evec` carries, the same way, the partner's node next to this half (the
+    // high half's first node for the low half and vice versa) on the rows behind / at / ahead of j (lanes 1, 2, 3).
+    double c0vec, evec = 0.0;
+    int epos = 0;
+    if constexpr (G > 1) {
+        const int inode = (half == 0) ? 64 * B + 1 : 64 * B;
+        epos = (sizeof(T) == 4) ? hadi_pos_f32(B, G, inode) : hadi_pos(B, G, inode);
+    }
     {
         double t2[B], t1[B];
 #pragma unroll
         for (int r = 0; r < B; r++) t2[r] = t1[r] = 0.0;
-        if (row_ok(js - 2 * dir)) hadi_get_block<B, 1, T>(Ub + (ptrdiff_t)(js - 2 * dir) * rowp, 0, lane, t2);
-        if (row_ok(js - dir)) hadi_get_block<B, 1, T>(Ub + (ptrdiff_t)(js - dir) * rowp, 0, lane, t1);
+        if (row_ok(js - 2 * dir)) hadi_get_block<B, G, T>(Ub + (ptrdiff_t)(js - 2 * dir) * rowp, half, lane, t2);
+        if (row_ok(js - dir)) hadi_get_block<B, G, T>(Ub + (ptrdiff_t)(js - dir) * rowp, half, lane, t1);
         if constexpr (AMER == 2) {  // U = max(P, U_0) on the rows behind (the current row keeps its raw P for lambda_bar)
             double pay[B];
             hadi_get_block<B, 1>(payl, 0, lane, pay);
@@ -1360,10 +1527,11 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
             um1[r] = (T)t1[r];
         }
     }
-    hadi_get_block<B, 1, T>(Ub + (size_t)js * rowp, 0, lane, u0);
+    hadi_get_block<B, G, T>(Ub + (size_t)js * rowp, half, lane, u0);
     {
         const int rr = js + (lane - 2) * dir;
-        c0vec = (lane < 4 && row_ok(rr)) ? (double)Ub[(ptrdiff_t)rr * rowp + c0slot] : 0.0;
+        c0vec = (half == 0 && lane < 4 && row_ok(rr)) ? (double)Ub[(ptrdiff_t)rr * rowp + c0slot] : 0.0;
+        if constexpr (G > 1) evec = (lane < 4 && row_ok(rr)) ? (double)Ub[(ptrdiff_t)rr * rowp + epos] : 0.0;
     }
 #if !defined(HADI_EMU)
     // Consume the prologue's register loads HERE: otherwise hipcc parks their s_waitcnt vmcnt(0) at the loop header,
@@ -1371,6 +1539,7 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
 #pragma unroll
     for (int r = 0; r < B; r++) asm volatile("" : "+v"(um2[r]), "+v"(um1[r]), "+v"(u0[r]));  // (T and double operands)
     asm volatile("" : "+v"(c0vec));
+    if constexpr (G > 1) asm volatile("" : "+v"(evec));
 #endif
 
 #if defined(HADI_STAMPS) && !defined(HADI_EMU)
@@ -1384,20 +1553,24 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
         HadiSRow srow;
         hadi_sload_issue(a.rowc + ((size_t)inst * nrows + j) * HADI_RC, srow);  // flies during the DMA wait
         hadi_wave_rendezvous();
-        // the row four ahead goes to the slot of row j: row j is in registers, and this wavefront's last read of that
+        // the row NS ahead goes to the slot of row j: row j is in registers, and this wavefront's last read of that
         // slot (the re-read in the previous step) has been retired there.  Issued BEFORE the wait below, so that the
         // prefetch does not queue behind it.
         int z = 0;
-        if (t + 4 <= cnt + 1) z = fetch(j + 4 * dir);
+        if (t + NS <= cnt + 1) z = fetch(j + NS * dir);
         hadi_wait_vmcnt(after0 + z);  // the row two ahead has landed (the row one ahead landed a step earlier)
         HADI_STAMPC(24);  // wait for the DMA
-        after0 = after1 + z;
-        after1 = 0;
+        if constexpr (NS == 4) {
+            after0 = after1 + z;
+            after1 = 0;
+        } else {
+            after0 = 0;
+        }
         hadi_wave_rendezvous();
         double up1[B], up2[B];
-        hadi_get_block<B, 1, T>(slot(j + dir), 0, lane, up1);
-        hadi_get_block<B, 1, T>(slot(j + 2 * dir), 0, lane, up2);
-        {
+        hadi_get_block<B, G, T>(slot(j + dir), half, lane, up1);
+        hadi_get_block<B, G, T>(slot(j + 2 * dir), half, lane, up2);
+        if (half == 0) {  // (wave-uniform; always true for G = 1)
             const double c0new = (double)slot(j + 2 * dir)[c0slot];  // (every lane reads the same word)
             c0vec = (lane == 4) ? c0new : c0vec;
         }
@@ -1438,10 +1611,22 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
             e0p1 = fmax(c0p1, pay_c0); e0p2 = fmax(c0p2, pay_c0);
         }
         double un[B];
-        if (j == nrows - 1) hadi_strip_step<B, AMER, true, T>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un);
-        else hadi_strip_step<B, AMER, false, T>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un);
-        after0 += B / 2;  // the row's vector stores (the i = 0 store is not counted: lower bound)
-        after1 += B / 2;
+        double xb_ = 0.0, x0_ = 0.0, xa_ = 0.0;  // the partner's boundary node on the rows behind / at / ahead (G = 2)
+        if constexpr (G > 1) {
+            xb_ = hadi_read_lane(evec, 1); x0_ = hadi_read_lane(evec, 2); xa_ = hadi_read_lane(evec, 3);
+        }
+        if (j == nrows - 1) hadi_strip_step<B, AMER, true, T, G>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_);
+        else hadi_strip_step<B, AMER, false, T, G>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_);
+        after0 += hadi_put_block_stores<B, T>();  // the row's vector stores (the i = 0 store is not counted: lower bound)
+        after1 += hadi_put_block_stores<B, T>();
+        double enew = 0.0;
+        if constexpr (G > 1) {
+            // The partner's boundary node of the row TWO ahead, from the partner's half of the ring slot.  Safe here and only
+            // here: the partner retired its DMA of that row before it published this step's token (which the exchange inside
+            // the step has just seen), and it refills that slot two steps on -- after the next exchange, which needs this
+            // wavefront's next token.
+            enew = (double)slot(j + 2 * dir)[epos];  // (every lane reads the same word)
+        }
 #pragma unroll
         for (int r = 0; r < B; r++) {
             um2[r] = um1[r];
@@ -1452,6 +1637,10 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the re-read is retired before the next step reuses that slot
 #endif
         c0vec = hadi_lane_next(c0vec);  // lane k takes lane k + 1: one row on
+        if constexpr (G > 1) {
+            evec = hadi_lane_next(evec);
+            evec = (lane == 3) ? enew : evec;
+        }
 #if defined(HADI_STAMPS) && !defined(HADI_EMU)
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev_) :: "memory");  // the step stamped itself
 #endif

@@ -128,6 +128,32 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
         if (L.B == 4 && p.RS >= 16 && p.RS <= 64 && sblk >= (long long)cus) p.use_strip = 1;
         if (tu.strip >= 0) p.use_strip = (tu.strip && p.RS >= 1 && p.RS <= 64) ? 1 : 0;
     }
+    // Paired strips (512 < m1 <= 1024, hadi_pass_a_strip<8, EU, T, 2>): 4 pairs of wavefronts per block, one strip per pair.
+    // Same round model as above; a paired row step costs more than a single-wavefront one (second right-hand side in the
+    // cyclic reduction, the pair rendezvous).  The caller keeps American and Craig-Sneyd sweeps on the shared ring.
+    if (L.B == 8 && L.G == 2) {
+        const int spb = HADI_STRIP_WAVES(L.B) / 2, ns = state_bytes == 8 ? 3 : 4;
+        const int cus = target_waves / 8 > 0 ? target_waves / 8 : 1;
+        int best_sb = 0;
+        double best_cost = 0.0;
+        for (int sb = 1; sb <= 8; sb++) {
+            const int rs = (L.nrows + spb * sb - 1) / (spb * sb);
+            if (rs < 8 || rs > 64) continue;
+            const long long blocks = (long long)n_inst * sb, rounds = (blocks + cus - 1) / cus;
+            const double cost = (double)rounds * (rs + 6);
+            if (!best_sb || cost < best_cost - 1e-9) { best_sb = sb; best_cost = cost; }
+        }
+        if (!best_sb && tu.strip == 1) { best_sb = 1; best_cost = 1e30; }  // forced (tests): one block of four short strips
+        if (best_sb) {
+            const double t_strip = best_cost * 3.3e-3, t_ring = 4.69e-6 * (double)n_inst * L.nrows + 0.012;  // ms
+            p.sblocks = best_sb;
+            p.RS = (L.nrows + spb * best_sb - 1) / (spb * best_sb);
+            p.grid_as = (int)(((long long)n_inst * p.sblocks + 7) / 8 * 8);
+            p.smem_as = (size_t)spb * ns * L.rowp * state_bytes + ((size_t)4 * 64 * L.B * L.G + (size_t)spb * 16) * sizeof(double);
+            p.use_strip = (t_strip < t_ring) ? 1 : 0;
+            if (tu.strip >= 0) p.use_strip = tu.strip ? 1 : 0;
+        }
+    }
     p.ctiles = (L.rowp + 63) / 64;
     // Column tiles per block.  The pitch is 64*B*G + pad, so an instance has nfull = B*G full tiles and one SHORT tile
     // (the pad columns: little traffic, but a whole solve -- about 0.3 of a full tile's time).  The full tiles are dealt

@@ -37,7 +37,11 @@ static void run_pass_a(const HadiPlan &pl, const HadiSweepArgs &a, int n, int mo
 }
 
 static int run_row_pass(const HadiPlan &pl, const HadiSweepArgs &a, int n, int mode) {
-    if (pl.use_strip && mode == 0) {  // same choice as hadi_api.hip
+    if (pl.use_strip && mode == 0 && pl.L.G == 2 && !a.american) {  // paired strips
+        emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<8, false, double, 2>(a, n); }, pl.smem_as);
+        return 0;
+    }
+    if (pl.use_strip && mode == 0 && pl.L.G == 1) {  // same choice as hadi_api.hip
         switch (pl.L.B * 2 + (a.american ? 1 : 0)) {
             case 16: emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<8, false>(a, n); }, pl.smem_as); break;
             case 17: emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<8, true>(a, n); }, pl.smem_as); break;
@@ -67,7 +71,9 @@ static void run_pass_a_f32(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
                 pl.smem_a - ring_elems * (sizeof(double) - sizeof(float)));
 }
 static int run_sweep_f32(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
-    if (pl.use_strip && pl.L.B == 8) {
+    if (pl.use_strip && pl.L.B == 8 && pl.L.G == 2) {
+        emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<8, false, float, 2>(a, n); }, pl.smem_as);
+    } else if (pl.use_strip && pl.L.B == 8) {
         emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<8, false, float>(a, n); },
                     (size_t)8 * 4 * pl.L.rowp * sizeof(float) + (size_t)4 * 64 * pl.L.B * sizeof(double));
     } else switch (pl.L.B * 10 + pl.L.G) {
@@ -90,7 +96,7 @@ static void run_pass_a_amp(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
                 pl.smem_a + (size_t)pl.L.rowp * sizeof(double));
 }
 static int run_sweep_amp(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
-    if (pl.use_strip) {  // same choice as hadi_api.hip
+    if (pl.use_strip && pl.L.G == 1) {  // same choice as hadi_api.hip
         const unsigned nt = 64 * HADI_STRIP_WAVES(pl.L.B);
         const size_t sm = pl.smem_as + (size_t)pl.L.rowp * sizeof(double);
         switch (pl.L.B) {

@@ -7,6 +7,7 @@
 // performance, parity claims and every shipped code path use the real gfx950 build.
 #pragma once
 #include <pthread.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <cmath>

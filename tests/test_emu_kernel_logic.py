@@ -150,6 +150,23 @@ def test_two_waves_per_row_split_solve(emu):
     _run(emu, 530, 10, 2, [100.0], O.AM, 8, r_f=0.01)
 
 
+def test_paired_strip_row_pass(emu):
+    # 512 < m1 <= 1024 on barrier-free strips: a PAIR of wavefronts walks each strip, one half of the row each (own LDS-DMA
+    # pieces, split tridiagonal solve with a 2x2 exchange and a pair rendezvous per row, the partner's boundary node carried
+    # from the partner's half of the ring).  41 rows -> 4 strips of 11 (ascending and descending, the last one short and
+    # carrying the b2 row); 3-slot ring (fp64 state) and 4-slot ring of floats (fp32 state); full width m1 = 1024; put data.
+    emu.emu_set_tuning(b"strip", 1)
+    try:
+        _run(emu, 600, 40, 3, [100.0, 93.0], O.EU, 1, r_f=0.01)
+        _run(emu, 1024, 20, 2, [100.0], O.EU, 1)
+        _run(emu, 700, 70, 2, [104.0], O.DIV, 1)          # 71 rows -> 4 strips of 18
+        _run(emu, 600, 40, 3, [100.0], O.EU, 1, scheme=2)  # fp32 state
+        _run(emu, 640, 30, 2, [100.0], O.EU, 1, put=True)
+        _run(emu, 530, 30, 2, [100.0], O.AM, 1)            # American stays on the shared ring
+    finally:
+        emu.emu_set_tuning(b"reset", 0)
+
+
 def test_craig_sneyd_predictor_corrector(emu):
     # solver.hpp:781-907: Douglas predictor + corrector re-adding dt/2 (A0 Y2 - A0 U); r_f != 0 exercises the b terms
     _run(emu, 40, 12, 3, [100.0, 91.0], O.EU, 8, r_f=0.01, scheme=1)
@@ -190,9 +207,14 @@ def test_plan_invariants_over_shapes_and_batch_sizes(emu):
                 if B >= 2 and G == 1:  # strips can be forced for any of these (hadi_set_tuning "strip"), so check them all
                     assert RS * nwv * sblocks >= nrows and grid_as >= n * sblocks
                     assert smem_as + rowp * 8 <= LDS
+                elif G == 2:  # paired strips: 4 pairs per block, 3 ring slots of doubles
+                    if use_strip:
+                        assert 8 <= RS <= 64 and RS * 4 * sblocks >= nrows and grid_as >= n * sblocks
+                        assert smem_as == 4 * 3 * rowp * 8 + (4 * 64 * B * G + 4 * 16) * 8 and smem_as <= LDS
+                        seen_strip.add(16)
                 else:
                     assert not use_strip
-                if use_strip:
+                if use_strip and G == 1:
                     assert B in (2, 4, 8) and (8 if B == 8 else 16) <= RS <= 64
                     seen_strip.add(B)
                 # column tiles: the blocks' ranges (hadi_pb_tile_range) partition [0, ctiles), none is empty
@@ -207,7 +229,7 @@ def test_plan_invariants_over_shapes_and_batch_sizes(emu):
                 if (m1, m2, n, tw) == (1024, 512, 64, 2048):  # config 5: 16 full tiles on 4 blocks, the short one appended
                     assert (btpw, bgroups) == (4, 4)
                 assert grid_b == (n * bgroups + 7) // 8 * 8 and smem_b <= LDS and P <= 16
-    assert seen_strip == {2, 4, 8}
+    assert seen_strip == {2, 4, 8, 16}
     assert emu.emu_plan_full(100, 101, 1, 8, o) == 0  # m2 > m1 is covered (two b1 entries on the v-rows k*m1)
     assert emu.emu_plan_full(1025, 100, 1, 8, o) != 0  # m1 too wide
     assert emu.emu_plan_full(600, 528, 1, 8, o) != 0  # more than 16 chunks

@@ -614,6 +614,42 @@ def test_strip_row_pass_theta_range(solver, forced_strips, theta):
     _assert_field(U, Uo)
 
 
+@pytest.mark.parametrize("fp32", [False, True])
+@pytest.mark.parametrize("variant,name", [(H.EU, "EU"), (H.DIV, "DIV")])
+@pytest.mark.parametrize("m1,m2,N,n", [(600, 40, 5, 2), (1024, 64, 4, 2), (700, 300, 4, 2), (1024, 512, 3, 1), (530, 37, 24, 3)])
+def test_paired_strip_row_pass_vs_oracle(solver, forced_strips, fp32, variant, name, m1, m2, N, n):
+    """512 < m1 <= 1024 on barrier-free strips: a pair of wavefronts per strip, half a row each (own LDS-DMA pieces and
+    counted waits, split tridiagonal solve with the 2x2 exchange and a pair rendezvous per row, the partner's boundary node
+    read from the partner's half of the ring).  Chosen by itself for large batches (config 5); forced here so that short,
+    ragged, ascending and descending strips, the 3-slot ring (fp64 state) and the 4-slot ring of floats meet the oracle."""
+    strikes = Cm.strikes_for(n)
+    grids, U0 = _batch(m1, m2, strikes)
+    U = U0.copy()
+    div = H.Dividends(*Cm.DIVS) if variant == H.DIV else None
+    solver.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U,
+                           variant=variant, dividends=div, state_precision=H.STATE_FP32 if fp32 else H.STATE_FP64)
+    assert ("hadi_pass_a_strip<8,EU,float,2>" if fp32 else "hadi_pass_a_strip<8,EU,double,2>") in solver.describe_last_sweep()
+    p = O.make_params(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA,
+                      O.DIV if variant == H.DIV else O.EU, Cm.DIVS if variant == H.DIV else None, state_fp32=1 if fp32 else 0)
+    Uo, _, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0)
+    if fp32:
+        _assert_field(U, Uo, rtol=2e-7 * N)
+    else:
+        _assert_field(U, Uo)
+
+
+def test_american_sweeps_of_wide_grids_stay_on_the_shared_ring(solver, forced_strips):
+    """The paired strips cover the European step; with strips forced an American sweep at m1 > 512 must still run (and
+    meet the oracle) on the shared-ring kernel."""
+    m1, m2, N, n = 600, 40, 5, 2
+    strikes = Cm.strikes_for(n)
+    grids, U0, U, lam = _hadi_solve(solver, m1, m2, N, strikes, H.AM, r_f=0.01, want_lambda=True)
+    assert "strip" not in solver.describe_last_sweep()
+    p = Cm.oracle_params(m1, m2, N, "AM", r_f=0.01)
+    Uo, lo, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0, want_lambda=True)
+    _assert_field(U, Uo)
+
+
 def test_strips_chosen_by_themselves_at_two_nodes_per_lane(solver):
     """64 < m1 <= 128 with several blocks per CU: the plan picks 4-strip blocks on its own (hadi_plan.h); 1100 instances
     of 128x64, a few steps, against the oracle."""
@@ -785,6 +821,9 @@ STRICT_CASES = [
     (200, 100, 6, 2, H.AM, {"strip": 0}, False),
     (100, 50, 6, 2, H.EU, {"strip": 0, "small_grid": 0}, False),
     (700, 300, 4, 1, H.EU, {}, True),
+    (700, 300, 4, 1, H.EU, {"strip": 1}, False),   # paired strips, 3-slot ring
+    (1024, 100, 4, 2, H.EU, {"strip": 1}, True),   # paired strips, 4-slot ring of floats
+    (1024, 512, 3, 1, H.EU, {"strip": 1}, False),
 ]
 
 
