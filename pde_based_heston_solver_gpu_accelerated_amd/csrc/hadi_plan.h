@@ -145,7 +145,9 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
         }
         if (!best_sb && tu.strip == 1) { best_sb = 1; best_cost = 1e30; }  // forced (tests): one block of four short strips
         if (best_sb) {
-            const double t_strip = best_cost * 3.3e-3, t_ring = 4.69e-6 * (double)n_inst * L.nrows + 0.012;  // ms
+            // measured at 1024x512 (fp64 state), ms per launch, strips / ring: 8 instances 0.067 / 0.034, 16: 0.068 / 0.051,
+            // 32: 0.071 / 0.085, 64: 0.127 / 0.143, 128: 0.254 / 0.309, 256: 0.498 / 0.562
+            const double t_strip = best_cost * 3.25e-3, t_ring = 4.3e-6 * (double)n_inst * L.nrows + 0.015;  // ms
             p.sblocks = best_sb;
             p.RS = (L.nrows + spb * best_sb - 1) / (spb * best_sb);
             p.grid_as = (int)(((long long)n_inst * p.sblocks + 7) / 8 * 8);

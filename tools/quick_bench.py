@@ -21,6 +21,8 @@ CASES = {
     "c5f64_g17": ["--workload", "c5", "--state", "fp64", "--tuning", "col_groups=17"], "c5f64_g3": ["--workload", "c5", "--state", "fp64", "--tuning", "col_groups=3"],
     "c5f64_r24": ["--workload", "c5", "--state", "fp64", "--tuning", "row_tile=24"], "c5f64_r64": ["--workload", "c5", "--state", "fp64", "--tuning", "row_tile=64"],
     "c5f64_r32": ["--workload", "c5", "--state", "fp64", "--tuning", "row_tile=32"],
+    **{"c5f64_%d%s" % (k, t): ["--workload", "c5", "--state", "fp64", "--instances", str(k), "--timesteps", "400", "--tuning", "strip=%d" % v]
+       for k in (8, 16, 32, 48, 64, 96, 128, 192, 256) for t, v in (("s", 1), ("r", 0))},
     "c2_g1": ["--workload", "c2", "--tuning", "col_groups=1"], "c2_g2": ["--workload", "c2", "--tuning", "col_groups=2"], "c2_g9": ["--workload", "c2", "--tuning", "col_groups=9"],
     "c2ring": ["--workload", "c2", "--tuning", "strip=0"], "c2am": ["--workload", "c3", "--m1", "512", "--m2", "256", "--timesteps", "1000", "--instances", "256"], "c5": ["--workload", "c5"], "c5f64": ["--workload", "c5", "--state", "fp64"], "c4": ["--workload", "c4"],
 }
