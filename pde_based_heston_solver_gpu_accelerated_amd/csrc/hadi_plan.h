@@ -166,15 +166,29 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
         const int nfull = L.rowp / 64, nshort = p.ctiles - nfull;
         const int cus = target_waves / 8 > 0 ? target_waves / 8 : 1;
         auto gfull_of = [&](int b) { return nfull > 0 ? (nfull + b - 1) / b : 1; };
-        auto cost = [&](int b) {
+        // own = the short tile gets a block of its own instead of riding with the last block
+        auto cost = [&](int b, bool own) {
             const int gf = gfull_of(b);
-            const double w_last = (double)(nfull - (gf - 1) * b) + 0.3 * nshort;
-            const double w = (gf > 1 && (double)b > w_last) ? (double)b : w_last;
-            const long long rounds = ((long long)n_inst * gf + cus - 1) / cus;
             // up to eight chunks the kernel holds three tiles in registers, all loaded up front; a fourth tile waits for a
             // free buffer (512x256 x256: 2 blocks of 4 and 4+short tiles 0.129 ms against 0.109 for 3 blocks of 3,3,2+short)
-            const double late = (L.P <= 8 && b > 3) ? 1.0 * (b - 3) : 0.0;
-            return (double)rounds * (w + (b < 2 ? 0.6 : 0.0) + late);
+            auto weight = [&](double tiles, int count) {
+                return tiles + (count < 2 ? 0.6 : 0.0) + ((L.P <= 8 && count > 3) ? 1.0 * (count - 3) : 0.0);
+            };
+            const int last_full = nfull - (gf - 1) * b;
+            // a launch that leaves half the CUs idle is bound by the latency of its longest block, not by traffic: there the
+            // short tile costs a whole tile time (512x256, ONE instance: 17.5 -> 24.8 ms per 1000 steps with it appended)
+            const double sw = (2ll * n_inst * (gf + (own ? 1 : 0)) <= cus) ? 1.0 : 0.3;
+            double w = gf > 1 ? weight((double)b, b) : 0.0;
+            if (own) {
+                const double wl = weight((double)last_full, last_full), ws = weight(sw, 1);
+                if (wl > w) w = wl;
+                if (ws > w) w = ws;
+            } else {
+                const double wl = weight(last_full + sw * nshort, last_full + nshort);
+                if (wl > w) w = wl;
+            }
+            const long long rounds = ((long long)n_inst * (gf + (own ? 1 : 0)) + cus - 1) / cus;
+            return (double)rounds * w;
         };
         // start from "about three blocks per CU in the launch" and move only to a split that needs fewer tile-rounds
         const int want_blocks = (3 * target_waves) / 8;  // target_waves = 8 per CU
@@ -183,9 +197,10 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
         if (groups > p.ctiles) groups = p.ctiles;
         int btpw = (p.ctiles + groups - 1) / groups;
         if (btpw > nfull && nfull > 0) btpw = nfull;
-        for (int b = 1; b <= nfull; b++)
-            if (cost(b) < cost(btpw) - 1e-9) btpw = b;
         bool own_short = false;
+        for (int b = 1; b <= nfull; b++)
+            for (int own = 0; own <= (nshort ? 1 : 0); own++)
+                if (cost(b, own != 0) < cost(btpw, own_short) - 1e-9) { btpw = b; own_short = own != 0; }
         // Up to four chunks (m2 <= 131) a block is at most 256 threads and two or more of them share a CU: blocks of ONE
         // tile then overlap each other better than tiles pipeline inside a block (measured, 256x128 x512 American:
         // 0.094 -> 0.083 ms per launch; 200x100 x700: 0.087 -> 0.084; 128x64 x2000: 0.070 -> 0.068); the short tile gets

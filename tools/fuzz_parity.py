@@ -14,7 +14,8 @@ cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 s = H.HestonADI(0)
 worst = 0.0
 for c in range(cases):
-    m1 = rng.choice([rng.randint(20, 64), rng.randint(65, 128), rng.randint(129, 256), rng.randint(257, 512), rng.randint(513, 800)])
+    m1 = rng.choice([rng.randint(20, 64), rng.randint(65, 128), rng.randint(129, 256), rng.randint(257, 512), rng.randint(513, 1024)])
+    if os.environ.get("FUZZ_WIDE"): m1 = rng.choice([rng.randint(513, 1024), 1024, 513])  # two wavefronts per row only
     m2 = rng.randint(8, 300) if rng.random() < 0.2 else rng.randint(8, min(m1, 300))  # (m2 > m1 now and then)
     N = rng.randint(2, 12)
     n = rng.choice([1, 2, 3, 5, 9, 40, 130, 300]) if m1 * m2 < 40000 else rng.choice([1, 2, 3, 5, 9, 70])
@@ -30,7 +31,7 @@ for c in range(cases):
     U, lam = U0.copy(), np.zeros_like(U0)
     div = H.Dividends(*Cm.DIVS) if variant in (H.DIV, H.AM_DIV) else None
     if rng.random() < 0.3: s.set_tuning("american_p", 0)
-    if rng.random() < 0.3: s.set_tuning("strip", 1)
+    if rng.random() < (0.7 if os.environ.get("FUZZ_WIDE") else 0.3): s.set_tuning("strip", 1)
     try:
         s.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, r_f, *model, grids, U, variant=variant, U_0=U0,
                           lambda_bar=lam if variant in (H.AM, H.AM_DIV) else None, dividends=div,
