@@ -165,6 +165,9 @@ int hadi_set_profiling(hadi_ctx *ctx, int enabled);
 int hadi_get_timing(const hadi_ctx *ctx, hadi_timing *out);
 /* Execution-path switches (results agree to round-off; the library reads NO environment variables):
  *   "small_grid"  LDS-resident one-launch path for grids that fit in LDS (default 1)
+ *   "small_seq"   ... European / dividend sweeps of such grids on the one-wavefront-per-instance kernel that solves the
+ *                 lines sequentially, one per lane: -1 automatic (default: batches of at least 4 instances per CU), 0 never
+ *                 (the block-per-instance kernel, which the American sweeps always use), 1 always
  *   "graph"       hipGraph replay of the time loop for small batches (default 1)
  *   "american_p"  American sweeps keep P = U_bar - dt*lambda_bar in place of U and no lambda_bar array whenever every
  *                 payoff of the batch depends on s only (default 1; 0 = always the explicit (U, lambda_bar) pair)

@@ -47,6 +47,7 @@ struct Ctx {
     unsigned long long graph_clock = 0;
     int use_graph = 1;
     int use_small = 1;  // LDS-resident one-launch path for small grids
+    int small_seq = -1;  // ... European / dividend sweeps on the one-wavefront-per-instance kernel: -1 by batch size, 0 never, 1 always
     int use_amp = 1;    // American sweeps without the lambda_bar array when the payoff depends on s only
     int device_vgrid = 1;  // compute_base_prices / compute_jacobian: v-grids rebuilt per instance on the device
     int sub_batch = 1;     // large batches run sub-batch by sub-batch (run_sweep)
@@ -212,6 +213,8 @@ hipError_t raise_all_lds_limits() {
     if ((e = raise_lds_limit(hadi_pass_a_strip<8, 2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_a_strip<4, 2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_a_strip<2, 2>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_small_seq_kernel<1>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_small_seq_kernel<2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_kernel<1, 4, false>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_kernel<1, 4, true>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_kernel<2, 4, false>)) != hipSuccess) return e;
@@ -566,11 +569,20 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
 
     // ---- small grids: the whole instance fits in LDS -> one launch runs the entire time loop ----------
     const size_t smem_small = american ? pl.smem_small_am : pl.smem_small_eu;
+    // European / dividend sweeps: one wavefront per instance with sequential line solves (hadi_small_seq_kernel) issues ~40 %
+    // fewer instructions per instance and step but runs them on ONE wavefront -- ahead once the batch oversubscribes the CUs
+    // (50x25: 3000 instances x 50 steps 3.79 -> 2.66 ms), behind while it does not (500 x 20 steps: 0.41 -> 0.47 ms; a single
+    // instance: 10 -> 17 us per step).  "small_seq" = 1 forces it, 0 forbids it, -1 (default) picks by batch size.
+    const bool seq = takes_small_path && !american && (c->small_seq > 0 || (c->small_seq < 0 && d.n >= 4 * c->cu_count));
+    const size_t smem_seq = (size_t)hadi_small_seq_layout(L.m1, L.nrows).total * sizeof(double);
     if (takes_small_path) {
         {
-            char buf[160];
-            std::snprintf(buf, sizeof buf, "hadi_small_kernel<%d,%d,%s>: whole time loop in one launch, instance resident in LDS (%zu B)", L.B,
-                          (c->tune.small_waves ? c->tune.small_waves : (d.n <= 2 * c->cu_count ? 8 : 4)) == 8 ? 8 : 4, american ? "AM" : "EU", smem_small);
+            char buf[192];
+            if (seq)
+                std::snprintf(buf, sizeof buf, "hadi_small_seq_kernel<%d>: whole time loop in one launch, one wavefront per instance, lines solved sequentially in LDS (%zu B)", L.B, smem_seq);
+            else
+                std::snprintf(buf, sizeof buf, "hadi_small_kernel<%d,%d,%s>: whole time loop in one launch, instance resident in LDS (%zu B)", L.B,
+                              (c->tune.small_waves ? c->tune.small_waves : (d.n <= 2 * c->cu_count ? 8 : 4)) == 8 ? 8 : 4, american ? "AM" : "EU", smem_small);
             c->last_path = buf;
         }
         HadiSmallArgs sm;
@@ -596,7 +608,10 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         // dependent per-step phases; more waves share the rows of the row pass)
         // (measured, 50x25 grid: 1 instance x 100 steps 1.27 -> 1.04 ms with 8; 3000 instances x 50 steps 4.19 -> 4.58 ms)
         const int sw = c->tune.small_waves ? c->tune.small_waves : (d.n <= 2 * c->cu_count ? 8 : 4);
-        if (sw == 8) {
+        if (seq) {
+            if (L.B == 1) hipLaunchKernelGGL((hadi_small_seq_kernel<1>), dim3(d.n), dim3(64), smem_seq, s, a, sm);
+            else hipLaunchKernelGGL((hadi_small_seq_kernel<2>), dim3(d.n), dim3(64), smem_seq, s, a, sm);
+        } else if (sw == 8) {
             if (L.B == 1) {
                 if (american) hipLaunchKernelGGL((hadi_small_kernel<1, 8, true>), dim3(d.n), dim3(512), smem_small, s, a, sm);
                 else hipLaunchKernelGGL((hadi_small_kernel<1, 8, false>), dim3(d.n), dim3(512), smem_small, s, a, sm);
@@ -1150,6 +1165,7 @@ int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value) {
     if (!c || !key) return HADI_ERR_INVALID;
     if (!std::strcmp(key, "graph")) c->use_graph = value ? 1 : 0;
     else if (!std::strcmp(key, "small_grid")) c->use_small = value ? 1 : 0;
+    else if (!std::strcmp(key, "small_seq")) c->small_seq = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "american_p")) c->use_amp = value ? 1 : 0;
     else if (!std::strcmp(key, "device_vgrid")) c->device_vgrid = value ? 1 : 0;
     else if (!std::strcmp(key, "sub_batch")) c->sub_batch = value ? 1 : 0;
@@ -1168,6 +1184,7 @@ int hadi_get_tuning(const hadi_ctx *ctx, const char *key, int *value) {
     if (!c || !key || !value) return HADI_ERR_INVALID;
     if (!std::strcmp(key, "graph")) *value = c->use_graph;
     else if (!std::strcmp(key, "small_grid")) *value = c->use_small;
+    else if (!std::strcmp(key, "small_seq")) *value = c->small_seq;
     else if (!std::strcmp(key, "american_p")) *value = c->use_amp;
     else if (!std::strcmp(key, "device_vgrid")) *value = c->device_vgrid;
     else if (!std::strcmp(key, "sub_batch")) *value = c->sub_batch;

@@ -2297,6 +2297,241 @@ __global__ void __launch_bounds__(64 * W) hadi_small_kernel(HadiSweepArgs a, Had
 }
 
 // ------------------------------------------------------------------------------------------------
+// Small grids, European / dividend sweeps: ONE wavefront per instance, lines solved SEQUENTIALLY, one line per lane.
+// The kernel above runs the big-grid row step on 51-node rows: a whole wavefront and six cyclic-reduction levels (54
+// ds_bpermute, ~400 instructions) per row -- at one node per lane almost all of it is overhead, and 26 rows x 8
+// wavefronts cost ~10 us per time step.  Here the roles are turned round, as in the reference's own team kernels
+// (hes_a1_kernels.hpp:139-161, one thread per v-row; hes_a2_shuffled_kernels.hpp:243-299, one thread per s-column):
+//   row pass     lane j <-> v-row j (nrows <= 33 lanes busy) walks i = 1 .. m1: explicit operators from a sliding window of
+//                three columns (five new LDS values per node), Y0, forward Thomas with the pivot recomputed on the fly; the
+//                back substitution walks i = m1 .. 1.  No cross-lane traffic at all.
+//   column pass  lane i <-> s-column i: pentadiagonal forward / backward sweep with the precomputed factors.
+// State in LDS in NATURAL order, pitch odd (conflict-free both ways): U (two zero halo rows above and below) and Y.  The
+// forward sweep needs three values per node for the way back (the normalised right-hand side, the multiplier c', and the
+// explicit A2 correction of the output) but only two arrays exist: the output is rewritten as
+//   Y_i = x_i + corr_i = (ys_i + corr_i + c'_i corr_{i+1}) - c'_i Y_{i+1} = g_i - c'_i Y_{i+1},
+// g_i goes to Y, and c'_i goes to column i-1 of U's own row -- every lane is at the same i (one wavefront), so that column
+// has been consumed by all of them.  The column pass rebuilds U completely.  ~45 instructions per node against ~10 x that.
+struct HadiSmallSeqLayout {
+    int pitch;     // doubles per row in LDS: odd, >= m1 + 2 (column m1 + 1 stays zero: the s-neighbour of the last node)
+    int off_y, off_coef, off_b2, off_ptab, total;  // offsets in doubles: U starts at 0 with (nrows + 4) rows
+};
+HADI_HD inline HadiSmallSeqLayout hadi_small_seq_layout(int m1, int nrows) {
+    HadiSmallSeqLayout l;
+    l.pitch = (m1 + 2) | 1;
+    l.off_y = (nrows + 4) * l.pitch;
+    l.off_coef = l.off_y + nrows * l.pitch;
+    l.off_coef = (l.off_coef + 1) & ~1;  // 16-byte aligned quads
+    l.off_b2 = l.off_coef + 4 * (m1 + 2);
+    l.off_ptab = l.off_b2 + (m1 + 2);
+    l.total = l.off_ptab + nrows * 5;
+    return l;
+}
+
+template <int B>
+__global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, HadiSmallArgs sm) {
+    HADI_DYN_SMEM(double, smem);
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= a.n_inst) return;
+    const int inst = sm.order ? sm.order[blockIdx.x] : (int)blockIdx.x;
+    const HadiInstPar ip = a.ipar[inst];
+    const int nrows = a.L.nrows, rowp = a.L.rowp, m1 = a.L.m1;
+    const HadiSmallSeqLayout Ls = hadi_small_seq_layout(m1, nrows);
+    const int PL = Ls.pitch;
+    double *Ul = smem + 2 * PL;  // row 0 of U
+    double *Yl = smem + Ls.off_y;
+    double *coefl = smem + Ls.off_coef;  // [i][4]: Bm, Bp, Dm, Dp of node i
+    double *b2l = smem + Ls.off_b2;
+    double *ptab = smem + Ls.off_ptab;   // [k][5]: L, L2, Q, C, C2
+    double *__restrict__ Ug = a.U + (size_t)inst * a.L.inst_stride;
+
+    for (int e = lane; e < Ls.total; e += 64) smem[e] = 0.0;
+    __syncthreads();
+    for (int e = lane; e < nrows * (m1 + 1); e += 64) {
+        const int j = e / (m1 + 1), i = e - j * (m1 + 1);
+        Ul[j * PL + i] = Ug[(size_t)j * rowp + hadi_pos(B, 1, i)];
+    }
+    {
+        const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B;
+        for (int e = lane; e < 4 * (m1 + 1); e += 64) {
+            const int i = e >> 2, k = e & 3;
+            coefl[e] = (i >= 1) ? sc[k * 64 * B + hadi_pos(B, 1, i)] : 0.0;
+        }
+        const double *__restrict__ b2g = a.b2row + (size_t)inst * rowp;
+        for (int i = lane; i <= m1; i += 64) b2l[i] = b2g[hadi_pos(B, 1, i)];
+        const double *__restrict__ pg = a.pb + (size_t)inst * a.L.nrows_pad * HADI_PBW;
+        for (int e = lane; e < nrows * 5; e += 64) ptab[e] = pg[(e / 5) * HADI_PBW + e % 5];
+    }
+    // this lane's v-row: its table entry stays in registers for the whole time loop
+    const int j = lane;
+    const bool act = j < nrows;
+    const bool last = (j == nrows - 1);
+    double v = 0.0, wm = 0.0, wz = 0.0, wp = 0.0, a2l2 = 0.0, a2l1 = 0.0, a2m = 0.0, a2u1 = 0.0, a2u2 = 0.0, b1val = 0.0;
+    int b1col = -1;
+    bool b1_at0 = false;
+    if (act) {
+        const double *__restrict__ rc = a.rowc + ((size_t)inst * nrows + j) * HADI_RC;
+        v = rc[RC_V]; wm = rc[RC_WM]; wz = rc[RC_WZ]; wp = rc[RC_WP];
+        a2l2 = rc[RC_L2]; a2l1 = rc[RC_L1]; a2m = rc[RC_M]; a2u1 = rc[RC_U1]; a2u2 = rc[RC_U2];
+        b1val = rc[RC_B1VAL];
+        const int b1raw = (int)rc[RC_B1COL];
+        b1_at0 = b1raw == 0 || b1raw >= HADI_B1_BOTH;  // (two entries on one v-row: m2 > m1 only)
+        b1col = b1raw >= HADI_B1_BOTH ? b1raw - HADI_B1_BOTH : b1raw;
+    }
+    const double dt = ip.dt, thdt = ip.thdt, qd = ip.q, half_rd = ip.half_rd;
+    const double inv0 = 1.0 / (1.0 + ip.thdt * ip.hr0);
+    const double *urow = Ul + (act ? j : 0) * PL;  // (idle lanes walk row 0 and store nothing)
+    double *yrow = Yl + (act ? j : 0) * PL;
+    double *crow = Ul + (act ? j : 0) * PL;        // column i - 1 of this row receives c'_i
+    __syncthreads();
+
+    const int N = ip.N < sm.Nmax ? ip.N : sm.Nmax;
+    const double *__restrict__ vs = sm.vec_s ? sm.vec_s + (size_t)inst * (m1 + 1) : nullptr;
+    for (int n = 1; n <= N; n++) {
+        // ---- discrete dividend at the start of the step (device_solver.hpp:448-504) ---------------
+        const int dv = sm.div_flag ? sm.div_flag[(size_t)inst * sm.flag_stride + n - 1] : -1;
+        if (dv >= 0) {
+            for (int e = lane; e < nrows * PL; e += 64) Yl[e] = Ul[e];  // U_temp
+            __syncthreads();
+            const double amount = sm.div_amounts[dv], pct = sm.div_pcts[dv];
+            for (int e = lane; e < nrows * (m1 + 1); e += 64) {
+                const int jj = e / (m1 + 1), i = e - jj * (m1 + 1);
+                const double *src = Yl + jj * PL;
+                const double new_s = vs[i] * (1.0 - pct) - amount;
+                double out = ip.put ? src[0] : 0.0;  // ex-dividend spot <= 0: a call is worth 0 (device_solver.hpp:499-503), a put its s = 0 value
+                if (new_s > 0) {
+                    int lo = 0, hi = m1 + 1;  // first k with s[k] > new_s (0 if none)
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (vs[mid] > new_s) hi = mid;
+                        else lo = mid + 1;
+                    }
+                    const int idx = (lo <= m1) ? lo : 0;
+                    if (idx > 0) {
+                        const double s_low = vs[idx - 1], s_high = vs[idx];
+                        const double weight = (new_s - s_low) / (s_high - s_low);
+                        out = (1.0 - weight) * src[idx - 1] + weight * src[idx];
+                    } else {
+                        out = src[0];
+                    }
+                }
+                Ul[jj * PL + i] = out;
+            }
+            __syncthreads();
+        }
+        const double e_nm1 = exp(ip.bc_rate * ip.dt * (n - 1));  // device_solver.hpp:238
+        const double e_n = exp(ip.bc_rate * ip.dt * n);          // device_solver.hpp:246
+        const double cb1 = dt * e_nm1 + thdt * (e_n - e_nm1);
+        const double b1l = b1val * cb1;
+        // ---- row pass: lane <-> v-row, i = 1 .. m1 (same formulas as hadi_row_step) --------------------------------
+        // column i = 0 (A0 and A1 rows are zero there; only A2 and the boundary act)
+        const double c0m2 = urow[-2 * PL], c0m1 = urow[-PL], c00 = urow[0], c0p1 = urow[PL], c0p2 = urow[2 * PL];
+        // first interior column, raw: rows j-2 .. j+2
+        double r_m2 = urow[-2 * PL + 1], r_m1 = urow[-PL + 1], r_0 = urow[1], r_p1 = urow[PL + 1], r_p2 = urow[2 * PL + 1];
+        double yout_c0, x0;
+        {
+            const double a2c0 = a2l2 * c0m2 + a2l1 * c0m1 + a2m * c00 + a2u1 * c0p1 + a2u2 * c0p2;
+            const double b1c0 = b1_at0 ? b1val : 0.0;
+            const double b2c0 = last ? b2l[0] : 0.0;
+            const double a1c0 = -ip.hr0 * c00;  // A1 row 0: empty for the call (hr0 = 0), the reaction term for the put
+            double y0c0 = c00 + dt * (a2c0 + a1c0 + (b1c0 + b2c0) * e_nm1);
+            y0c0 = y0c0 + thdt * (b1c0 * e_n - (a1c0 + b1c0 * e_nm1));
+            const double c2c0 = thdt * (b2c0 * e_n - (a2c0 + b2c0 * e_nm1));
+            x0 = y0c0 * inv0;  // A1 row 0 is decoupled: the identity for the call (hes_a1_kernels.hpp:56-61)
+            yout_c0 = x0 + c2c0;
+        }
+        hadi_wave_rendezvous();  // (emulator: everyone has read column 0 and 1 before c' overwrites column 0)
+        double u_prev = c00, u_cur = r_0;
+        double t_prev = wm * c0m1 + wz * c00 + wp * c0p1;
+        double t_cur = wm * r_m1 + wz * r_0 + wp * r_p1;
+        double a2u_cur = fma(a2u2, r_p2, fma(a2l2, r_m2, a2l1 * r_m1 + a2m * r_0 + a2u1 * r_p1));
+        double b2c = last ? b2l[1] : 0.0;
+        double corr_cur = thdt * (b2c * e_n - (a2u_cur + b2c * e_nm1));
+        // raw values of column 2 (column m1 + 1 is the zero spare)
+        r_m2 = urow[-2 * PL + 2]; r_m1 = urow[-PL + 2]; r_0 = urow[2]; r_p1 = urow[PL + 2]; r_p2 = urow[2 * PL + 2];
+        double cp_prev = 0.0, ys_prev = 0.0;
+        for (int i = 1; i <= m1; i++) {
+            // column i + 1 (fetched one step ahead), then the fetch of column i + 2
+            const double u_next = r_0;
+            const double t_next = wm * r_m1 + wz * r_0 + wp * r_p1;
+            const double a2u_next = fma(a2u2, r_p2, fma(a2l2, r_m2, a2l1 * r_m1 + a2m * r_0 + a2u1 * r_p1));
+            const int inx = (i + 2 <= m1 + 1) ? i + 2 : m1 + 1;
+            r_m2 = urow[-2 * PL + inx]; r_m1 = urow[-PL + inx]; r_0 = urow[inx]; r_p1 = urow[PL + inx]; r_p2 = urow[2 * PL + inx];
+            const double2 cB = *reinterpret_cast<const double2 *>(coefl + 4 * i);      // Bm, Bp
+            const double2 cD = *reinterpret_cast<const double2 *>(coefl + 4 * i + 2);  // Dm, Dp
+            const double lo = fma(v, cD.x, qd * cB.x);
+            const double up = fma(v, cD.y, qd * cB.y);
+            const double mn = -((lo + up) + half_rd);
+            const double A1U = lo * u_prev + mn * u_cur + up * u_next;
+            const double A0U = cB.x * t_prev - (cB.x + cB.y) * t_cur + cB.y * t_next;
+            // Y0 = U + dt (A0U + A1U + A2U + b e_{n-1}) + theta dt (b1 e_n - (A1U + b1 e_{n-1})), device_solver.hpp:236-250
+            double S = A0U + A1U + a2u_cur;
+            S += b2c * e_nm1;
+            double y = fma(dt, S, u_cur);
+            y = fma(-thdt, A1U, y);
+            y += (i == b1col) ? b1l : 0.0;
+            double il = -thdt * lo;
+            const double im = 1.0 - thdt * mn;
+            const double iu = -thdt * up;
+            if (i == 1) {  // x_0 is known: move it to the right-hand side
+                y -= il * x0;
+                il = 0.0;
+            }
+            const double inv = hadi_rcp(fma(-il, cp_prev, im));
+            const double cp = iu * inv;
+            const double ys = fma(-il, ys_prev, y) * inv;
+            const double b2n = (last && i < m1) ? b2l[i + 1] : 0.0;
+            const double corr_next = thdt * (b2n * e_n - (a2u_next + b2n * e_nm1));
+            if (act) {
+                yrow[i] = ys + corr_cur + cp * corr_next;  // g_i  (c'_{m1} = 0: the row ends there)
+                crow[i - 1] = cp;
+            }
+            u_prev = u_cur; u_cur = u_next;
+            t_prev = t_cur; t_cur = t_next;
+            a2u_cur = a2u_next; corr_cur = corr_next; b2c = b2n;
+            cp_prev = cp; ys_prev = ys;
+            hadi_wave_rendezvous();  // (emulator: the lanes walk in lock step on the GPU)
+        }
+        // back substitution on the output itself: Y_i = g_i - c'_i Y_{i+1}
+        if (act) {
+            double Yn = yrow[m1];
+            for (int i = m1 - 1; i >= 1; i--) {
+                Yn = fma(-crow[i - 1], Yn, yrow[i]);
+                yrow[i] = Yn;
+            }
+            yrow[0] = yout_c0;
+        }
+        __syncthreads();
+        // ---- column pass: lane <-> s-column, sequential pentadiagonal sweeps (hes_a2_shuffled_kernels.hpp:243-299) ----
+        // (measured and left out, 50x25 x3000: fetching a node's coefficients one iteration ahead 2.64 -> 2.72 ms; the column
+        // held in 33 registers with all loads up front 2.64 -> 2.88 ms)
+        for (int col = lane; col <= m1; col += 64) {
+            double ym1 = 0.0, ym2 = 0.0;
+            for (int k = 0; k < nrows; k++) {
+                const double *t = ptab + k * 5;
+                const double yk = (Yl[k * PL + col] - t[PB_L] * ym1 - t[PB_L2] * ym2) * t[PB_Q];
+                Yl[k * PL + col] = yk;
+                ym2 = ym1;
+                ym1 = yk;
+            }
+            double xp1 = 0.0, xp2 = 0.0;
+            for (int k = nrows - 1; k >= 0; k--) {
+                const double *t = ptab + k * 5;
+                const double xk = Yl[k * PL + col] - t[PB_C] * xp1 - t[PB_C2] * xp2;
+                xp2 = xp1;
+                xp1 = xk;
+                Ul[k * PL + col] = xk;
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = lane; e < nrows * (m1 + 1); e += 64) {
+        const int jj = e / (m1 + 1), i = e - jj * (m1 + 1);
+        Ug[(size_t)jj * rowp + hadi_pos(B, 1, i)] = Ul[jj * PL + i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Setup: one block per instance builds all operator tables (replaces bounds.initialize and the three
 // build_matrix calls at the top of every reference launcher, e.g. jacobian_computation.cpp:255-261).
 struct HadiSetupArgs {

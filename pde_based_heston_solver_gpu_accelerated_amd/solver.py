@@ -106,7 +106,7 @@ class HestonADI:
         self._lib.hadi_set_profiling(self._h, 1 if enabled else 0)
 
     def set_tuning(self, key, value):
-        """Execution-path switch (hadi.h: 'small_grid', 'graph', 'american_p', 'strip', 'row_tile', 'col_groups',
+        """Execution-path switch (hadi.h: 'small_grid', 'small_seq', 'graph', 'american_p', 'strip', 'row_tile', 'col_groups',
         'small_waves', 'device_vgrid'); results agree to round-off."""
         rc = self._lib.hadi_set_tuning(self._h, key.encode(), int(value))
         if rc != nat.HADI_OK:

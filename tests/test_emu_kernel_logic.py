@@ -184,6 +184,19 @@ def test_small_grid_lds_resident_kernel(emu):
     _run(emu, 100, 30, 3, [96.0], O.EU, 8, r_f=0.01, small=2)
 
 
+def test_small_grid_sequential_kernel(emu):
+    # European / dividend sweeps of LDS-resident grids: one wavefront per instance, lane <-> v-row in the row pass (sequential
+    # Thomas, c' parked in the consumed columns of U), lane <-> s-column in the column pass.  One and two nodes per lane in
+    # the packed layout (m1 <= 64 / <= 128), r_f != 0, dividends, put data, more v-nodes than s-nodes, two column rounds.
+    _run(emu, 50, 25, 6, [100.0, 91.0], O.EU, 8, small=3)
+    _run(emu, 50, 25, 24, [100.0], O.DIV, 8, r_f=0.01, small=3)
+    _run(emu, 100, 30, 3, [96.0], O.EU, 8, r_f=0.01, small=3)
+    _run(emu, 64, 32, 3, [100.0], O.EU, 8, small=3)
+    _run(emu, 20, 25, 4, [100.0], O.EU, 8, r_f=0.02, small=3)
+    _run(emu, 50, 25, 5, [100.0], O.EU, 8, small=3, put=True)
+    _run(emu, 40, 12, 24, [105.0], O.DIV, 8, small=3, put=True)
+
+
 def test_plan_invariants_over_shapes_and_batch_sizes(emu):
     """Host logic (hadi_plan.h): for every supported shape and a range of batch sizes the launch geometry covers all rows,
     columns and instances, and every kernel's dynamic LDS fits the 160 KB of a CU (incl. the payoff row the American P

@@ -166,14 +166,16 @@ def test_small_grid_kernel_and_streaming_kernels_agree(solver, variant, name):
     m1, m2, N, strikes = 50, 25, 20, Cm.strikes_for(6)
     p = Cm.oracle_params(m1, m2, N, name)
     fields = []
-    for small, graph in ((1, 1), (0, 1), (0, 0)):
+    for small, graph, seq in ((1, 1, 1), (0, 1, 1), (0, 0, 1), (1, 1, 0)):
         solver.set_tuning("small_grid", small)
         solver.set_tuning("graph", graph)
+        solver.set_tuning("small_seq", seq)  # (European / dividends: sequential one-wavefront kernel or the block kernel)
         try:
             grids, U0, U, lam = _hadi_solve(solver, m1, m2, N, strikes, variant, want_lambda=variant in (H.AM, H.AM_DIV))
         finally:
             solver.set_tuning("small_grid", 1)
             solver.set_tuning("graph", 1)
+            solver.set_tuning("small_seq", -1)
         fields.append((U, lam))
     Uo, lamo, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0, want_lambda=True)
     for U, lam in fields:
@@ -181,6 +183,7 @@ def test_small_grid_kernel_and_streaming_kernels_agree(solver, variant, name):
         if lamo is not None:
             assert np.abs(lam - lamo).max() <= 1e-8 * max(1.0, np.abs(lamo).max())
     assert np.abs(fields[0][0] - fields[1][0]).max() <= 1e-11 * np.abs(Uo).max()
+    assert np.abs(fields[0][0] - fields[3][0]).max() <= 1e-11 * np.abs(Uo).max()
     assert np.array_equal(fields[1][0], fields[2][0])  # graph replay == direct launches, bit for bit
 
 
@@ -765,18 +768,51 @@ def test_fp32_state_restrictions(solver):
         assert e.value.status == 2  # HADI_ERR_UNSUPPORTED
 
 
-def test_small_grid_kernel_on_a_batch_larger_than_two_per_cu(solver):
-    """More than 2 instances per CU -> 4 wavefronts per instance (throughput shape of the LDS-resident kernel); small
-    batches (every other small-grid test) run 8 per instance.  Per-instance maturities exercise the dispatch order."""
+@pytest.mark.parametrize("put", [False, True])
+@pytest.mark.parametrize("variant,name", [(H.EU, "EU"), (H.DIV, "DIV")])
+@pytest.mark.parametrize("m1,m2,N,n", [(50, 25, 24, 5), (25, 20, 20, 3), (100, 25, 6, 2), (128, 26, 5, 2), (64, 32, 7, 3), (20, 25, 9, 2), (65, 8, 24, 4)])
+def test_small_grid_sequential_kernel_vs_oracle(solver, put, variant, name, m1, m2, N, n):
+    """hadi_small_seq_kernel (one wavefront per instance; lane <-> v-row in the row pass, lane <-> s-column in the column
+    pass) on the LDS-resident shapes: one and two nodes per packed lane, two and three column rounds (m1 > 63), m2 > m1, the
+    full 33 v-rows, dividends, put boundary data, r_f != 0 -- full field against the oracle."""
+    strikes = Cm.strikes_for(n)
+    grids, U0 = _batch(m1, m2, strikes)
+    if put:
+        U0 = grids.put_payoff(strikes)
+    U = U0.copy()
+    div = H.Dividends(*Cm.DIVS) if variant == H.DIV else None
+    solver.set_tuning("small_seq", 1)  # (chosen by itself from 4 instances per CU on)
+    try:
+        solver.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U,
+                               variant=variant, dividends=div, option_type=H.PUT if put else H.CALL, strikes=strikes if put else None)
+    finally:
+        solver.set_tuning("small_seq", -1)
+    assert "hadi_small_seq_kernel" in solver.describe_last_sweep()
+    p = O.make_params(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA,
+                      O.DIV if variant == H.DIV else O.EU, Cm.DIVS if variant == H.DIV else None,
+                      option_type=O.PUT if put else O.CALL, strikes=np.array(strikes) if put else None)
+    Uo, _, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0)
+    _assert_field(U, Uo)
+
+
+@pytest.mark.parametrize("seq", [1, 0])
+def test_small_grid_kernel_on_a_batch_larger_than_two_per_cu(solver, seq):
+    """A batch of several instances per CU with per-instance maturities (dispatch order: longest time loops first) on both
+    LDS-resident kernels: the one-wavefront-per-instance sequential kernel (default for European / dividend sweeps) and the
+    block-per-instance kernel (more than 2 instances per CU -> 4 wavefronts per instance, its throughput shape)."""
     m1, m2, n = 50, 25, 640
     strikes = Cm.strikes_for(n)
     Ns = [4 + (k % 5) for k in range(n)]
     per = {"N_i": Ns, "delta_t_i": [0.5 / N for N in Ns]}
     grids, U0 = _batch(m1, m2, strikes)
     U = U0.copy()
-    solver.DO_timestepping(m1, m2, 1, 1.0, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U,
-                           per_instance=per)
-    assert "hadi_small_kernel<1,4,EU>" in solver.describe_last_sweep()
+    solver.set_tuning("small_seq", seq)
+    try:
+        solver.DO_timestepping(m1, m2, 1, 1.0, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U,
+                               per_instance=per)
+    finally:
+        solver.set_tuning("small_seq", -1)
+    assert ("hadi_small_seq_kernel<1>" if seq else "hadi_small_kernel<1,4,EU>") in solver.describe_last_sweep()
     for N in sorted(set(Ns)):
         rows = np.array([k for k in range(n) if Ns[k] == N])
         p = O.make_params(m1, m2, N, 0.5 / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA)
@@ -786,7 +822,11 @@ def test_small_grid_kernel_on_a_batch_larger_than_two_per_cu(solver):
 
 def test_describe_last_sweep_names_the_kernels(solver):
     _hadi_solve(solver, 50, 25, 4, [100.0], H.EU)
-    assert "hadi_small_kernel" in solver.describe_last_sweep()
+    assert "hadi_small_kernel<1,8,EU>" in solver.describe_last_sweep()
+    _hadi_solve(solver, 50, 25, 2, Cm.strikes_for(1100), H.EU)   # at least 4 instances per CU: one wavefront per instance
+    assert "hadi_small_seq_kernel<1>" in solver.describe_last_sweep()
+    _hadi_solve(solver, 50, 25, 2, Cm.strikes_for(1100), H.AM)
+    assert "hadi_small_kernel<1,4,AM>" in solver.describe_last_sweep()
     _hadi_solve(solver, 128, 64, 2, [100.0], H.AM)
     d = solver.describe_last_sweep()
     assert "hadi_pass_a<2,1" in d and "AM-P" in d and "hadi_pass_b<8,AM-P>" in d
