@@ -2314,12 +2314,12 @@ __global__ void __launch_bounds__(64 * W) hadi_small_kernel(HadiSweepArgs a, Had
 // has been consumed by all of them.  The column pass rebuilds U completely.  ~45 instructions per node against ~10 x that.
 struct HadiSmallSeqLayout {
     int pitch;     // doubles per row in LDS: odd, >= m1 + 2 (column m1 + 1 stays zero: the s-neighbour of the last node)
-    int off_y, off_coef, off_b2, off_ptab, total;  // offsets in doubles: U starts at 0 with (nrows + 4) rows
+    int off_y, off_coef, off_b2, off_ptab, total;  // offsets in doubles: U starts at 0 (nrows rows, no halo rows)
 };
 HADI_HD inline HadiSmallSeqLayout hadi_small_seq_layout(int m1, int nrows) {
     HadiSmallSeqLayout l;
     l.pitch = (m1 + 2) | 1;
-    l.off_y = (nrows + 4) * l.pitch;
+    l.off_y = nrows * l.pitch;
     l.off_coef = l.off_y + nrows * l.pitch;
     l.off_coef = (l.off_coef + 1) & ~1;  // 16-byte aligned quads
     l.off_b2 = l.off_coef + 4 * (m1 + 2);
@@ -2338,7 +2338,7 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
     const int nrows = a.L.nrows, rowp = a.L.rowp, m1 = a.L.m1;
     const HadiSmallSeqLayout Ls = hadi_small_seq_layout(m1, nrows);
     const int PL = Ls.pitch;
-    double *Ul = smem + 2 * PL;  // row 0 of U
+    double *Ul = smem;  // row 0 of U
     double *Yl = smem + Ls.off_y;
     double *coefl = smem + Ls.off_coef;  // [i][4]: Bm, Bp, Dm, Dp of node i
     double *b2l = smem + Ls.off_b2;
@@ -2381,6 +2381,11 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
     const double dt = ip.dt, thdt = ip.thdt, qd = ip.q, half_rd = ip.half_rd;
     const double inv0 = 1.0 / (1.0 + ip.thdt * ip.hr0);
     const double *urow = Ul + (act ? j : 0) * PL;  // (idle lanes walk row 0 and store nothing)
+    // The v-neighbours j-2 .. j+2, clamped to the grid instead of zero halo rows (1.7 KB that cost the sixth instance per CU):
+    // a clamped row only ever meets a zero weight -- the first / last rows of A0 and A2 have no entries beyond the grid.
+    const int jr = act ? j : 0;
+    const double *pm2 = Ul + (jr >= 2 ? jr - 2 : 0) * PL, *pm1 = Ul + (jr >= 1 ? jr - 1 : 0) * PL;
+    const double *pp1 = Ul + (jr + 1 < nrows ? jr + 1 : nrows - 1) * PL, *pp2 = Ul + (jr + 2 < nrows ? jr + 2 : nrows - 1) * PL;
     double *yrow = Yl + (act ? j : 0) * PL;
     double *crow = Ul + (act ? j : 0) * PL;        // column i - 1 of this row receives c'_i
     __syncthreads();
@@ -2425,9 +2430,9 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
         const double b1l = b1val * cb1;
         // ---- row pass: lane <-> v-row, i = 1 .. m1 (same formulas as hadi_row_step) --------------------------------
         // column i = 0 (A0 and A1 rows are zero there; only A2 and the boundary act)
-        const double c0m2 = urow[-2 * PL], c0m1 = urow[-PL], c00 = urow[0], c0p1 = urow[PL], c0p2 = urow[2 * PL];
+        const double c0m2 = pm2[0], c0m1 = pm1[0], c00 = urow[0], c0p1 = pp1[0], c0p2 = pp2[0];
         // first interior column, raw: rows j-2 .. j+2
-        double r_m2 = urow[-2 * PL + 1], r_m1 = urow[-PL + 1], r_0 = urow[1], r_p1 = urow[PL + 1], r_p2 = urow[2 * PL + 1];
+        double r_m2 = pm2[1], r_m1 = pm1[1], r_0 = urow[1], r_p1 = pp1[1], r_p2 = pp2[1];
         double yout_c0, x0;
         {
             const double a2c0 = a2l2 * c0m2 + a2l1 * c0m1 + a2m * c00 + a2u1 * c0p1 + a2u2 * c0p2;
@@ -2448,7 +2453,7 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
         double b2c = last ? b2l[1] : 0.0;
         double corr_cur = thdt * (b2c * e_n - (a2u_cur + b2c * e_nm1));
         // raw values of column 2 (column m1 + 1 is the zero spare)
-        r_m2 = urow[-2 * PL + 2]; r_m1 = urow[-PL + 2]; r_0 = urow[2]; r_p1 = urow[PL + 2]; r_p2 = urow[2 * PL + 2];
+        r_m2 = pm2[2]; r_m1 = pm1[2]; r_0 = urow[2]; r_p1 = pp1[2]; r_p2 = pp2[2];
         double cp_prev = 0.0, ys_prev = 0.0;
         for (int i = 1; i <= m1; i++) {
             // column i + 1 (fetched one step ahead), then the fetch of column i + 2
@@ -2456,7 +2461,7 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
             const double t_next = wm * r_m1 + wz * r_0 + wp * r_p1;
             const double a2u_next = fma(a2u2, r_p2, fma(a2l2, r_m2, a2l1 * r_m1 + a2m * r_0 + a2u1 * r_p1));
             const int inx = (i + 2 <= m1 + 1) ? i + 2 : m1 + 1;
-            r_m2 = urow[-2 * PL + inx]; r_m1 = urow[-PL + inx]; r_0 = urow[inx]; r_p1 = urow[PL + inx]; r_p2 = urow[2 * PL + inx];
+            r_m2 = pm2[inx]; r_m1 = pm1[inx]; r_0 = urow[inx]; r_p1 = pp1[inx]; r_p2 = pp2[inx];
             const double2 cB = *reinterpret_cast<const double2 *>(coefl + 4 * i);      // Bm, Bp
             const double2 cD = *reinterpret_cast<const double2 *>(coefl + 4 * i + 2);  // Dm, Dp
             const double lo = fma(v, cD.x, qd * cB.x);
