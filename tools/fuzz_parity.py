@@ -15,8 +15,10 @@ s = H.HestonADI(0)
 worst = 0.0
 for c in range(cases):
     m1 = rng.choice([rng.randint(20, 64), rng.randint(65, 128), rng.randint(129, 256), rng.randint(257, 512), rng.randint(513, 1024)])
+    if os.environ.get("FUZZ_SMALL"): m1 = rng.randint(8, 128)  # LDS-resident shapes only
     if os.environ.get("FUZZ_WIDE"): m1 = rng.choice([rng.randint(513, 1024), 1024, 513])  # two wavefronts per row only
     m2 = rng.randint(8, 300) if rng.random() < 0.2 else rng.randint(8, min(m1, 300))  # (m2 > m1 now and then)
+    if os.environ.get("FUZZ_SMALL"): m2 = rng.randint(4, 32)
     N = rng.randint(2, 12)
     n = rng.choice([1, 2, 3, 5, 9, 40, 130, 300]) if m1 * m2 < 40000 else rng.choice([1, 2, 3, 5, 9, 70])
     variant = rng.choice([H.EU, H.AM, H.DIV, H.AM_DIV])
@@ -31,6 +33,7 @@ for c in range(cases):
     U, lam = U0.copy(), np.zeros_like(U0)
     div = H.Dividends(*Cm.DIVS) if variant in (H.DIV, H.AM_DIV) else None
     if rng.random() < 0.3: s.set_tuning("american_p", 0)
+    if rng.random() < 0.5: s.set_tuning("small_seq", 1)  # (LDS-resident grids, European / dividends: the one-wavefront kernel)
     if rng.random() < (0.7 if os.environ.get("FUZZ_WIDE") else 0.3): s.set_tuning("strip", 1)
     try:
         s.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, r_f, *model, grids, U, variant=variant, U_0=U0,
@@ -39,7 +42,7 @@ for c in range(cases):
                           state_precision=H.STATE_FP32 if f32 else H.STATE_FP64)
         path = s.describe_last_sweep()
     finally:
-        s.set_tuning("american_p", 1); s.set_tuning("strip", -1)
+        s.set_tuning("american_p", 1); s.set_tuning("strip", -1); s.set_tuning("small_seq", -1)
     p = O.make_params(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, r_f, *model, variant, Cm.DIVS if div is not None else None,
                       option_type=O.PUT if put else O.CALL, strikes=np.array(strikes) if put else None, state_fp32=1 if f32 else 0)
     Uo, lo, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0, want_lambda=True)
