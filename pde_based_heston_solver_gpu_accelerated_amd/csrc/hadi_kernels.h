@@ -2313,17 +2313,20 @@ __global__ void __launch_bounds__(64 * W) hadi_small_kernel(HadiSweepArgs a, Had
 // g_i goes to Y, and c'_i goes to column i-1 of U's own row -- every lane is at the same i (one wavefront), so that column
 // has been consumed by all of them.  The column pass rebuilds U completely.  ~45 instructions per node against ~10 x that.
 struct HadiSmallSeqLayout {
-    int pitch;     // doubles per row in LDS: odd, >= m1 + 2 (column m1 + 1 stays zero: the s-neighbour of the last node)
-    int off_y, off_coef, off_b2, off_ptab, total;  // offsets in doubles: U starts at 0 (nrows rows, no halo rows)
+    int pitch;     // doubles per row in LDS: odd, >= m1 + 3 (columns m1 + 1, m1 + 2 stay zero: the s-neighbour of the last
+                   // node and the column the one-ahead fetch touches behind it)
+    int off_y, off_coef, off_b2, off_zero, off_dummy, off_ptab, total;  // offsets in doubles: U starts at 0 (nrows rows)
 };
 HADI_HD inline HadiSmallSeqLayout hadi_small_seq_layout(int m1, int nrows) {
     HadiSmallSeqLayout l;
-    l.pitch = (m1 + 2) | 1;
+    l.pitch = (m1 + 3) | 1;
     l.off_y = nrows * l.pitch;
     l.off_coef = l.off_y + nrows * l.pitch;
     l.off_coef = (l.off_coef + 1) & ~1;  // 16-byte aligned quads
     l.off_b2 = l.off_coef + 4 * (m1 + 2);
-    l.off_ptab = l.off_b2 + (m1 + 2);
+    l.off_zero = l.off_b2 + (m1 + 2);       // a row of zeros: the "b2 row" of every v-row but the last
+    l.off_dummy = l.off_zero + (m1 + 2);    // where the idle lanes (>= nrows) put their results
+    l.off_ptab = l.off_dummy + l.pitch;
     l.total = l.off_ptab + nrows * 5;
     return l;
 }
@@ -2386,8 +2389,9 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
     const int jr = act ? j : 0;
     const double *pm2 = Ul + (jr >= 2 ? jr - 2 : 0) * PL, *pm1 = Ul + (jr >= 1 ? jr - 1 : 0) * PL;
     const double *pp1 = Ul + (jr + 1 < nrows ? jr + 1 : nrows - 1) * PL, *pp2 = Ul + (jr + 2 < nrows ? jr + 2 : nrows - 1) * PL;
-    double *yrow = Yl + (act ? j : 0) * PL;
-    double *crow = Ul + (act ? j : 0) * PL;        // column i - 1 of this row receives c'_i
+    double *yrow = act ? Yl + j * PL : smem + Ls.off_dummy;  // (idle lanes store into a dummy row)
+    double *crow = act ? Ul + j * PL : smem + Ls.off_dummy;  // column i - 1 of this row receives c'_i
+    const double *b2p = last ? b2l : smem + Ls.off_zero;      // b2 lives on the last v-row only
     __syncthreads();
 
     const int N = ip.N < sm.Nmax ? ip.N : sm.Nmax;
@@ -2437,7 +2441,7 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
         {
             const double a2c0 = a2l2 * c0m2 + a2l1 * c0m1 + a2m * c00 + a2u1 * c0p1 + a2u2 * c0p2;
             const double b1c0 = b1_at0 ? b1val : 0.0;
-            const double b2c0 = last ? b2l[0] : 0.0;
+            const double b2c0 = b2p[0];
             const double a1c0 = -ip.hr0 * c00;  // A1 row 0: empty for the call (hr0 = 0), the reaction term for the put
             double y0c0 = c00 + dt * (a2c0 + a1c0 + (b1c0 + b2c0) * e_nm1);
             y0c0 = y0c0 + thdt * (b1c0 * e_n - (a1c0 + b1c0 * e_nm1));
@@ -2450,17 +2454,20 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
         double t_prev = wm * c0m1 + wz * c00 + wp * c0p1;
         double t_cur = wm * r_m1 + wz * r_0 + wp * r_p1;
         double a2u_cur = fma(a2u2, r_p2, fma(a2l2, r_m2, a2l1 * r_m1 + a2m * r_0 + a2u1 * r_p1));
-        double b2c = last ? b2l[1] : 0.0;
+        double b2c = b2p[1];
         double corr_cur = thdt * (b2c * e_n - (a2u_cur + b2c * e_nm1));
         // raw values of column 2 (column m1 + 1 is the zero spare)
         r_m2 = pm2[2]; r_m1 = pm1[2]; r_0 = urow[2]; r_p1 = pp1[2]; r_p2 = pp2[2];
-        double cp_prev = 0.0, ys_prev = 0.0;
+        // x_0 is known and moves to the right-hand side of node 1: with ys_0 = x_0 and c'_0 = 0 the general step does exactly
+        // that (pivot im - il 0, right-hand side y - il x_0)
+        double cp_prev = 0.0, ys_prev = x0;
+#pragma unroll 2
         for (int i = 1; i <= m1; i++) {
             // column i + 1 (fetched one step ahead), then the fetch of column i + 2
             const double u_next = r_0;
             const double t_next = wm * r_m1 + wz * r_0 + wp * r_p1;
             const double a2u_next = fma(a2u2, r_p2, fma(a2l2, r_m2, a2l1 * r_m1 + a2m * r_0 + a2u1 * r_p1));
-            const int inx = (i + 2 <= m1 + 1) ? i + 2 : m1 + 1;
+            const int inx = i + 2;  // (<= m1 + 2: a zero column)
             r_m2 = pm2[inx]; r_m1 = pm1[inx]; r_0 = urow[inx]; r_p1 = pp1[inx]; r_p2 = pp2[inx];
             const double2 cB = *reinterpret_cast<const double2 *>(coefl + 4 * i);      // Bm, Bp
             const double2 cD = *reinterpret_cast<const double2 *>(coefl + 4 * i + 2);  // Dm, Dp
@@ -2475,22 +2482,16 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
             double y = fma(dt, S, u_cur);
             y = fma(-thdt, A1U, y);
             y += (i == b1col) ? b1l : 0.0;
-            double il = -thdt * lo;
+            const double il = -thdt * lo;
             const double im = 1.0 - thdt * mn;
             const double iu = -thdt * up;
-            if (i == 1) {  // x_0 is known: move it to the right-hand side
-                y -= il * x0;
-                il = 0.0;
-            }
             const double inv = hadi_rcp(fma(-il, cp_prev, im));
             const double cp = iu * inv;
             const double ys = fma(-il, ys_prev, y) * inv;
-            const double b2n = (last && i < m1) ? b2l[i + 1] : 0.0;
+            const double b2n = b2p[i + 1];  // (entry m1 + 1 is zero)
             const double corr_next = thdt * (b2n * e_n - (a2u_next + b2n * e_nm1));
-            if (act) {
-                yrow[i] = ys + corr_cur + cp * corr_next;  // g_i  (c'_{m1} = 0: the row ends there)
-                crow[i - 1] = cp;
-            }
+            yrow[i] = ys + corr_cur + cp * corr_next;  // g_i  (c'_{m1} = 0: the row ends there)
+            crow[i - 1] = cp;
             u_prev = u_cur; u_cur = u_next;
             t_prev = t_cur; t_cur = t_next;
             a2u_cur = a2u_next; corr_cur = corr_next; b2c = b2n;
