@@ -166,7 +166,7 @@ int hadi_get_timing(const hadi_ctx *ctx, hadi_timing *out);
 /* Execution-path switches (results agree to round-off; the library reads NO environment variables):
  *   "small_grid"  LDS-resident one-launch path for grids that fit in LDS (default 1)
  *   "small_seq"   ... European / dividend sweeps of such grids on the one-wavefront-per-instance kernel that solves the
- *                 lines sequentially, one per lane: -1 automatic (default: batches of at least 3 instances per CU), 0 never
+ *                 lines sequentially, one per lane: -1 automatic (default: batches of more instances than CUs), 0 never
  *                 (the block-per-instance kernel, which the American sweeps always use), 1 always
  *   "graph"       hipGraph replay of the time loop for small batches (default 1)
  *   "american_p"  American sweeps keep P = U_bar - dt*lambda_bar in place of U and no lambda_bar array whenever every

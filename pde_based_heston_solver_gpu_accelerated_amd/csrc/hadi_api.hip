@@ -570,11 +570,11 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     // ---- small grids: the whole instance fits in LDS -> one launch runs the entire time loop ----------
     const size_t smem_small = american ? pl.smem_small_am : pl.smem_small_eu;
     // European / dividend sweeps: one wavefront per instance with sequential line solves (hadi_small_seq_kernel) issues about
-    // half the instructions per instance and step but runs them on ONE wavefront -- ahead once the batch oversubscribes the
-    // CUs (50x25: 3000 instances x 50 steps 3.75 -> 2.35 ms, 1024 x 50: 1.41 -> 1.12), behind while it does not (500 x 100
-    // steps: 1.55 -> 1.64 ms; a single instance: 10 -> 14 us per step).  "small_seq" = 1 forces it, 0 forbids it, -1
-    // (default) picks by batch size: from 3 instances per CU on.
-    const bool seq = takes_small_path && !american && (c->small_seq > 0 || (c->small_seq < 0 && d.n >= 3 * c->cu_count));
+    // half the instructions per instance and step but runs them on ONE wavefront -- ahead once there are more instances than
+    // CUs (50x25, 40 steps, ms block kernel / this one: 256 instances 0.49 / 0.55, 320: 0.67 / 0.60, 512: 0.71 / 0.63, 768: 0.95 /
+    // 0.80; 3000 x 50 steps: 3.75 / 2.13), behind below that (a single instance: 10 against 12 us per step).
+    // "small_seq" = 1 forces it, 0 forbids it, -1 (default) picks by batch size.
+    const bool seq = takes_small_path && !american && (c->small_seq > 0 || (c->small_seq < 0 && d.n > c->cu_count));
     const size_t smem_seq = (size_t)hadi_small_seq_layout(L.m1, L.nrows).total * sizeof(double);
     if (takes_small_path) {
         {

@@ -2499,9 +2499,20 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
             hadi_wave_rendezvous();  // (emulator: the lanes walk in lock step on the GPU)
         }
         // back substitution on the output itself: Y_i = g_i - c'_i Y_{i+1}
-        if (act) {
+        {   // (idle lanes walk their dummy row)
             double Yn = yrow[m1];
-            for (int i = m1 - 1; i >= 1; i--) {
+            int i = m1 - 1;
+            for (; i >= 8; i -= 8) {  // eight nodes per round: 16 independent LDS reads, then the dependent FMAs
+                double g[8], cq[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) { g[q] = yrow[i - q]; cq[q] = crow[i - q - 1]; }
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    Yn = fma(-cq[q], Yn, g[q]);
+                    yrow[i - q] = Yn;
+                }
+            }
+            for (; i >= 1; i--) {
                 Yn = fma(-crow[i - 1], Yn, yrow[i]);
                 yrow[i] = Yn;
             }
@@ -2512,8 +2523,23 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
         // (measured and left out, 50x25 x3000: fetching a node's coefficients one iteration ahead 2.64 -> 2.72 ms; the column
         // held in 33 registers with all loads up front 2.64 -> 2.88 ms)
         for (int col = lane; col <= m1; col += 64) {
+            // eight rows per round: the independent LDS reads first, then the dependent recurrence
             double ym1 = 0.0, ym2 = 0.0;
-            for (int k = 0; k < nrows; k++) {
+            int k = 0;
+            for (; k + 8 <= nrows; k += 8) {
+                double yv[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) yv[q] = Yl[(k + q) * PL + col];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const double *t = ptab + (k + q) * 5;
+                    const double yk = (yv[q] - t[PB_L] * ym1 - t[PB_L2] * ym2) * t[PB_Q];
+                    Yl[(k + q) * PL + col] = yk;
+                    ym2 = ym1;
+                    ym1 = yk;
+                }
+            }
+            for (; k < nrows; k++) {
                 const double *t = ptab + k * 5;
                 const double yk = (Yl[k * PL + col] - t[PB_L] * ym1 - t[PB_L2] * ym2) * t[PB_Q];
                 Yl[k * PL + col] = yk;
@@ -2521,7 +2547,21 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
                 ym1 = yk;
             }
             double xp1 = 0.0, xp2 = 0.0;
-            for (int k = nrows - 1; k >= 0; k--) {
+            k = nrows - 1;
+            for (; k >= 7; k -= 8) {
+                double yv[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) yv[q] = Yl[(k - q) * PL + col];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const double *t = ptab + (k - q) * 5;
+                    const double xk = yv[q] - t[PB_C] * xp1 - t[PB_C2] * xp2;
+                    xp2 = xp1;
+                    xp1 = xk;
+                    Ul[(k - q) * PL + col] = xk;
+                }
+            }
+            for (; k >= 0; k--) {
                 const double *t = ptab + k * 5;
                 const double xk = Yl[k * PL + col] - t[PB_C] * xp1 - t[PB_C2] * xp2;
                 xp2 = xp1;

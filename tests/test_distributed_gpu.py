@@ -24,8 +24,13 @@ def test_two_rank_calibration_equals_single_rank():
     one, two = _run(1, 29631), _run(2, 29632)
     assert two["world"] == 2 and two["shard"][0] == 0 and 0 < two["shard"][1] < 60
     assert one["iterations"] == two["iterations"] and one["pde_solves"] == two["pde_solves"] == 60 * 7 * one["iterations"] - 60
+    # The first error is a sum of squared price differences: equal to round-off.  The later ones follow parameters that came
+    # out of a forward-difference Jacobian (eps = 1e-6: round-off of 1e-13 in a price is 1e-7 in J), and the two runs differ in
+    # summation order across ranks AND in kernel (360 instances per launch pick the one-wavefront small-grid kernel, 180 per
+    # rank the block kernel).
+    assert abs(one["errors"][0] - two["errors"][0]) <= 1e-9 * max(1.0, one["errors"][0])
     for a, b in zip(one["errors"], two["errors"]):
-        assert abs(a - b) <= 1e-6 * max(1.0, a)          # J^T J is summed in a different order across ranks
+        assert abs(a - b) <= 1e-4 * max(1.0, a)
     for k in ("eta", "sigma", "rho", "v0"):
         assert abs(one[k] - two[k]) <= 1e-3 * max(1e-2, abs(one[k]))
     assert abs(one["kappa"] - two["kappa"]) <= 1e-2 * abs(one["kappa"])

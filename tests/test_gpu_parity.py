@@ -781,7 +781,7 @@ def test_small_grid_sequential_kernel_vs_oracle(solver, put, variant, name, m1, 
         U0 = grids.put_payoff(strikes)
     U = U0.copy()
     div = H.Dividends(*Cm.DIVS) if variant == H.DIV else None
-    solver.set_tuning("small_seq", 1)  # (chosen by itself from 3 instances per CU on)
+    solver.set_tuning("small_seq", 1)  # (chosen by itself for batches of more instances than CUs)
     try:
         solver.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U,
                                variant=variant, dividends=div, option_type=H.PUT if put else H.CALL, strikes=strikes if put else None)
@@ -823,7 +823,7 @@ def test_small_grid_kernel_on_a_batch_larger_than_two_per_cu(solver, seq):
 def test_describe_last_sweep_names_the_kernels(solver):
     _hadi_solve(solver, 50, 25, 4, [100.0], H.EU)
     assert "hadi_small_kernel<1,8,EU>" in solver.describe_last_sweep()
-    _hadi_solve(solver, 50, 25, 2, Cm.strikes_for(1100), H.EU)   # at least 3 instances per CU: one wavefront per instance
+    _hadi_solve(solver, 50, 25, 2, Cm.strikes_for(1100), H.EU)   # more instances than CUs: one wavefront per instance
     assert "hadi_small_seq_kernel<1>" in solver.describe_last_sweep()
     _hadi_solve(solver, 50, 25, 2, Cm.strikes_for(1100), H.AM)
     assert "hadi_small_kernel<1,4,AM>" in solver.describe_last_sweep()

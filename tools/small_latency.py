@@ -16,5 +16,7 @@ def run(n, N, variant=H.EU):
         s.DO_timestepping(50, 25, N, 1.0 / N, 0.8, 0.025, 0.0, -0.9, 0.3, 1.5, 0.04, gd, U, variant=variant, U_0=U0)
         best = min(best, time.perf_counter() - t)
     return best * 1e3, float(U[0, 500].item())
-for n, N in ((1, 100), (60, 20), (500, 20), (500, 100), (1024, 50), (3000, 50)):
+cases = ((1, 100), (60, 20), (500, 20), (500, 100), (1024, 50), (3000, 50))
+if os.environ.get("SIZES"): cases = tuple((int(x), 40) for x in os.environ["SIZES"].split(","))
+for n, N in cases:
     print(n, N, "%.3f ms" % run(n, N)[0], run(n, N)[1])
