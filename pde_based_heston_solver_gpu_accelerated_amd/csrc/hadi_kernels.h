@@ -2257,8 +2257,23 @@ __global__ void __launch_bounds__(64 * W) hadi_small_kernel(HadiSweepArgs a, Had
         HADI_STAMP(9);  // barrier
         // ---- column pass: one thread per storage column, sequential pentadiagonal sweeps in LDS --------
         for (int col = tid; col < rowp; col += NT) {
+            // rounds of eight rows: the independent LDS reads first, then the dependent recurrence (as in hadi_small_seq_kernel)
             double ym1 = 0.0, ym2 = 0.0;
-            for (int k = 0; k < nrows; k++) {
+            int k = 0;
+            for (; k + 8 <= nrows; k += 8) {
+                double yv[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) yv[q] = Yl[(size_t)(k + q) * rowp + col];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const double *t = ptab + (size_t)(k + q) * HADI_PBW;
+                    const double yk = (yv[q] - t[PB_L] * ym1 - t[PB_L2] * ym2) * t[PB_Q];
+                    Yl[(size_t)(k + q) * rowp + col] = yk;
+                    ym2 = ym1;
+                    ym1 = yk;
+                }
+            }
+            for (; k < nrows; k++) {
                 const double *t = ptab + (size_t)k * HADI_PBW;
                 const double yk = (Yl[(size_t)k * rowp + col] - t[PB_L] * ym1 - t[PB_L2] * ym2) * t[PB_Q];
                 Yl[(size_t)k * rowp + col] = yk;
@@ -2266,7 +2281,23 @@ __global__ void __launch_bounds__(64 * W) hadi_small_kernel(HadiSweepArgs a, Had
                 ym1 = yk;
             }
             double xp1 = 0.0, xp2 = 0.0;
-            for (int k = nrows - 1; k >= 0; k--) {
+            k = nrows - 1;
+            if constexpr (!AMER) {
+                for (; k >= 7; k -= 8) {
+                    double yv[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) yv[q] = Yl[(size_t)(k - q) * rowp + col];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const double *t = ptab + (size_t)(k - q) * HADI_PBW;
+                        const double xk = yv[q] - t[PB_C] * xp1 - t[PB_C2] * xp2;
+                        xp2 = xp1;
+                        xp1 = xk;
+                        Ul[(size_t)(k - q) * rowp + col] = xk;
+                    }
+                }
+            }
+            for (; k >= 0; k--) {
                 const double *t = ptab + (size_t)k * HADI_PBW;
                 const double xk = Yl[(size_t)k * rowp + col] - t[PB_C] * xp1 - t[PB_C2] * xp2;
                 xp2 = xp1;
