@@ -177,6 +177,15 @@ struct HadiTables {
 // wavefronts (= strips) per block of the strip row pass: 8 at 8 nodes per lane (one block fills a CU's LDS and
 // registers); 4 at 4 and 2 nodes per lane, where a v-line is short and 8 strips would be ~17 rows each
 #define HADI_STRIP_WAVES(B) ((B) == 8 ? 8 : 4)
+// Slots of a strip wavefront's private LDS ring = rows ahead of the current one that are fetched or in flight (the row NS
+// ahead is issued when the row two ahead is waited for: a lead of NS - 2 row steps).  8 nodes per lane: 4 slots fill the
+// 160 KB of a CU (3 for the paired strips with an fp64 state).  Narrower rows have LDS to spare, but a deeper ring does not
+// pay: measured with 8 slots at 4 nodes per lane, 256x128 x512 American puts 0.0841 -> 0.0871 ms per launch, 200x100 x700
+// 0.076 -> 0.116 (the LDS costs an occupancy step) -- the DMA wait the in-kernel stamps show is not what bounds the pass.
+#ifndef HADI_STRIP_NS_NARROW
+#define HADI_STRIP_NS_NARROW 4
+#endif
+#define HADI_STRIP_NS(B, G, ES) ((G) == 2 ? ((ES) == 8 ? 3 : 4) : ((B) <= 4 ? HADI_STRIP_NS_NARROW : 4))
 enum { RC_V = 0, RC_WM = 1, RC_WZ = 2, RC_WP = 3, RC_L2 = 4, RC_L1 = 5, RC_M = 6, RC_U1 = 7, RC_U2 = 8,
        RC_B1VAL = 9, RC_B1COL = 10, RC_VTH = 11 /* theta dt v */, RC_LAST = 12 };
 // pb columns: forward  y_k = (rhs_k - PB_L y_{k-1} - PB_L2 y_{k-2}) * PB_Q

@@ -1402,7 +1402,8 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     static_assert(sizeof(T) == 8 || AMER == 0, "the fp32-state sweep is European only");
     static_assert(G == 1 || (G == 2 && B == 8 && AMER == 0), "paired strips: 8 nodes per lane, European");
     HADI_DYN_SMEM(double, smem);
-    constexpr int NS = (G == 2 && sizeof(T) == 8) ? 3 : 4, NWV = HADI_STRIP_WAVES(B), NPAIR = NWV / G, c0slot = 64 * B * G;
+    constexpr int NS = HADI_STRIP_NS(B, G, (int)sizeof(T)), NWV = HADI_STRIP_WAVES(B), NPAIR = NWV / G, c0slot = 64 * B * G;
+    constexpr int NA = NS - 2;  // DMA batches in flight behind the one that is waited for
     const int lane = threadIdx.x & 63;
     const int wave = HADI_UNIFORM((int)(threadIdx.x >> 6));
     const int pair = wave / G, half = wave - pair * G;  // (G = 1: pair = wave, half = 0)
@@ -1461,7 +1462,7 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     }
 
     T *ring = reinterpret_cast<T *>(smem) + (size_t)pair * NS * rowp;
-    auto slot = [&](int jj) { return ring + (size_t)(NS == 4 ? (jj & 3) : (jj + 12) % NS) * rowp; };  // (jj >= -4)
+    auto slot = [&](int jj) { return ring + (size_t)((NS & (NS - 1)) == 0 ? (jj & (NS - 1)) : (jj + 12) % NS) * rowp; };  // (jj >= -4)
     // returns the number of vector-memory instructions issued (rows outside the allocation are zero-filled)
     auto fetch = [&](int jj) -> int {
         const bool exists = jj >= 0 && jj < npad;
@@ -1482,15 +1483,19 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     const int js = dir > 0 ? j0 : j1 - 1;
     auto row_ok = [&](int jj) { return jj >= 0 && jj < npad; };
     // ---- prologue: the next rows ahead to the ring, the two rows behind and the first row to registers ----
-    // after0 = vector-memory instructions issued after the DMA of the row needed next (two ahead), after1 = ... after the
-    // DMA of the row after that (4-slot ring only: with 3 slots the row two ahead is the youngest DMA)
-    int after0 = 0, after1 = 0;
+    // aft[k] = vector-memory instructions issued after the DMA of the row 2 + k ahead: aft[0] belongs to the row that is
+    // waited for next, the row NS - 1 ahead is the youngest DMA (nothing behind it yet)
+    int aft[NA];
+#pragma unroll
+    for (int k = 0; k < NA; k++) aft[k] = 0;
     fetch(js + dir);
-    if constexpr (NS == 4) {
-        fetch(js + 2 * dir);
-        after0 = fetch(js + 3 * dir);
-    } else {
-        fetch(js + 2 * dir);
+    fetch(js + 2 * dir);
+#pragma unroll
+    for (int q = 3; q < NS; q++) {
+        const int zq = fetch(js + q * dir);
+#pragma unroll
+        for (int k = 0; k < NA; k++)
+            if (k + 2 < q) aft[k] += zq;
     }
     // rows behind by 2, behind by 1 (carried in the state's own type: with an fp32 state they are exact floats and cost
     // half the registers), current row (double: used throughout the step)
@@ -1558,14 +1563,11 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
         // prefetch does not queue behind it.
         int z = 0;
         if (t + NS <= cnt + 1) z = fetch(j + NS * dir);
-        hadi_wait_vmcnt(after0 + z);  // the row two ahead has landed (the row one ahead landed a step earlier)
+        hadi_wait_vmcnt(aft[0] + z);  // the row two ahead has landed (the row one ahead landed a step earlier)
         HADI_STAMPC(24);  // wait for the DMA
-        if constexpr (NS == 4) {
-            after0 = after1 + z;
-            after1 = 0;
-        } else {
-            after0 = 0;
-        }
+#pragma unroll
+        for (int k = 0; k + 1 < NA; k++) aft[k] = aft[k + 1] + z;
+        aft[NA - 1] = 0;
         hadi_wave_rendezvous();
         double up1[B], up2[B];
         hadi_get_block<B, G, T>(slot(j + dir), half, lane, up1);
@@ -1617,8 +1619,8 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
         }
         if (j == nrows - 1) hadi_strip_step<B, AMER, true, T, G>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_);
         else hadi_strip_step<B, AMER, false, T, G>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_);
-        after0 += hadi_put_block_stores<B, T>();  // the row's vector stores (the i = 0 store is not counted: lower bound)
-        after1 += hadi_put_block_stores<B, T>();
+#pragma unroll
+        for (int k = 0; k < NA; k++) aft[k] += hadi_put_block_stores<B, T>();  // the row's vector stores (the i = 0 store is not counted: lower bound)
         double enew = 0.0;
         if constexpr (G > 1) {
             // The partner's boundary node of the row TWO ahead, from the partner's half of the ring slot.  Safe here and only

@@ -90,7 +90,7 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
         p.sblocks = (ns + nwv - 1) / nwv;
         p.RS = (L.nrows + nwv * p.sblocks - 1) / (nwv * p.sblocks);
         p.grid_as = (int)(((long long)n_inst * p.sblocks + 7) / 8 * 8);
-        p.smem_as = ((size_t)nwv * 4 * L.rowp + (size_t)4 * 64 * L.B) * sizeof(double);
+        p.smem_as = ((size_t)nwv * HADI_STRIP_NS(L.B, 1, 8) * L.rowp + (size_t)4 * 64 * L.B) * sizeof(double);
         // hadi_set_tuning("strip", 1) forces strips wherever the geometry allows them (tests).
         const int cus = target_waves / 8 > 0 ? target_waves / 8 : 1;
         p.use_strip = 0;
