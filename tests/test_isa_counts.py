@@ -1,0 +1,87 @@
+"""Build-time check of the hand-kept instruction counts behind the counted `s_waitcnt vmcnt(n)` of the row passes (no GPU).
+
+The LDS-DMA prefetch of a row is retired by `hadi_wait_vmcnt(n)` with n = the number of vector-memory instructions the
+wavefront issued AFTER that row's DMA: the DMA pieces of younger rows (`fetch()` returns their count) and the result stores
+of the row steps in between (`hadi_put_block_stores<B, T>()`).  Vector-memory operations retire in issue order, so n may be
+a LOWER bound of what was really issued (the wait is then stricter than needed) but never more: an over-count lets the wait
+pass with a DMA piece still in flight and the next step reads a stale ring row -- silently, and only when the memory is slow
+(the fp32-state kernels carried exactly that over-count until round 2: B/2 counted, B/4 quad stores emitted).  The emulator
+does not model vmcnt and the strict-build comparison on the GPU only catches it if the timing cooperates; this test reads
+the compiler's own assembly instead (hipcc --save-temps, as tools/kernel_regs.py does)."""
+import os, re, subprocess, sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+PAD = lambda B, es: 8 if B < 4 else (32 if es == 4 else 16)                     # HADI_ROW_PAD
+STORES = lambda B, es: 1 if B == 1 else (B // 4 if (es == 4 and B >= 4) else B // 2)  # hadi_put_block_stores
+STRIP_NS = lambda B, G, es: (3 if es == 8 else 4) if G == 2 else 4              # HADI_STRIP_NS (default build)
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    import kernel_regs
+    _, asm = kernel_regs.collect()
+    out = {}
+    for m in re.finditer(r"^(_Z\w+):.*?\n(.*?)^\s*s_endpgm", asm, re.S | re.M):
+        name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
+        if name.startswith("void hadi_pass_a"):
+            out[name.replace("(HadiSweepArgs, int)", "").replace("void ", "")] = m.group(2)
+    assert len(out) > 30
+    return out
+
+
+def test_python_mirrors_match_the_source():
+    """The formulas above are mirrors of hadi_put_block_stores / HADI_ROW_PAD / HADI_STRIP_NS: tie them to the source text."""
+    csrc = os.path.join(ROOT, "pde_based_heston_solver_gpu_accelerated_amd", "csrc")
+    k = open(os.path.join(csrc, "hadi_kernels.h")).read()
+    c = open(os.path.join(csrc, "hadi_core.h")).read()
+    assert "return B == 1 ? 1 : (sizeof(T) == 4 && B >= 4) ? B / 4 : B / 2;" in k
+    assert "for (int k = 0; k < NA; k++) aft[k] += hadi_put_block_stores<B, T>();" in k      # strips
+    assert "for (int k = 0; k < PD; k++) ya[k] += hadi_put_block_stores<B, T>();" in k       # shared ring
+    assert "#define HADI_ROW_PAD(B, ES) ((B) < 4 ? 8 : ((ES) == 4 ? 32 : 16))" in c
+    assert "#define HADI_STRIP_NS(B, G, ES) ((G) == 2 ? ((ES) == 8 ? 3 : 4) : ((B) <= 4 ? HADI_STRIP_NS_NARROW : 4))" in c
+    assert "#define HADI_STRIP_NS_NARROW 4" in c
+
+
+def _args(name):
+    return [a.strip() for a in name[name.index("<") + 1:name.rindex(">")].split(",")]
+
+
+def test_strip_kernels_issue_at_least_the_stores_and_exactly_the_dma_pieces_the_waits_count(kernels):
+    seen = 0
+    for name, body in kernels.items():
+        if not name.startswith("hadi_pass_a_strip<"):
+            continue
+        B, amer, T, G = _args(name)
+        B, G, es = int(B), int(G), 4 if T == "float" else 8
+        n_dma = len(re.findall(r"\bglobal_load_lds_dwordx4\b", body))
+        n_st = len(re.findall(r"\bglobal_store_dwordx4\b", body)) + (len(re.findall(r"\bglobal_store_dwordx2\b", body)) if (B == 2 and es == 4) else 0)
+        # fetch(): NS call sites (NS - 1 in the prologue, one in the loop)
+        rowp = 64 * B * G + PAD(B, es)
+        if G == 1:
+            pieces = -(-(rowp * es // 16) // 64)          # hadi_row_dma_count: whole 1 KiB pieces + the partial one
+        else:
+            pieces = (B * es // 16) + 1                   # hadi_half_row_to_lds: the half's pieces + the pad piece (low half)
+        assert n_dma == STRIP_NS(B, G, es) * pieces, (name, n_dma)
+        # hadi_strip_step is instantiated twice (last v-row or not): each copy stores the row block once
+        assert n_st >= 2 * STORES(B, es), (name, n_st)
+        seen += 1
+    assert seen >= 12
+
+
+def test_ring_kernels_issue_at_least_the_stores_the_waits_count(kernels):
+    seen = 0
+    for name, body in kernels.items():
+        if not name.startswith("hadi_pass_a<"):
+            continue
+        B, G, W, NG, PD, amer, mode, T = _args(name)
+        B, es = int(B), 4 if T == "float" else 8
+        wide = len(re.findall(r"\bglobal_store_dwordx4\b", body))
+        narrow = len(re.findall(r"\bglobal_store_dwordx2\b", body)) + len(re.findall(r"\bglobal_store_dword\b", body))
+        n_st = wide if B >= 2 and not (B == 2 and es == 4) else narrow   # one node per lane stores single elements
+        assert n_st >= 2 * STORES(B, es), (name, n_st)   # two copies of hadi_row_step (last v-row or not)
+        seen += 1
+    assert seen >= 25
