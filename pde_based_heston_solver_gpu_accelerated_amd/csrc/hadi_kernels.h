@@ -1071,6 +1071,13 @@ __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : B == 4 ? HADI_R
 // into SGPRs.  Against the shared-ring kernel:
 // no block-wide barrier (its wait was ~40 % of a wavefront's time there), twice the rows in flight per CU, a quarter
 // of the LDS reads; the price is 4 halo rows per strip read again (mostly L2 hits).
+// American P representation on strips: from this many nodes per lane on, the raw P of row j is read again from its ring slot
+// (kept one step longer) instead of being carried in registers.  At 8 nodes per lane that ends the spilling (256 VGPRs + 12
+// spilled -> 228; 512x256 x256 American: row pass 0.140 -> 0.121 ms per launch); at 4 the kernel fits either way and the
+// shorter prefetch costs more than the registers gain (256x128 x512 American puts: 0.0841 -> 0.0866).
+#ifndef HADI_AMP_KEEP_MIN_B
+#define HADI_AMP_KEEP_MIN_B 8
+#endif
 template <class T>
 struct HadiStripCtxT {
     const double *coef;  // LDS: Bm, Bp, Dm, Dp, each 64*B doubles in row layout
@@ -1118,7 +1125,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
                                                const double (&up1)[B], const double (&up2)[B], double c0m2, double c0m1,
                                                double c00, double c0p1, double c0p2, const double (&p_raw)[B],
                                                double lamc0_in, const T *next_row, double (&u_next)[B],
-                                               double eb = 0.0, double e0 = 0.0, double ea = 0.0) {
+                                               double eb = 0.0, double e0 = 0.0, double ea = 0.0, const T *raw_row = nullptr) {
     static_assert(G == 1 || (G == 2 && AMER == 0), "paired strips cover the European step");
     const int lane = c.lane, rowp = c.rowp;
     const int half = (G > 1) ? c.half : 0;
@@ -1182,9 +1189,17 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
     double lam[B], b2v[B];
     if constexpr (AMER == 1) hadi_get_block<B, 1>(c.Li + (size_t)j * rowp, 0, lane, lam);
     if constexpr (AMER == 2) {
+        // 8 nodes per lane: the raw P of row j is read again from its ring slot, which stays intact through this step (the
+        // kernel keeps one slot behind the prefetch for it) -- carried in 16 more registers the kernel spilled
+        double praw8[B];
+        if constexpr (B >= HADI_AMP_KEEP_MIN_B) hadi_get_block<B, 1, T>(raw_row, 0, lane, praw8);
+        else {
+#pragma unroll
+            for (int r = 0; r < B; r++) praw8[r] = 0.0;
+        }
 #pragma unroll
         for (int r = 0; r < B; r++) {
-            lam[r] = (u0[r] - p_raw[r]) * c.inv_dt;  // exactly max(0, (U_0 - P) / dt): U = max(P, U_0)
+            lam[r] = (u0[r] - (B >= HADI_AMP_KEEP_MIN_B ? praw8[r] : p_raw[r])) * c.inv_dt;  // exactly max(0, (U_0 - P) / dt): U = max(P, U_0)
             if (lane == c.m1_lane && r == c.m1_r) lam[r] = 0.0;  // s_max keeps lambda_bar = 0, as in hadi_row_step
         }
     }
@@ -1403,7 +1418,10 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     static_assert(G == 1 || (G == 2 && B == 8 && AMER == 0), "paired strips: 8 nodes per lane, European");
     HADI_DYN_SMEM(double, smem);
     constexpr int NS = HADI_STRIP_NS(B, G, (int)sizeof(T)), NWV = HADI_STRIP_WAVES(B), NPAIR = NWV / G, c0slot = 64 * B * G;
-    constexpr int NA = NS - 2;  // DMA batches in flight behind the one that is waited for
+    // American P representation at 8 nodes per lane: one slot stays BEHIND the prefetch -- row j itself, whose raw P the step
+    // reads again for lambda_bar -- so the row D = NS - 1 ahead is fetched, not the row NS ahead
+    constexpr int KEEP = (AMER == 2 && B >= HADI_AMP_KEEP_MIN_B && G == 1) ? 1 : 0, D = NS - KEEP;
+    constexpr int NA = D - 2;  // DMA batches in flight behind the one that is waited for
     const int lane = threadIdx.x & 63;
     const int wave = HADI_UNIFORM((int)(threadIdx.x >> 6));
     const int pair = wave / G, half = wave - pair * G;  // (G = 1: pair = wave, half = 0)
@@ -1488,10 +1506,11 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     int aft[NA];
 #pragma unroll
     for (int k = 0; k < NA; k++) aft[k] = 0;
+    if constexpr (KEEP) fetch(js);  // (the first row too: the step reads its raw P from the ring)
     fetch(js + dir);
     fetch(js + 2 * dir);
 #pragma unroll
-    for (int q = 3; q < NS; q++) {
+    for (int q = 3; q < D; q++) {
         const int zq = fetch(js + q * dir);
 #pragma unroll
         for (int k = 0; k < NA; k++)
@@ -1558,11 +1577,11 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
         HadiSRow srow;
         hadi_sload_issue(a.rowc + ((size_t)inst * nrows + j) * HADI_RC, srow);  // flies during the DMA wait
         hadi_wave_rendezvous();
-        // the row NS ahead goes to the slot of row j: row j is in registers, and this wavefront's last read of that
-        // slot (the re-read in the previous step) has been retired there.  Issued BEFORE the wait below, so that the
-        // prefetch does not queue behind it.
+        // the row D ahead goes to the slot of row j (of row j - 1 when one slot is kept behind): that row is in registers,
+        // and this wavefront's last read of the slot (in the previous step) has been retired there.  Issued BEFORE the
+        // wait below, so that the prefetch does not queue behind it.
         int z = 0;
-        if (t + NS <= cnt + 1) z = fetch(j + NS * dir);
+        if (t + D <= cnt + 1) z = fetch(j + D * dir);
         hadi_wait_vmcnt(aft[0] + z);  // the row two ahead has landed (the row one ahead landed a step earlier)
         HADI_STAMPC(24);  // wait for the DMA
 #pragma unroll
@@ -1603,7 +1622,7 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
             const double pay_c0 = payl[c0slot];
 #pragma unroll
             for (int r = 0; r < B; r++) {
-                praw[r] = u0[r];  // the raw P of row j: lambda_bar comes from it inside the step
+                if constexpr (!KEEP) praw[r] = u0[r];  // the raw P of row j: lambda_bar comes from it inside the step
                 u0[r] = fmax(u0[r], pay[r]);
                 up1[r] = fmax(up1[r], pay[r]);
                 up2[r] = fmax(up2[r], pay[r]);
@@ -1617,8 +1636,8 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
         if constexpr (G > 1) {
             xb_ = hadi_read_lane(evec, 1); x0_ = hadi_read_lane(evec, 2); xa_ = hadi_read_lane(evec, 3);
         }
-        if (j == nrows - 1) hadi_strip_step<B, AMER, true, T, G>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_);
-        else hadi_strip_step<B, AMER, false, T, G>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_);
+        if (j == nrows - 1) hadi_strip_step<B, AMER, true, T, G>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_, slot(j));
+        else hadi_strip_step<B, AMER, false, T, G>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_, slot(j));
 #pragma unroll
         for (int k = 0; k < NA; k++) aft[k] += hadi_put_block_stores<B, T>();  // the row's vector stores (the i = 0 store is not counted: lower bound)
         double enew = 0.0;
