@@ -171,8 +171,12 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
             const int gf = gfull_of(b);
             // up to eight chunks the kernel holds three tiles in registers, all loaded up front; a fourth tile waits for a
             // free buffer (512x256 x256: 2 blocks of 4 and 4+short tiles 0.129 ms against 0.109 for 3 blocks of 3,3,2+short)
+            // (a single FOURTH tile is free when the blocks do not queue up behind each other on a CU: in a single-round launch
+            // its wait overlaps the other CUs' traffic -- 512x256 x128: 2 blocks of 4 and 4+short tiles 0.0628 ms against 0.0663
+            // for 4 blocks of 2)
+            const bool queued = (long long)n_inst * (gf + (own ? 1 : 0)) > cus;
             auto weight = [&](double tiles, int count) {
-                return tiles + (count < 2 ? 0.6 : 0.0) + ((L.P <= 8 && count > 3) ? 1.0 * (count - 3) : 0.0);
+                return tiles + (count < 2 ? 0.6 : 0.0) + ((L.P <= 8 && count > 3 && (queued || count > 4)) ? 1.0 * (count - 3) : 0.0);
             };
             const int last_full = nfull - (gf - 1) * b;
             // a launch that leaves half the CUs idle is bound by the latency of its longest block, not by traffic: there the
@@ -184,7 +188,10 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
                 if (wl > w) w = wl;
                 if (ws > w) w = ws;
             } else {
-                const double wl = weight(last_full + sw * nshort, last_full + nshort);
+                // (the single-tile penalty looks at all tiles of the block, the late-tile penalty at its FULL tiles: the short
+                // one behind them is a sliver of traffic)
+                double wl = weight(last_full + sw * nshort, last_full);
+                if (last_full + nshort >= 2 && last_full < 2) wl -= 0.6;
                 if (wl > w) w = wl;
             }
             const long long rounds = ((long long)n_inst * (gf + (own ? 1 : 0)) + cus - 1) / cus;

@@ -23,6 +23,8 @@ CASES = {
     "c5f64_r32": ["--workload", "c5", "--state", "fp64", "--tuning", "row_tile=32"],
     **{"c5f64_%d%s" % (k, t): ["--workload", "c5", "--state", "fp64", "--instances", str(k), "--timesteps", "400", "--tuning", "strip=%d" % v]
        for k in (8, 16, 32, 48, 64, 96, 128, 192, 256) for t, v in (("s", 1), ("r", 0))},
+    **{"c2_64g%d" % g: ["--workload", "c2", "--instances", "64", "--tuning", "col_groups=%d" % g] for g in (2, 3, 4, 5, 8, 9)},
+    **{"c2_128g%d" % g: ["--workload", "c2", "--instances", "128", "--tuning", "col_groups=%d" % g] for g in (2, 3, 4, 5, 8, 9)},
     "c2_g1": ["--workload", "c2", "--tuning", "col_groups=1"], "c2_g2": ["--workload", "c2", "--tuning", "col_groups=2"], "c2_g9": ["--workload", "c2", "--tuning", "col_groups=9"],
     "c2ring": ["--workload", "c2", "--tuning", "strip=0"], "c2am": ["--workload", "c3", "--m1", "512", "--m2", "256", "--timesteps", "1000", "--instances", "256"], "c5": ["--workload", "c5"], "c5f64": ["--workload", "c5", "--state", "fp64"], "c4": ["--workload", "c4"],
 }
