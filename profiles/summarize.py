@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turns raw rocprofv3 output (gpurun_out/..., scratch) into the committed summaries under profiles/.
 
-    python profiles/summarize.py <raw_dir> <tag> [instances] [m1] [m2]
+    python profiles/summarize.py <raw_dir> <tag> [instances] [m1] [m2] [key prefix] [algorithmic bytes per point and pass]
 
 raw_dir holds kt/ (rocprofv3 --kernel-trace --stats of bench.py) and pmc/{sq1,sq2,fetch,write}
 (profiles/collect_pmc.sh).  Writes profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc_summary.json and
@@ -33,6 +33,8 @@ def main():
     inst = int(sys.argv[3]) if len(sys.argv) > 3 else 256
     m1 = int(sys.argv[4]) if len(sys.argv) > 4 else 512
     m2 = int(sys.argv[5]) if len(sys.argv) > 5 else 256
+    prefix = sys.argv[6] if len(sys.argv) > 6 else ""   # key prefix in pmc_traffic.json, e.g. "c5f64:" (bench.py looks it up)
+    bytes_alg = float(sys.argv[7]) if len(sys.argv) > 7 else 16.0  # algorithmic bytes per point and pass
     here = os.path.dirname(os.path.abspath(__file__))
     ks = glob.glob(os.path.join(raw, "kt", "*", "*kernel_stats.csv"))
     if ks:
@@ -60,7 +62,7 @@ def main():
         v["hbm_read_bytes_corrected"] = rd
         v["hbm_write_bytes"] = wr
         v["hbm_bytes_per_point"] = (rd + wr) / pts
-        v["algorithmic_bytes_per_point"] = 16.0
+        v["algorithmic_bytes_per_point"] = bytes_alg
         if "TCC_HIT_sum" in v:
             v["l2_hit_rate"] = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
         traffic[k] = rd + wr
@@ -70,7 +72,7 @@ def main():
     if pa:
         path = os.path.join(here, "pmc_traffic.json")
         rec = json.load(open(path)) if os.path.exists(path) else {}
-        rec["%dx%dx%d" % (m1, m2, inst)] = {
+        rec["%s%dx%dx%d" % (prefix, m1, m2, inst)] = {
             "pass_a_bytes_per_launch": pa[0], "pass_b_bytes_per_launch": pb[0] if pb else None,
             "source": "profiles/%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE x2 on gfx950)" % tag}
         json.dump(rec, open(path, "w"), indent=1, sort_keys=True)
