@@ -14,7 +14,7 @@ import pde_based_heston_solver_gpu_accelerated_amd as H
 import numpy as np, torch
 n, N = int(sys.argv[1]) if len(sys.argv) > 1 else 256, 20
 m1, m2 = int(os.environ.get("M1", "512")), int(os.environ.get("M2", "256"))
-strikes = [85 + 30 * k / (n - 1) for k in range(n)]
+strikes = [85 + 30 * k / max(1, n - 1) for k in range(n)]
 g = H.GridViewsBatch.for_strikes(m1, m2, 100.0, 0.04, strikes); U0 = g.call_payoff(strikes)
 dev = torch.device("cuda:0"); gd = g.to(dev); U = torch.from_numpy(U0).to(dev)
 s = H.HestonADI(0)
