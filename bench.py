@@ -261,7 +261,7 @@ def main():
             if os.path.exists(pmc):
                 try:
                     rec = json.load(open(pmc))
-                    key = "%s%s:%dx%dx%d" % (wl, "f64" if (wl == "c5" and not f32) else "", m1, m2, n_loc)
+                    key = "%s%s:%dx%dx%d" % (wl, "f64" if (wl == "c5" and state == "fp64") else "", m1, m2, n_loc)
                     key = key if key in rec else "%dx%dx%d" % (m1, m2, n_loc) if wl == "c2" else key
                     if key in rec:
                         roofline["traffic"] = rec[key]["pass_a_bytes_per_launch"]
