@@ -92,6 +92,35 @@ def surface_points(H):
     return H.make_calibration_points([S_0 * 0.75 + 1.0 * i for i in range(50)], mats)
 
 
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher: this process becomes the launcher.  It starts N copies of
+    itself -- one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on
+    127.0.0.1 -- BEFORE anything here touches the GPU or imports torch, relays rank 0's JSON line and exits non-zero if any
+    rank failed (the same contract as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)."""
+    import socket
+    import subprocess
+    import __graft_entry__ as G
+    G.build()  # once, here: the ranks then find the artefacts up to date (hipcc needs no GPU)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [q.wait() for q in procs[1:]]
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    if any(codes):
+        print("bench.py: rank exit codes %s" % codes, file=sys.stderr)
+        sys.exit(next(c for c in codes if c) if all(isinstance(c, int) for c in codes) else 1)
+    sys.exit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,6 +142,16 @@ def main():
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (a 1-GPU box cannot host one GPU per rank)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            spawn_ranks(args, sys.argv[1:])  # does not return
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        ap.error("--gpus %d does not match the launcher's WORLD_SIZE=%s: n_gpus on the result line is always --gpus"
+                 % (args.gpus, os.environ["WORLD_SIZE"]))
+    if args.state and args.workload in ("c3", "c4"):
+        ap.error("--state applies to the European workloads c2 and c5 (c3 is American, c4 runs LDS-resident in fp64)")
 
     import numpy as np
     import torch
@@ -138,7 +177,7 @@ def main():
     dist, group, collective = None, None, None
     if world > 1:
         dist, group, collective = init_distributed(args, torch, dev_index)
-    n_gpus = world if world > 1 else 1
+    n_gpus = args.gpus  # (== world: checked above)
     dev = torch.device("cuda", dev_index)
     coll_dev = dev if (group is not None) else torch.device("cpu")
     comm = H.Communicator(device=coll_dev, group=group)
@@ -318,7 +357,7 @@ def main():
                 single.update(reference_price=8.8942192888223310, price_abs_err=abs(price1 - 8.8942192888223310))
 
         state_err = None
-        if state == "fp32" and n_gpus == 1 and not args.skip_single:
+        if state == "fp32" and wl in ("c2", "c5") and n_gpus == 1 and not args.skip_single:
             # what the fp32 state costs at this step count: the K ~ 100 instance once more with the fp64 state
             gk = H.GridViewsBatch.for_strikes(m1, m2, S_0, V_0, [strikes[k_mid]])
             gkd, uk = gk.to(dev), torch.from_numpy(gk.call_payoff([strikes[k_mid]])).to(dev)

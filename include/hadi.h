@@ -59,7 +59,9 @@ enum hadi_status {
     HADI_ERR_HIP = 3,          /* a HIP runtime call failed */
     HADI_ERR_NOT_ON_GRID = 4,  /* S_0 is not a node of some instance's s-grid */
     HADI_ERR_NO_DEVICE = 5,    /* no usable GPU: the product has no CPU path */
-    HADI_ERR_ALLOC = 6
+    HADI_ERR_ALLOC = 6,
+    HADI_ERR_INTERNAL = 7      /* a kernel reported a failure through the handle's device error word (e.g. the bounded
+                                  rendezvous of a two-wavefront row ran out of polls): the outputs of the call are invalid */
 };
 
 enum hadi_variant { HADI_EU = 0, HADI_AM = 1, HADI_DIV = 2, HADI_AM_DIV = 3 };
@@ -179,7 +181,10 @@ int hadi_get_timing(const hadi_ctx *ctx, hadi_timing *out);
  *                 cache run sub-batch by sub-batch through the time loop (default 1; instances are independent)
  *   "device_vgrid" v-grids of compute_base_prices / compute_jacobian rebuilt per instance on the device (default 1;
  *                 0 = built once on the host with glibc sinh/asinh and broadcast -- bit-identical to the reference's
- *                 host-side Grid, needs one shared V_0) */
+ *                 host-side Grid, needs one shared V_0)
+ *   "debug_fault" TEST HOOK, 0 in production: 1 = the high half of every two-wavefront row (m1 > 512) withholds its
+ *                 rendezvous token on v-row 1, so that the partner's bounded poll runs out (~0.2 s) -- the call must then
+ *                 return HADI_ERR_INTERNAL instead of a field solved with stale exchange values */
 int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value);
 int hadi_get_tuning(const hadi_ctx *ctx, const char *key, int *value);
 /* Device the handle runs on: name, CU count, gcn arch string (for bench reports). */
@@ -256,6 +261,9 @@ int hadi_compute_parameter_update(int n, const double *J, const double *residual
  * Both run the product kernels the batch shape selects; p->U is not modified; out is [n][m] in p->memspace. */
 int hadi_debug_row_pass(hadi_ctx *ctx, const hadi_problem *p, int step, double *Y1rhs);
 int hadi_debug_col_solve(hadi_ctx *ctx, const hadi_problem *p, double *X);
+/* out[k] = the reciprocal of x[k] exactly as the line solves of the sweep form it (v_rcp_f64 + one Newton step: within
+ * 1.5 ulp, no IEEE division); x and out are HOST arrays of n doubles.  Tests bound its error. */
+int hadi_debug_rcp(hadi_ctx *ctx, int n, const double *x, double *out);
 
 #ifdef __cplusplus
 }

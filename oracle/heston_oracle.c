@@ -24,6 +24,12 @@
 #include <omp.h>
 #endif
 
+/* fp64 under its own name: the adjudicator build (heston_oracle_xp.c) compiles this file with `double` redefined to an
+ * extended type, but the dividend dating below must keep the reference's fp64 round-off either way. */
+#ifndef HO_F64
+#define HO_F64 double
+#endif
+
 /* ---- coeff.hpp:24-126 : 3-point non-uniform FD weights ------------------ */
 static double fd_delta(const double *D, int i, int pos) {
     if (pos == -1) return 2 / (D[i] * (D[i] + D[i + 1]));
@@ -502,10 +508,11 @@ static void timestepping(ho_ws *w, const ho_params *p, const double *vec_s,
 
     for (int n = 1; n <= N; n++) {
         if (dividend) { /* device_solver.hpp:426-517 */
-            const double t = n * delta_t;
+            /* (quirk) dated in fp64: n * delta_t = 12 * 0.05 = 0.6000000000000001 decides the step */
+            const HO_F64 t = n * (HO_F64)delta_t, t_next = (n + 1) * (HO_F64)delta_t;
             const int process = (current_div_idx < p->num_dividends &&
                                  t <= p->div_dates[current_div_idx] &&
-                                 p->div_dates[current_div_idx] < (n + 1) * delta_t);
+                                 p->div_dates[current_div_idx] < t_next);
             if (process) {
                 dividend_jump(w, vec_s, U, p->div_amounts[current_div_idx], p->div_percentages[current_div_idx], p->option_type == 1);
                 if (p->state_fp32) /* libhadi widens, jumps and rounds the state again */

@@ -11,6 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libheston_oracle.so")
+_LIB_XP_PATH = os.path.join(_HERE, "libheston_oracle_xp.so")  # the extended-precision adjudicator (heston_oracle_xp.c)
 
 EU, AM, DIV, AM_DIV = 0, 1, 2, 3
 _dp = C.POINTER(C.c_double)
@@ -43,8 +44,9 @@ def build(force=False):
     fd = os.open(os.path.join(_HERE, ".build.lock"), os.O_CREAT | os.O_RDWR, 0o644)
     try:  # several test ranks may get here at once
         fcntl.flock(fd, fcntl.LOCK_EX)
-        if force or not os.path.exists(_LIB_PATH) or \
-                os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "heston_oracle.c")):
+        srcs = [os.path.join(_HERE, f) for f in ("heston_oracle.c", "heston_oracle.h", "heston_oracle_xp.c", "Makefile")]
+        newest = max(os.path.getmtime(f) for f in srcs)
+        if force or any(not os.path.exists(l) or os.path.getmtime(l) < newest for l in (_LIB_PATH, _LIB_XP_PATH)):
             subprocess.check_call(["make", "-C", _HERE, "-s"])
     finally:
         fcntl.flock(fd, fcntl.LOCK_UN)
@@ -154,6 +156,36 @@ def solve_batch(params, vec_s, vec_v, delta_s, delta_v, U, U_0=None, threads=0, 
     t = lib().ho_solve_batch(C.byref(params), C.c_int(n), _p(_f64(vec_s)), _p(_f64(vec_v)),
                              _p(_f64(delta_s)), _p(_f64(delta_v)), _p(U), _p(U_0), _p(lam), C.c_int(threads))
     return U, lam, t
+
+
+_lib_xp = None
+
+
+def solve_xp(params, vec_s, vec_v, delta_s, delta_v, U, U_0=None, strike=None):
+    """ONE instance through the adjudicator: the oracle's source compiled with binary128 arithmetic
+    (heston_oracle_xp.c); fp64 inputs widened exactly, outputs rounded to fp64 once.  Returns (U_T, lambda_bar or None).
+    ~100x slower than solve(): meant for the handful of instances a parity test or the fuzz tool needs adjudicated."""
+    global _lib_xp
+    if _lib_xp is None:
+        build()
+        _lib_xp = C.CDLL(_LIB_XP_PATH)
+        _lib_xp.hoxp_solve.restype = C.c_int
+    p = params
+    m = (p.m1 + 1) * (p.m2 + 1)
+    U = _f64(U).reshape(-1).copy()
+    U_0 = None if U_0 is None else _f64(U_0).reshape(-1)
+    assert U.size == m and np.asarray(vec_s).size == p.m1 + 1 and np.asarray(vec_v).size == p.m2 + 1
+    lam = np.zeros(m) if p.variant in (AM, AM_DIV) else None
+    nd = p.num_dividends
+    rc = _lib_xp.hoxp_solve(
+        C.c_int(p.m1), C.c_int(p.m2), C.c_int(p.N), C.c_int(p.variant), C.c_double(p.delta_t), C.c_double(p.theta),
+        C.c_double(p.r_d), C.c_double(p.r_f), C.c_double(p.rho), C.c_double(p.sigma), C.c_double(p.kappa), C.c_double(p.eta),
+        C.c_int(nd), p.div_dates if nd else None, p.div_amounts if nd else None, p.div_percentages if nd else None,
+        C.c_int(p.scheme), C.c_int(p.state_fp32), C.c_int(p.option_type), C.c_double(p.strike if strike is None else strike),
+        _p(_f64(vec_s)), _p(_f64(vec_v)), _p(_f64(delta_s)), _p(_f64(delta_v)), _p(U), _p(U_0), _p(lam))
+    if rc != 0:
+        raise RuntimeError("hoxp_solve failed rc=%d" % rc)
+    return U, lam
 
 
 def base_prices(params, S_0, V_0, vec_s, vec_v, delta_s, delta_v, U, U_0=None, V=5.0, d=5.0 / 500, threads=0):

@@ -69,7 +69,7 @@ EXPORTS = [
     "hadi_compute_jacobian", "hadi_compute_jacobian_american",
     "hadi_compute_jacobian_dividends", "hadi_compute_jacobian_american_dividends",
     "hadi_lm_partials", "hadi_lm_partials_device", "hadi_lm_solve", "hadi_compute_parameter_update",
-    "hadi_debug_row_pass", "hadi_debug_col_solve",
+    "hadi_debug_row_pass", "hadi_debug_col_solve", "hadi_debug_rcp",
 ]
 
 _lib = None
@@ -117,6 +117,7 @@ def _load(LIB_PATH):
     L.hadi_lm_partials_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _dp]
     L.hadi_debug_row_pass.argtypes = [C.c_void_p, C.POINTER(Problem), C.c_int, C.c_void_p]
     L.hadi_debug_col_solve.argtypes = [C.c_void_p, C.POINTER(Problem), C.c_void_p]
+    L.hadi_debug_rcp.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
     L.hadi_device_info.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _ip, C.c_char_p, C.c_int]
     L.hadi_describe_last_sweep.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.hadi_stream.argtypes = [C.c_void_p]

@@ -59,6 +59,11 @@ struct Ctx {
     DevBuf div_flag, div_amt, div_pct;
     DevBuf pay_mis;  // American: per-instance payoff-shape flags (hadi_payoff_shape_kernel)
     DevBuf order;    // small-grid path: dispatch order of the instances (multi-maturity batches)
+    // Sticky device error word: one int in host-pinned, device-visible memory.  Kernels OR a HADI_DEVERR_* code into it
+    // (system-scope atomic, only ever on a failure path); finish_timing reads it after the stream synchronisation every
+    // entry point ends with -- no copy, no extra launch -- and turns a non-zero word into HADI_ERR_INTERNAL.
+    int *err_host = nullptr, *err_dev = nullptr;
+    int debug_fault = 0;  // test hook (hadi_set_tuning "debug_fault"): HADI_DEBUG_* bits handed to the sweep kernels
 };
 
 // Every GPU entry point runs on the handle's device whatever the caller's current device is (a torch rank that
@@ -260,7 +265,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     struct SubBatch { int off, cnt; HadiPlan pl; };
     std::vector<SubBatch> subs;
     if (d.scheme == HADI_SCHEME_DOUGLAS && !d.debug && c->sub_batch && d.n > c->cu_count &&
-        2ll * c->cu_count * pl.L.inst_stride * (long long)sizeof(double) >= (256ll << 20)) {
+        2ll * c->cu_count * pl.L.inst_stride * (long long)state_bytes >= (256ll << 20)) {  // (bytes the sweep streams: 4 per element with the fp32 state)
         const int cu = c->cu_count, full = d.n / cu, rem = d.n - full * cu;
         for (int k = 0; k < full; k++) subs.push_back(SubBatch{k * cu, cu, pl});
         if (rem >= cu / 4) subs.push_back(SubBatch{full * cu, rem, pl});
@@ -387,6 +392,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     a.L = L; a.n_inst = d.n; a.R = pl.R; a.ntiles = pl.ntiles; a.ctiles = pl.ctiles; a.btpw = pl.btpw; a.bgroups = pl.bgroups;
     a.american = american ? 1 : 0; a.pos_m1 = pl.pos_m1;
     a.RS = pl.RS; a.sblocks = pl.sblocks;
+    a.err = c->err_dev; a.debug = c->debug_fault;
     a.R1 = cs ? ptr<double>(c->R1) : nullptr;
     a.C2 = cs ? ptr<double>(c->C2) : nullptr;
     // Craig-Sneyd: the predictor's column pass writes V (= Y2), the corrector's row pass reads V
@@ -668,8 +674,8 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         std::string key;
         auto put = [&](const void *p_, size_t nbytes) { key.append(static_cast<const char *>(p_), nbytes); };
         {  // field by field: struct padding is not initialised
-            const void *ptrs[] = {a.pay_mis, a.U, a.Y, a.LAM, a.U0, a.scoef, a.b2row, a.rowc, a.pb, a.rinv, a.ipar, a.R1, a.C2, av.U};
-            const int ints[] = {a.L.m1, a.L.m2, a.L.B, a.L.G, a.L.P, a.n_inst, a.R, a.ntiles, a.ctiles, a.btpw, a.bgroups,
+            const void *ptrs[] = {a.pay_mis, a.U, a.Y, a.LAM, a.U0, a.scoef, a.b2row, a.rowc, a.pb, a.rinv, a.ipar, a.R1, a.C2, av.U, a.err};
+            const int ints[] = {a.debug, a.L.m1, a.L.m2, a.L.B, a.L.G, a.L.P, a.n_inst, a.R, a.ntiles, a.ctiles, a.btpw, a.bgroups,
                                 a.american, a.pos_m1, d.scheme, d.prec, (int)amp, pl.use_strip, pl.RS, pl.sblocks, pl.grid_as, pl.grid_a, pl.grid_b, pl.block_b, pl.W, (int)pl.smem_a, (int)pl.smem_b};
             put(ptrs, sizeof(ptrs));
             put(ints, sizeof(ints));
@@ -724,6 +730,8 @@ int finish_timing(Ctx *c, const SweepDesc &d, const HadiPlan &pl) {
     hipStream_t s = c->stream;
     HIP_TRY(c, hipEventRecord(c->ev[3], s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    // the sticky device error word (see Ctx::err_host): whatever a kernel of this call reported is visible now
+    const int deverr = __atomic_exchange_n(c->err_host, 0, __ATOMIC_ACQ_REL);
     float ms = 0;
     hadi_timing &t = c->timing;
     t = hadi_timing{};
@@ -743,6 +751,9 @@ int finish_timing(Ctx *c, const SweepDesc &d, const HadiPlan &pl) {
         t.pass_b_launches = (long long)d.Nmax * c->last_nsub;
     }
     (void)pl;
+    if (deverr)
+        return fail(c, HADI_ERR_INTERNAL, "device-side failure 0x%x during the sweep%s: the results of this call are invalid", deverr,
+                    (deverr & HADI_DEVERR_RENDEZVOUS) ? " (a pair rendezvous of a two-wavefront row ran out of polls)" : "");
     return HADI_OK;
 }
 
@@ -1079,6 +1090,7 @@ void release_handle(Ctx *c) {
         if (e) (void)hipEventDestroy(e);
     if (c->wait_ev) (void)hipEventDestroy(c->wait_ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->err_host) (void)hipHostFree(c->err_host);
     delete c;
 }
 
@@ -1110,6 +1122,7 @@ const char *hadi_status_string(int s) {
         case HADI_ERR_NOT_ON_GRID: return "S_0 is not a grid node";
         case HADI_ERR_NO_DEVICE: return "no usable gfx950 GPU (libhadi has no CPU path)";
         case HADI_ERR_ALLOC: return "device allocation failed";
+        case HADI_ERR_INTERNAL: return "device-side failure reported by a kernel (results invalid)";
         default: return "unknown";
     }
 }
@@ -1133,6 +1146,11 @@ int hadi_create(hadi_ctx **out, int device_id) {
     ok = ok && raise_all_lds_limits() == hipSuccess;
     for (auto &e : c->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&c->err_host), 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+    if (ok) {
+        *c->err_host = 0;
+        ok = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->err_dev), c->err_host, 0) == hipSuccess;
+    }
     if (!ok) {  // one way out: whatever was created is released
         release_handle(c);
         return HADI_ERR_HIP;
@@ -1171,6 +1189,7 @@ int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value) {
     else if (!std::strcmp(key, "device_vgrid")) c->device_vgrid = value ? 1 : 0;
     else if (!std::strcmp(key, "sub_batch")) c->sub_batch = value ? 1 : 0;
     else if (!std::strcmp(key, "strip")) c->tune.strip = value < 0 ? -1 : (value ? 1 : 0);
+    else if (!std::strcmp(key, "debug_fault")) c->debug_fault = value;
     else if (!std::strcmp(key, "row_tile")) c->tune.row_tile = value > 0 ? value : 0;
     else if (!std::strcmp(key, "col_groups")) c->tune.col_groups = value > 0 ? value : 0;
     else if (!std::strcmp(key, "small_waves")) {
@@ -1190,6 +1209,7 @@ int hadi_get_tuning(const hadi_ctx *ctx, const char *key, int *value) {
     else if (!std::strcmp(key, "device_vgrid")) *value = c->device_vgrid;
     else if (!std::strcmp(key, "sub_batch")) *value = c->sub_batch;
     else if (!std::strcmp(key, "strip")) *value = c->tune.strip;
+    else if (!std::strcmp(key, "debug_fault")) *value = c->debug_fault;
     else if (!std::strcmp(key, "row_tile")) *value = c->tune.row_tile;
     else if (!std::strcmp(key, "col_groups")) *value = c->tune.col_groups;
     else if (!std::strcmp(key, "small_waves")) *value = c->tune.small_waves;
@@ -1288,6 +1308,21 @@ int hadi_debug_row_pass(hadi_ctx *ctx, const hadi_problem *p, int step, double *
 
 int hadi_debug_col_solve(hadi_ctx *ctx, const hadi_problem *p, double *X) {
     return solve_common(reinterpret_cast<Ctx *>(ctx), p, false, false, 0.0, 0.0, nullptr, 2, 1, X);
+}
+
+int hadi_debug_rcp(hadi_ctx *ctx, int n, const double *x, double *out) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return HADI_ERR_INVALID;
+    if (n < 1 || !x || !out) return fail(c, HADI_ERR_INVALID, "bad arguments");
+    DeviceGuard guard(c->device);
+    int rc;
+    if ((rc = ensure(c, c->natU, (size_t)n * 8)) || (rc = ensure(c, c->natOut, (size_t)n * 8))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->natU.p, x, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(hadi_rcp_kernel, dim3(grid1d((size_t)n)), dim3(256), 0, c->stream, n, ptr<double>(c->natU), ptr<double>(c->natOut));
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, c->natOut.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HADI_OK;
 }
 
 #define HADI_VARIANT_WRAPPERS(suffix, variant)                                                                   \

@@ -43,7 +43,30 @@ struct HadiSweepArgs {
     int btpw, bgroups;  // pass B: column tiles per block, blocks per instance
     int american;
     int pos_m1;      // storage position of i = m1 (lambda_bar is forced to 0 there)
+    int *err;        // the handle's sticky error word (host-pinned, device-visible): kernels OR a HADI_DEVERR_* code into it,
+                     // the host reads it after the sweep and fails the call (hadi.h: HADI_ERR_INTERNAL)
+    int debug;       // test hooks, 0 in production (hadi_set_tuning "debug_fault"): HADI_DEBUG_* bits
 };
+
+// Device-side error codes (bits of *HadiSweepArgs.err)
+#define HADI_DEVERR_RENDEZVOUS 1  // a pair rendezvous of the two-wavefront rows ran out of polls: the partner's token never came
+// Test hooks (bits of HadiSweepArgs.debug)
+#define HADI_DEBUG_WITHHOLD_TOKEN 1  // the high half of every two-wavefront row withholds its token on v-row 1
+
+// Bounded poll of the pair rendezvous: ~0.2 s on the GPU (a resident partner answers within microseconds; under the
+// host-thread emulator every poll is a sched_yield of one of 512 threads).  With the test hook set the bound is short,
+// so that the forced failure costs microseconds.
+#define HADI_RENDEZVOUS_POLLS(debug) (((debug) & HADI_DEBUG_WITHHOLD_TOKEN) ? (1 << 12) : (1 << 22))
+// Guard exhausted: record it where the host will see it.  The row is solved with whatever the exchange buffer holds -- the
+// kernel must drain, a hang would cost the GPU -- and the host turns the recorded code into HADI_ERR_INTERNAL: a stale-value
+// solve is never returned as HADI_OK.
+HADI_DEV HADI_FORCEINLINE void hadi_report(int *err, int code) {
+#if defined(HADI_EMU)
+    __atomic_fetch_or(err, code, __ATOMIC_RELAXED);
+#else
+    __hip_atomic_fetch_or(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+}
 
 // Blocks b and b+8 share an XCD (and its L2).  Map the dispatch index so that consecutive logical
 // ids -- neighbouring row tiles of one instance, which share halo rows -- land on the same XCD.
@@ -465,6 +488,8 @@ struct HadiRowCtxT {
     const double *payrow;
     double inv_dt;
     int m1_lane, m1_r;
+    int *err;            // HadiSweepArgs.err / .debug (used by the G = 2 rendezvous only)
+    int debug;
     HADI_STAMP_ACC
 };
 typedef HadiRowCtxT<double> HadiRowCtx;
@@ -669,6 +694,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
         hadi_get_block<B, G>(c.coef + 3 * 64 * B * G, half, lane, Dp);
         double iu[B], cp[B];
         double il_last = 0.0, im_last = 1.0, d_last = 0.0;
+        double il_moved = 0.0;  // the i = 1 row's coupling to x_0 once it has been moved to the right-hand side
 #pragma unroll
         for (int r = 0; r < B; r++) {
             const double uL = (r == 0) ? u0L : u0[r == 0 ? 0 : r - 1];
@@ -695,6 +721,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
             iu[r] = -thdt * up;
             if (r == 0 && lane == 0 && first_half) {  // x_0 is known: move it to the right-hand side
                 y -= il * x0;
+                il_moved = il;
                 il = 0.0;
             }
             if (r < NB) {
@@ -716,6 +743,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
                 d_last = y;
             }
         }
+        (void)il_moved;
         HADI_STAMP(2);  // coefficients + Y0 + forward Thomas
         // reduced (interface) row of this lane:  ra*X(l-1) + rb*X(l) + rcc*X(l+1) = rf [- rs * boundary value]
         double ra, rb, rcc, rf, rs = 0.0;
@@ -749,7 +777,54 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
         // ---- parallel cyclic reduction over the 64 interface unknowns (normalised rows) -------------
         // Lanes without a partner at distance s have ra == 0 (left) / rcc == 0 (right) by induction, so the
         // (wrapped) values they fetch are multiplied by zero: no lane masks are needed.
-        {
+        if constexpr (NB == 0) {
+            // One node per lane (m1 <= 64: the reference's calibration grids): the cyclic reduction IS the whole line solve,
+            // so two nodes a tiny interval apart (S_0 inserted 7e-6 beside a node: off-diagonals of 1e7 against a row sum of
+            // ~1) are two of its unknowns.  In the plain update the new diagonal 1 - a cL - c aR is a difference of numbers
+            // that agree to 7 digits; the two nodes come out with independent errors of cond * eps each, and the NEXT
+            // step multiplies their difference by the 1e7 coupling again (found by the extended-precision adjudicator,
+            // oracle/heston_oracle_xp.c: fuzz seed 5 case 279, field error 1.7e-7 against 4.5e-10 for the Thomas sweep
+            // of the reference).  Carrying every row's EXCESS d = 1 + a + c (diagonal dominance; known analytically,
+            // 1 + theta dt r_d / 2 before normalisation) removes the cancellation: with cL = dL - 1 - aL, aR = dR - 1 - cR
+            //   new excess   e  = d - a dL - c dR          (for an M-matrix row: a sum of non-negative terms)
+            //   new diagonal bn = e + a aL + c cR           (likewise)
+            // Same number of cross-lane fetches as the plain update (dL, dR replace cL, aR), three more VALU operations
+            // per level.  The algebra holds for any signs; only the no-cancellation property needs a, c <= 0.
+            hadi_set_prio(3);
+            double rd = (1.0 + thdt * half_rd) - il_moved;  // row sum il + im + iu of I - theta dt A1 (il of the first node moved out)
+            rb = rd - ra - rcc;                              // diagonal from the off-diagonals and the excess
+            const double rinv0 = hadi_rcp(rb);
+            ra *= rinv0;
+            rcc *= rinv0;
+            rf *= rinv0;
+            rd *= rinv0;
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) {
+                const int up_lane = (lane - s) & 63, dn_lane = (lane + s) & 63;
+                double aL, dL, fL, cR, dR, fR;
+                if (s == 1) {
+                    aL = hadi_lane_prev(ra); dL = hadi_lane_prev(rd); fL = hadi_lane_prev(rf);
+                    cR = hadi_lane_next(rcc); dR = hadi_lane_next(rd); fR = hadi_lane_next(rf);
+                } else if (s == 32) {  // lane - 32 and lane + 32 are the same lane (mod 64)
+                    aL = hadi_lane_get(ra, up_lane); cR = hadi_lane_get(rcc, up_lane);
+                    dL = dR = hadi_lane_get(rd, up_lane); fL = fR = hadi_lane_get(rf, up_lane);
+                } else {
+                    aL = hadi_lane_get(ra, up_lane); dL = hadi_lane_get(rd, up_lane); fL = hadi_lane_get(rf, up_lane);
+                    cR = hadi_lane_get(rcc, dn_lane); dR = hadi_lane_get(rd, dn_lane); fR = hadi_lane_get(rf, dn_lane);
+                }
+                const double e = fma(-rcc, dR, fma(-ra, dL, rd));
+                const double bn = fma(rcc, cR, fma(ra, aL, e));
+                const double rn = hadi_rcp(bn);
+                rf = fma(-rcc, fR, fma(-ra, fL, rf)) * rn;
+                if (s < 32) {  // the last level only needs the right-hand side
+                    const double an = -(ra * aL) * rn;
+                    const double cn = -(rcc * cR) * rn;
+                    ra = an;
+                    rcc = cn;
+                    rd = e * rn;
+                }
+            }
+        } else {
             hadi_set_prio(3);
             const double rinv0 = hadi_rcp(rb);
             ra *= rinv0;
@@ -816,15 +891,19 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
         // behind its two values (same lane, so the LDS unit sees data before flag) and polls the partner's.  Both are
         // resident wavefronts of one block and `active` is the same for both, so the partner always arrives; the loop-top
         // barrier of the next iteration separates this exchange from the next use of the slots.  The poll is bounded so
-        // that a logic error can never hang the GPU (it would fail parity instead).
+        // that a logic error can never hang the GPU; running out of polls is reported through the handle's error word
+        // (hadi_report) and fails the call.
         if (active) {
             int *flags = reinterpret_cast<int *>(c.xch + 8 * c.wrow + 4);
             const int token = j + 1;
             const bool publisher = (!last_half && lane == 63) || (!first_half && lane == 0);  // the lanes that wrote the values
-            if (publisher) __hip_atomic_store(flags + half, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const bool withhold = (c.debug & HADI_DEBUG_WITHHOLD_TOKEN) && half == 1 && j == 1;  // (test hook)
+            if (publisher && !withhold) __hip_atomic_store(flags + half, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             int guard = 0;
-            while (__hip_atomic_load(flags + (1 - half), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != token && ++guard < (1 << 22))
+            const int polls = HADI_RENDEZVOUS_POLLS(c.debug);
+            while (__hip_atomic_load(flags + (1 - half), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != token && ++guard < polls)
                 __builtin_amdgcn_s_sleep(1);
+            if (guard >= polls && lane == 0) hadi_report(c.err, HADI_DEVERR_RENDEZVOUS);
         }
 #endif
     }
@@ -956,6 +1035,7 @@ __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : B == 4 ? HADI_R
     c.R1i = MODE ? a.R1 + (size_t)inst * a.L.inst_stride : nullptr;
     c.C2i = MODE ? a.C2 + (size_t)inst * a.L.inst_stride : nullptr;
     c.j0 = j0;
+    c.err = a.err; c.debug = a.debug;
     constexpr int c0slot = 64 * B * G;
     // storage positions of the s-neighbours of this lane's block (node before its first, node after its
     // last).  Before i = 1 comes the i = 0 slot; after the row's last node comes a pad slot (always 0).
@@ -1092,6 +1172,8 @@ struct HadiStripCtxT {
     int m1_lane, m1_r;
     int half;                 // G = 2: which half of the row this wavefront owns (0: nodes 1..64B, 1: the rest)
     double *xch;              // G = 2: LDS exchange of the wavefront pair, [2 row parities][4 values + 2 tokens + 2 spare]
+    int *err;                 // HadiSweepArgs.err / .debug (G = 2 rendezvous)
+    int debug;
     HADI_STAMP_ACC
 };
 
@@ -1347,10 +1429,12 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
         //   high half, lane 0:  t = C - x_hi D    (t = its first node = ys0 - XL ps0 - X gs0, XL = x_hi)
         // into the buffer of this row's parity, then the token behind the values (same lane: the LDS unit sees data before
         // flag).  The partner walks the same strip in the same direction, so it always arrives; it can be at most one row
-        // away, hence two buffers are enough.  The poll is bounded: a logic error fails parity instead of hanging the GPU.
+        // away, hence two buffers are enough.  The poll is bounded (a logic error must not hang the GPU); running out of
+        // polls is reported through the handle's error word (hadi_report) and fails the call.
         double *xb = c.xch + 8 * (j & 1);
         int *flags = reinterpret_cast<int *>(xb + 4);
         const int token = j + 1;
+        const bool withhold = (c.debug & HADI_DEBUG_WITHHOLD_TOKEN) && half == 1 && j == 1;  // (test hook)
         if (edge_hi) {
             xb[0] = rf;
             xb[1] = rs;
@@ -1359,17 +1443,19 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
         if (edge_lo) {
             xb[2] = ys[0] - rf * gs[0];
             xb[3] = ps[0] - rs * gs[0];
-            hadi_flag_store(flags + 1, token);
+            if (!withhold) hadi_flag_store(flags + 1, token);
         }
         hadi_wave_rendezvous();  // (emulator: this wavefront's own publisher lane has written)
         int guard = 0;
-        while (hadi_flag_load(flags + (1 - half)) != token && ++guard < (1 << 22)) {
+        const int polls = HADI_RENDEZVOUS_POLLS(c.debug);
+        while (hadi_flag_load(flags + (1 - half)) != token && ++guard < polls) {
 #if defined(HADI_EMU)
             sched_yield();
 #else
             __builtin_amdgcn_s_sleep(1);
 #endif
         }
+        if (guard >= polls && lane == 0) hadi_report(c.err, HADI_DEVERR_RENDEZVOUS);
         const double A = xb[0], Bc = xb[1], Cc = xb[2], Dd = xb[3];
         const double xhi = (A - Bc * Cc) / (1.0 - Bc * Dd);  // last node of the low half
         const double tlo = Cc - Dd * xhi;                    // first node of the high half
@@ -1459,6 +1545,7 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     c.coef = coef;
     c.half = half;
     c.xch = coef + 4 * 64 * B * G + pair * 16;
+    c.err = a.err; c.debug = a.debug;
     c.dt = hadi_uniform_d(ip.dt); c.thdt = hadi_uniform_d(ip.thdt);
     c.qth = hadi_uniform_d(ip.thdt * ip.q);
     c.c2 = hadi_uniform_d(ip.thdt * ip.half_rd);
@@ -2211,7 +2298,7 @@ __global__ void __launch_bounds__(64 * W) hadi_small_kernel(HadiSweepArgs a, Had
     c.Yi = Yl; c.Li = AMER ? LAMl : nullptr;
     c.rowc = rtab; c.j0 = 0;
     c.b2r = a.b2row + (size_t)inst * rowp;
-    c.coef = coef; c.xch = nullptr; c.R1i = nullptr; c.C2i = nullptr;
+    c.coef = coef; c.xch = nullptr; c.R1i = nullptr; c.C2i = nullptr; c.err = a.err; c.debug = 0;
     c.payrow = nullptr; c.inv_dt = 0.0; c.m1_lane = -1; c.m1_r = -1;
     {
         const int ifirst = 1 + B * lane;
@@ -2936,6 +3023,11 @@ __global__ void __launch_bounds__(256) hadi_jacobian_rows_kernel(int n0, const d
     const double b = prices[k];
     base[k] = b;
     for (int g = 1; g <= 5; g++) J[(size_t)k * 5 + (g - 1)] = (prices[(size_t)g * n0 + k] - b) / eps;
+}
+
+// Diagnostics (hadi_debug_rcp): the reciprocal every line solve of the sweep uses, elementwise.
+__global__ void __launch_bounds__(256) hadi_rcp_kernel(int n, const double *__restrict__ x, double *__restrict__ out) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) out[e] = hadi_rcp(x[e]);
 }
 
 // Replicate one of `nsrc` source rows (length len) into every instance's row: dst[inst] = src[sel[inst]]

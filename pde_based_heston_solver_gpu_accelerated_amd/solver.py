@@ -269,6 +269,15 @@ class HestonADI:
             self._raise(rc)
         return out
 
+    def debug_rcp(self, x):
+        """1/x exactly as the line solves of the sweep form it (v_rcp_f64 + one Newton step), elementwise (tests)."""
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        out = np.empty_like(x)
+        rc = self._lib.hadi_debug_rcp(self._h, int(x.size), x.ctypes.data_as(nat._dp), out.ctypes.data_as(nat._dp))
+        if rc != nat.HADI_OK:
+            self._raise(rc)
+        return out
+
     # ---- CS_scheme_shuffled (src/solver.hpp:781-907), batched on the device -----------------------
     def CS_scheme(self, m1, m2, N, delta_t, theta, r_d, r_f, rho, sigma, kappa, eta, grids, U, per_instance=None):
         """Craig-Sneyd time stepping of European options: Douglas predictor + corrector that re-adds half of

@@ -31,6 +31,8 @@ def main():
     U0 = grids.call_payoff(ks)
     market = np.array([H.market.call_price(Cm.S_0, p.strike, Cm.R_D, 0.2, p.maturity) for p in mine])
     solver = H.HestonADI(0)
+    if "--small-seq" in sys.argv:  # pin the small-grid kernel whatever the shard size (the automatic choice goes by batch size)
+        solver.set_tuning("small_seq", int(sys.argv[sys.argv.index("--small-seq") + 1]))
     if "--device-arrays" in sys.argv:
         # HBM-resident shard: Jacobian rows and prices stay on the GPU, hadi_lm_partials_device reduces them there and only
         # the 31 doubles of the all-reduce leave it

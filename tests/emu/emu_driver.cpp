@@ -17,12 +17,15 @@ thread_local int t_lane;
 
 // kernel-selection overrides, the emulator's stand-in for hadi_set_tuning
 static HadiTuning g_tune;
+static int g_err = 0, g_debug = 0;  // the handle's device error word and the "debug_fault" test hook
+extern "C" int emu_take_error() { const int e = g_err; g_err = 0; return e; }
 extern "C" int emu_set_tuning(const char *key, int value) {
     const std::string k(key);
-    if (k == "strip") g_tune.strip = value < 0 ? -1 : (value ? 1 : 0);
+    if (k == "debug_fault") g_debug = value;
+    else if (k == "strip") g_tune.strip = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "row_tile") g_tune.row_tile = value > 0 ? value : 0;
     else if (k == "col_groups") g_tune.col_groups = value > 0 ? value : 0;
-    else if (k == "reset") g_tune = HadiTuning();
+    else if (k == "reset") { g_tune = HadiTuning(); g_debug = 0; }
     else return 1;
     return 0;
 }
@@ -192,6 +195,7 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
     a.scoef = scoef.data(); a.b2row = b2row.data(); a.rowc = rowc.data(); a.pb = pb.data(); a.rinv = rinv.data();
     a.ipar = ipar.data(); a.L = L; a.n_inst = n_inst; a.R = pl.R; a.ntiles = pl.ntiles; a.ctiles = pl.ctiles; a.btpw = pl.btpw; a.bgroups = pl.bgroups;
     a.american = american; a.pos_m1 = pl.pos_m1; a.RS = pl.RS; a.sblocks = pl.sblocks;
+    a.err = &g_err; a.debug = g_debug;
     std::vector<int> pay_mis(n_inst, 0);
     a.pay_mis = american ? pay_mis.data() : nullptr;
     if (american) emu::launch(8, 64, [&]() { hadi_payoff_shape_kernel(L, n_inst, dU0.data(), pay_mis.data()); });

@@ -4,6 +4,8 @@ inside the loop are supplied by an oracle-backed stand-in solver defined HERE in
 solver needs a GPU); what is under test is the host logic and the collective."""
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -15,6 +17,8 @@ import pde_based_heston_solver_gpu_accelerated_amd as H
 from oracle import oracle as O
 
 import common as Cm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 OracleSolver = Cm.OracleSolver
@@ -147,3 +151,20 @@ def test_two_rank_gloo_lm_matches_single_rank():
         assert np.allclose(got, want, rtol=1e-5, atol=1e-9)
         assert solves == single["pde_solves"]
     assert out[0][3] == out[1][3]
+
+
+def test_bench_gpus_flag_is_never_ignored():
+    """bench.py --gpus N: (1) under a launcher whose WORLD_SIZE differs the run is refused before any GPU work; (2) without a
+    launcher and N > 1 the process spawns its N ranks itself and passes their failure on -- here there is no GPU, so every
+    rank fails in torch.cuda and the parent must exit non-zero with the rank codes (never a silent one-GPU run)."""
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    bad = subprocess.run([sys.executable, bench, "--gpus", "2"], capture_output=True, text=True, timeout=120,
+                         env=dict(env, WORLD_SIZE="3", RANK="0"))
+    assert bad.returncode != 0 and "does not match" in bad.stderr
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: the spawning path is exercised for real in tests/test_distributed_gpu.py")
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "c4",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode != 0 and "rank exit codes [1, 1]" in out.stderr and not out.stdout.strip()

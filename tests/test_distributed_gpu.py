@@ -37,6 +37,18 @@ def test_two_rank_calibration_equals_single_rank():
     assert max(abs(x - y) for x, y in zip(one["prices"], two["prices"])) <= 1e-4
 
 
+@pytest.mark.parametrize("small_seq", [0, 1])
+def test_two_rank_calibration_equals_single_rank_on_one_kernel(small_seq):
+    """The tight version of the comparison above: with the small-grid kernel PINNED (hadi_set_tuning "small_seq") both runs
+    execute the same arithmetic per instance and differ only in the summation order of the 31 doubles across ranks -- the
+    per-iteration errors then agree to 1e-6 (the 1e-4 bound above covers the mixed-kernel comparison only)."""
+    one, two = _run(1, 29638 + 2 * small_seq, "--small-seq", str(small_seq)), _run(2, 29639 + 2 * small_seq, "--small-seq", str(small_seq))
+    assert one["iterations"] == two["iterations"] and one["pde_solves"] == two["pde_solves"]
+    for a, b in zip(one["errors"], two["errors"]):
+        assert abs(a - b) <= 1e-6 * max(1.0, a), (one["errors"], two["errors"])
+    assert max(abs(x - y) for x, y in zip(one["prices"], two["prices"])) <= 1e-6
+
+
 def test_two_rank_calibration_with_device_resident_shards():
     """The same two-rank run with HBM-resident shards: J and the prices never leave the GPU, J^T J / J^T r / sum r^2 are
     reduced by hadi_lm_partials_device and only the 31 doubles cross to the all-reduce (here over a gloo subgroup --
@@ -67,6 +79,29 @@ def test_bench_refuses_gloo_for_a_multi_gpu_number():
     rec = json.loads(lines[-1])
     assert rec["n_gpus"] == 2 and rec["config"]["timing_collective"].startswith("gloo") and rec["value"] > 0
     assert rec["scaling"] == "strong" and rec["config"]["instances_total"] == 500
+
+
+@pytest.mark.parametrize("workload", ["c4", "c2"])
+def test_bench_spawns_its_own_ranks(workload):
+    """`python bench.py --gpus 2` WITHOUT a launcher (the shape of the driver's single-GPU command with another N): the parent
+    starts the ranks itself before anything touches the GPU, relays rank 0's line, and n_gpus on the line equals --gpus.
+    c4 is the one workload with a collective inside the timed region; c2 is the headline workload (no data-path collective)."""
+    bench = os.path.join(os.path.dirname(HERE), "bench.py")
+    cmd = [sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "1", "--share-device", "--allow-gloo", "--workload",
+           workload, "--no-cpu-baseline"]
+    if workload == "c2":
+        cmd += ["--instances", "24", "--m1", "128", "--m2", "64", "--timesteps", "10"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["timing_collective"].startswith("gloo")
+    if workload == "c2":
+        assert rec["config"]["instances_total"] == 48 and rec["scaling"] == "weak"
+    # a launcher whose world size contradicts --gpus is refused before any GPU work
+    bad = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="3", RANK="0"))
+    assert bad.returncode != 0 and "does not match" in bad.stderr
 
 
 def test_rccl_process_group_set_up_with_one_rank():

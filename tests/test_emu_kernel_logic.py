@@ -313,3 +313,74 @@ def test_setup_tables_against_oracle_operators(emu):
     b2 = np.zeros_like(b1)
     b2[m2 * (m1 + 1):] = [b2row[pos(i)] for i in range(m1 + 1)]
     assert np.array_equal(b2, d["b2"])
+
+
+def _fuzz_instance(seed, index, k, small=False):
+    """Instance k of a recorded fuzz case (tests/fuzz_cases.py) as single-instance arrays."""
+    import fuzz_cases as F
+    c = F.case(seed, index, small=small)
+    K = c["strikes"][k]
+    vs, vv, ds, dv, U0 = Cm.oracle_grids(c["m1"], c["m2"], [K])
+    return c, K, vs, vv, ds, dv, U0
+
+
+def test_one_node_per_lane_line_solve_keeps_close_nodes_together(emu):
+    """Regression, fuzz seed 5 case 279 (FUZZ_SMALL, round 2: 'BAD', field error 1.16e-7 on one instance): instance 101 has
+    S_0 = 100 inserted 7.4e-6 beside a node of the 16-interval s-grid -- off-diagonals of 1e7 in I - theta dt A1.  With one
+    node per lane the cyclic reduction is the whole line solve; its plain diagonal update 1 - a cL - c aR lost seven digits
+    there and, worse, gave the two close nodes INDEPENDENT errors, which the next step multiplies by the 1e7 coupling.
+    The extended-precision adjudicator (oracle/heston_oracle_xp.c) measured |libhadi - exact| = 1.7e-7 against 4.5e-10
+    for the reference's Thomas sweep; with the excess-carrying update (hadi_row_step, NB == 0) libhadi is at the oracle's
+    level.  All three kernels that run hadi_row_step<1>: streaming, LDS-resident with 4 and with 8 wavefronts."""
+    c, K, vs, vv, ds, dv, U0 = _fuzz_instance(5, 279, 101, small=True)
+    assert (c["m1"], c["m2"], c["N"], c["name"]) == (16, 11, 9, "AM_DIV") and ds.min() < 1e-5
+    m1, m2, N = c["m1"], c["m2"], c["N"]
+    par = np.array([c["model"]])
+    dd = [np.array(x, dtype=np.float64) for x in Cm.DIVS]
+    for variant in (O.AM_DIV, O.EU):
+        p = O.make_params(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, c["r_f"], *c["model"], variant,
+                          Cm.DIVS if variant == O.AM_DIV else None)
+        Uo, lo, _ = O.solve(p, vs[0], vv[0], ds[0], dv[0], U0[0], U0[0])
+        Ux, lx = O.solve_xp(p, vs[0], vv[0], ds[0], dv[0], U0[0], U0[0])
+        scale = np.abs(Ux).max()
+        e_oracle = np.abs(Uo - Ux).max() / scale
+        assert e_oracle < 2e-9  # the fp64 Thomas sweep itself: cond * eps
+        for small in (0, 1, 2):
+            U, lam = U0.copy(), np.zeros_like(U0)
+            rc = emu.emu_solve(1, m1, m2, N, C.c_double(Cm.T / N), C.c_double(Cm.THETA), C.c_double(Cm.R_D), C.c_double(c["r_f"]),
+                               _P(par), variant, _P(vs), _P(vv), _P(ds), _P(dv), _P(U), _P(U0), _P(lam), 8, len(dd[0]),
+                               _P(dd[0]), _P(dd[1]), _P(dd[2]), 64, small, 0, None)
+            assert rc == 0
+            e = np.abs(U[0] - Ux).max() / scale
+            assert e < max(3 * e_oracle, 1e-9), (variant, small, e, e_oracle)  # was 1.7e-7 (AM_DIV) / 2.2e-7 (EU)
+            if lx is not None:
+                el = np.abs(lam[0] - lx).max() / max(1.0, np.abs(lx).max())
+                assert el < max(10 * np.abs(lo - lx).max() / max(1.0, np.abs(lx).max()), 1e-8), (small, el)  # was 1.8e-6
+
+
+def test_rendezvous_timeout_sets_the_error_word(emu):
+    """The pair rendezvous of the two-wavefront rows polls a bounded number of times.  A partner that never publishes
+    (test hook: the high half withholds its token on v-row 1) must leave a code in the handle's error word -- the library
+    turns it into HADI_ERR_INTERNAL -- and the kernel must still drain."""
+    m1, m2, N = 600, 12, 1
+    vs, vv, ds, dv, U0 = Cm.oracle_grids(m1, m2, [100.0])
+    par = np.array([[Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA]])
+    dd = [np.array(x, dtype=np.float64) for x in Cm.DIVS]
+
+    def run():
+        U, lam = U0.copy(), np.zeros_like(U0)
+        rc = emu.emu_solve(1, m1, m2, N, C.c_double(Cm.T / 10), C.c_double(Cm.THETA), C.c_double(Cm.R_D), C.c_double(0.0), _P(par),
+                           O.EU, _P(vs), _P(vv), _P(ds), _P(dv), _P(U), _P(U0), _P(lam), 1, len(dd[0]), _P(dd[0]), _P(dd[1]),
+                           _P(dd[2]), 64, 0, 0, None)
+        assert rc == 0
+        return emu.emu_take_error()
+
+    emu.emu_set_tuning(b"strip", 1)  # paired strips (the shared ring's exchange is a block barrier under the emulator)
+    try:
+        assert run() == 0
+        emu.emu_set_tuning(b"debug_fault", 1)
+        assert run() == 1  # HADI_DEVERR_RENDEZVOUS
+        emu.emu_set_tuning(b"debug_fault", 0)
+        assert run() == 0  # the word is sticky until read, not beyond
+    finally:
+        emu.emu_set_tuning(b"reset", 0)

@@ -425,6 +425,60 @@ def test_more_v_nodes_than_s_nodes(solver, m1, m2, N, variant, name):
         assert _field_err(U, Uo) < FIELD_RTOL
 
 
+@pytest.mark.parametrize("m1,m2,N,variant,name,tuning", [
+    (300, 400, 2, H.EU, "EU", {"strip": 1}),        # strips, 8 nodes per lane; rows 300 carries b1 at columns 0 AND m1
+    (300, 400, 2, H.AM, "AM", {"strip": 0}),        # shared ring, same rows
+    (150, 160, 3, H.EU, "EU", {"strip": 1}),        # strips, 4 nodes per lane
+    (100, 130, 3, H.DIV, "DIV", {"strip": 1}),      # strips, 2 nodes per lane
+    (20, 50, 4, H.EU, "EU", {"small_seq": 1}),      # one wavefront per instance, rows 20 and 40 carry both entries
+    (20, 50, 4, H.DIV, "DIV", {"small_seq": 0}),    # block kernel
+    (40, 40, 4, H.EU, "EU", {"small_seq": 1}),      # m2 == m1: the last v-row r = m1 has its b1 entry at column 0 only
+    (64, 64, 3, H.AM, "AM", {}),
+    (600, 640, 2, H.EU, "EU", {"strip": 1}),        # paired strips: column 0 in the low half, column m1 in the high half
+    (600, 640, 2, H.EU, "EU", {"strip": 0}),
+])
+def test_two_b1_entries_per_row_on_every_row_kernel(solver, m1, m2, N, variant, name, tuning):
+    """The rows k*m1 of a grid with m2 >= m1 (RC_B1COL + HADI_B1_BOTH: b1 at column 0 and at column m1, or at column 0 alone
+    when m2 == m1) on each row-pass family by name: strips at 8 / 4 / 2 nodes per lane, paired strips, the shared ring, the
+    two LDS-resident kernels.  r_f != 0 so that the b1 terms carry weight."""
+    strikes = Cm.strikes_for(3)
+    grids, U0 = _batch(m1, m2, strikes)
+    U, lam = U0.copy(), np.zeros_like(U0)
+    american = variant in (H.AM, H.AM_DIV)
+    div = H.Dividends(*Cm.DIVS) if variant in (H.DIV, H.AM_DIV) else None
+    for k, v in tuning.items():
+        solver.set_tuning(k, v)
+    try:
+        solver.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.02, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U,
+                               variant=variant, U_0=U0, lambda_bar=lam if american else None, dividends=div)
+        path = solver.describe_last_sweep()
+    finally:
+        for k in tuning:
+            solver.set_tuning(k, -1)
+    if "strip" in tuning:
+        assert ("strip" in path) == bool(tuning["strip"]), path
+    if "small_seq" in tuning:
+        assert ("hadi_small_seq_kernel" in path) == bool(tuning["small_seq"]), path
+    p = Cm.oracle_params(m1, m2, N, name, r_f=0.02)
+    Uo, lo, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0, want_lambda=True)
+    assert _field_err(U, Uo) < FIELD_RTOL
+    if american:
+        assert np.abs(lam - lo).max() < 1e-8 * max(1.0, np.abs(lo).max())
+
+
+def test_reciprocal_of_the_line_solves_is_within_two_ulp(solver):
+    """hadi_rcp (v_rcp_f64 + ONE Newton step; round 2 dropped the third-order step to save an FMA on each of the 15 reciprocals
+    of a row): its error against the correctly rounded 1/x over the magnitudes the pivots take -- 1 (dt -> 0) to 1e9 (a
+    7e-6-wide s-interval) -- both signs, and near powers of two where v_rcp_f64's table switches."""
+    rng = np.random.default_rng(7)
+    x = np.concatenate([10.0 ** rng.uniform(-3, 10, 200000) * rng.choice([-1.0, 1.0], 200000),
+                        1.0 + rng.uniform(0, 1e-6, 20000), 2.0 ** rng.integers(-20, 30, 20000) * (1.0 + rng.uniform(-1e-9, 1e-9, 20000))])
+    got = solver.debug_rcp(x)
+    exact = 1.0 / x
+    ulp = np.spacing(np.abs(exact))
+    assert (np.abs(got - exact) / ulp).max() <= 2.0
+
+
 # ---- input ordering, device-side LM reduction --------------------------------------------------------------------------------
 def test_device_inputs_are_ordered_after_the_torch_stream(solver):
     """The handle runs on its own non-blocking stream: tensors written by torch ops enqueued right before the call (no
