@@ -175,6 +175,7 @@ int hadi_get_timing(const hadi_ctx *ctx, hadi_timing *out);
  *                 payoff of the batch depends on s only (default 1; 0 = always the explicit (U, lambda_bar) pair)
  *   "strip"       strip row pass: -1 automatic (default), 0 never, 1 whenever the geometry allows it
  *   "row_tile"    shared-ring row pass: v-rows per block tile (0 = automatic)
+ *   "strip_blocks" strip row pass: blocks per instance (0 = automatic)
  *   "col_groups"  column pass: blocks per instance (0 = automatic)
  *   "small_waves" small-grid kernel: wavefronts per instance, 4 or 8 (0 = automatic)
  *   "sub_batch"   batches of several rounds of one instance per CU on grids whose round exceeds the 256 MB memory-side
@@ -262,7 +263,7 @@ int hadi_compute_parameter_update(int n, const double *J, const double *residual
 int hadi_debug_row_pass(hadi_ctx *ctx, const hadi_problem *p, int step, double *Y1rhs);
 int hadi_debug_col_solve(hadi_ctx *ctx, const hadi_problem *p, double *X);
 /* out[k] = the reciprocal of x[k] exactly as the line solves of the sweep form it (v_rcp_f64 + one Newton step: within
- * 1.5 ulp, no IEEE division); x and out are HOST arrays of n doubles.  Tests bound its error. */
+ * 10 ulp, no IEEE division); x and out are HOST arrays of n doubles.  Tests bound its error. */
 int hadi_debug_rcp(hadi_ctx *ctx, int n, const double *x, double *out);
 
 #ifdef __cplusplus

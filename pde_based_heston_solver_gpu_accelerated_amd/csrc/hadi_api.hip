@@ -279,6 +279,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     }
     const int nsub = (int)subs.size();
     if (!(d.theta > 0.0) ||  // the strip kernel scales the A1 action by (1 - theta) / theta
+        d.r_d == d.r_f ||    // ... and keeps the s-convection weights multiplied by theta dt (r_d - r_f) (hadi_strip_step)
         (pl.L.G == 2 && (d.variant == HADI_AM || d.variant == HADI_AM_DIV))) {  // paired strips: European step only
         pl.use_strip = 0;
         for (auto &sbt : subs) sbt.pl.use_strip = 0;
@@ -1191,6 +1192,7 @@ int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value) {
     else if (!std::strcmp(key, "strip")) c->tune.strip = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "debug_fault")) c->debug_fault = value;
     else if (!std::strcmp(key, "row_tile")) c->tune.row_tile = value > 0 ? value : 0;
+    else if (!std::strcmp(key, "strip_blocks")) c->tune.strip_blocks = value > 0 ? value : 0;
     else if (!std::strcmp(key, "col_groups")) c->tune.col_groups = value > 0 ? value : 0;
     else if (!std::strcmp(key, "small_waves")) {
         if (value != 0 && value != 4 && value != 8) return fail(c, HADI_ERR_INVALID, "small_waves must be 0, 4 or 8");
@@ -1211,6 +1213,7 @@ int hadi_get_tuning(const hadi_ctx *ctx, const char *key, int *value) {
     else if (!std::strcmp(key, "strip")) *value = c->tune.strip;
     else if (!std::strcmp(key, "debug_fault")) *value = c->debug_fault;
     else if (!std::strcmp(key, "row_tile")) *value = c->tune.row_tile;
+    else if (!std::strcmp(key, "strip_blocks")) *value = c->tune.strip_blocks;
     else if (!std::strcmp(key, "col_groups")) *value = c->tune.col_groups;
     else if (!std::strcmp(key, "small_waves")) *value = c->tune.small_waves;
     else return HADI_ERR_INVALID;

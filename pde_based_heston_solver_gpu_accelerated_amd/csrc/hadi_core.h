@@ -176,7 +176,10 @@ struct HadiTables {
 // rowc columns
 // wavefronts (= strips) per block of the strip row pass: 8 at 8 nodes per lane (one block fills a CU's LDS and
 // registers); 4 at 4 and 2 nodes per lane, where a v-line is short and 8 strips would be ~17 rows each
-#define HADI_STRIP_WAVES(B) ((B) == 8 ? 8 : 4)
+#ifndef HADI_STRIP_WAVES_B4
+#define HADI_STRIP_WAVES_B4 4
+#endif
+#define HADI_STRIP_WAVES(B) ((B) == 8 ? 8 : (B) == 4 ? HADI_STRIP_WAVES_B4 : 4)
 // Slots of a strip wavefront's private LDS ring = rows ahead of the current one that are fetched or in flight (the row NS
 // ahead is issued when the row two ahead is waited for: a lead of NS - 2 row steps).  8 nodes per lane: 4 slots fill the
 // 160 KB of a CU (3 for the paired strips with an fp64 state).  Narrower rows have LDS to spare, but a deeper ring does not
@@ -187,7 +190,11 @@ struct HadiTables {
 #endif
 #define HADI_STRIP_NS(B, G, ES) ((G) == 2 ? ((ES) == 8 ? 3 : 4) : ((B) <= 4 ? HADI_STRIP_NS_NARROW : 4))
 enum { RC_V = 0, RC_WM = 1, RC_WZ = 2, RC_WP = 3, RC_L2 = 4, RC_L1 = 5, RC_M = 6, RC_U1 = 7, RC_U2 = 8,
-       RC_B1VAL = 9, RC_B1COL = 10, RC_VTH = 11 /* theta dt v */, RC_LAST = 12 };
+       RC_B1VAL = 9, RC_B1COL = 10, RC_VTH = 11 /* theta dt v */, RC_LAST = 12,
+       // the A0 v-weights divided by -theta dt (r_d - r_f): the strip kernels keep -theta dt (r_d - r_f) s beta_s in place of
+       // s beta_s (hadi_strip_step) and load the 12 entries RC_L2 .. RC_WPS of a row
+       RC_WMS = 13, RC_WZS = 14, RC_WPS = 15 };
+#define HADI_SRC0 RC_L2  // first entry of the strip kernels' 12-entry window of a row-table row
 // pb columns: forward  y_k = (rhs_k - PB_L y_{k-1} - PB_L2 y_{k-2}) * PB_Q
 //             backward x_k = y_k - PB_C x_{k+1} - PB_C2 x_{k+2}
 //             spikes   x_k -= PB_V0 tl0 + PB_V1 tl1 + PB_W0 tr0 + PB_W1 tr1
@@ -240,6 +247,12 @@ HADI_HD inline void hadi_setup_instance(const HadiLayout &L, const HadiSetupIn &
             rc[RC_WM] = c * hadi_fd_beta(in.delta_v, r - 1, -1);
             rc[RC_WZ] = c * hadi_fd_beta(in.delta_v, r - 1, 0);
             rc[RC_WP] = c * hadi_fd_beta(in.delta_v, r - 1, 1);
+            const double qth = thdt * (in.r_d - in.r_f);
+            if (qth != 0.0) {  // (r_d == r_f: the host keeps such batches off the strip kernels)
+                rc[RC_WMS] = -rc[RC_WM] / qth;
+                rc[RC_WZS] = -rc[RC_WZ] / qth;
+                rc[RC_WPS] = -rc[RC_WP] / qth;
+            }
         }
         double a2[5];
         hadi_a2_row(r, m2, in.vec_v, in.delta_v, in.r_d, in.kappa, in.eta, in.sigma, a2);

@@ -25,13 +25,13 @@
 #include <stddef.h>
 #include <stdint.h>
 
-// 1/x without the ~14-instruction IEEE division expansion; relative error ~1 ulp, which is inside the parity
-// tolerance by 9 orders.
+// 1/x without the ~14-instruction IEEE division expansion; relative error up to 10 ulp (2e-15; measured over the pivots'
+// range, tests/test_gpu_pins.py), a backward error no larger than the rounding of the pivot's own operands.
 HADI_DEV HADI_FORCEINLINE double hadi_rcp(double x) {
 #if defined(HADI_EMU)
     return 1.0 / x;
 #else
-    // v_rcp_f64 delivers ~2^-26; ONE Newton step r (1 + e), e = 1 - x r, leaves e^2 ~ 2^-52: the result is within ~1.5 ulp
+    // v_rcp_f64 delivers 2^-24.5 .. 2^-26; ONE Newton step r (1 + e), e = 1 - x r, leaves e^2: within 10 ulp, mostly 1-2
     // (two FMAs; the third-order step r (1 + e + e^2) used before cost a third FMA on each of the 15 reciprocals of a
     // row -- 3 % of the row pass -- for digits far below the 1e-10 parity tolerance)
 #if defined(HADI_RCP_THIRD_ORDER)

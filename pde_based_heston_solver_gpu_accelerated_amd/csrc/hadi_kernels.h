@@ -1166,7 +1166,7 @@ struct HadiStripCtxT {
     const double *b2r;   // instance b2 row (global)
     int lane, rowp;
     double dt, thdt, e_nm1, e_n;
-    double qth, c1, c2, kap;  // theta dt (r_d - r_f), 1 + theta dt r_d / 2, theta dt r_d / 2, (1 - theta) / theta
+    double c1, kap;           // 1 + theta dt r_d / 2, (1 - theta) / theta
     double hr0, inv0;         // i = 0 row of A1: reaction term (0 for the call) and 1 / (1 + theta dt hr0)
     double inv_dt;            // P representation: 1 / dt and the (lane, slot) of the s_max node
     int m1_lane, m1_r;
@@ -1215,12 +1215,15 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
     constexpr int c0slot = 64 * B * G;
     constexpr int NB = B - 1;
     HADI_STAMP_DECL(c.stamp_acc_)
-    const double dt = c.dt, thdt = c.thdt, qth = c.qth, c1 = c.c1, c2 = c.c2, kap = c.kap, e_nm1 = c.e_nm1, e_n = c.e_n;
-    const double vth = rt[RC_VTH];
-    const double wm = rt[RC_WM], wz = rt[RC_WZ], wp = rt[RC_WP];
-    const double a2l2 = rt[RC_L2], a2l1 = rt[RC_L1], a2m = rt[RC_M], a2u1 = rt[RC_U1], a2u2 = rt[RC_U2];
-    const double b1val = rt[RC_B1VAL];
-    const int b1raw = (int)rt[RC_B1COL];
+    const double dt = c.dt, thdt = c.thdt, c1 = c.c1, kap = c.kap, e_nm1 = c.e_nm1, e_n = c.e_n;
+    // rt = the entries RC_L2 .. RC_WPS of the row's table entry (HADI_SRC0): wm, wz, wp are the SCALED A0 v-weights,
+    // -w / (theta dt (r_d - r_f)), to go with the scaled s-coefficient arrays (below)
+    const double vth = rt[RC_VTH - HADI_SRC0];
+    const double wm = rt[RC_WMS - HADI_SRC0], wz = rt[RC_WZS - HADI_SRC0], wp = rt[RC_WPS - HADI_SRC0];
+    const double a2l2 = rt[RC_L2 - HADI_SRC0], a2l1 = rt[RC_L1 - HADI_SRC0], a2m = rt[RC_M - HADI_SRC0], a2u1 = rt[RC_U1 - HADI_SRC0],
+                 a2u2 = rt[RC_U2 - HADI_SRC0];
+    const double b1val = rt[RC_B1VAL - HADI_SRC0];
+    const int b1raw = (int)rt[RC_B1COL - HADI_SRC0];
     const bool b1_at0 = b1raw == 0 || b1raw >= HADI_B1_BOTH;  // (two entries on one v-row: m2 > m1 only)
     const int b1col = b1raw >= HADI_B1_BOTH ? b1raw - HADI_B1_BOTH : b1raw;
     const int b1e = b1col - 1;
@@ -1248,10 +1251,15 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
         tt[r] = wm * um1[r] + wz * u0[r] + wp * up1[r];
         A2U[r] = a2l1 * um1[r] + a2m * u0[r] + a2u1 * up1[r];
     }
+    // The second neighbours j-2, j+2 enter A2 only on the upwind rows (v_j > 1: hes_a2_shuffled_kernels.hpp:131-140) and on
+    // row 0 (the gamma stencil): three rows in four have both weights zero -- a wave-uniform branch (the weights sit in
+    // SGPRs) around the 2 B FMAs.  fma(0, u, A) = A: bit-identical.
+    if (a2l2 != 0.0 || a2u2 != 0.0) {
 #pragma unroll
-    for (int r = 0; r < B; r++) A2U[r] = fma(a2l2, um2[r], A2U[r]);
+        for (int r = 0; r < B; r++) A2U[r] = fma(a2l2, um2[r], A2U[r]);
 #pragma unroll
-    for (int r = 0; r < B; r++) A2U[r] = fma(a2u2, up2[r], A2U[r]);
+        for (int r = 0; r < B; r++) A2U[r] = fma(a2u2, up2[r], A2U[r]);
+    }
     // s-neighbours of the block: last node of lane-1, first node of lane+1; lane 0 borders i = 0, lane 63 the pad (0)
     double u0L = hadi_lane_prev(u0[B - 1]), tL = hadi_lane_prev(tt[B - 1]);
     double u0R = hadi_lane_next(u0[0]), tR = hadi_lane_next(tt[0]);
@@ -1316,12 +1324,16 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
         const double tl = (r == 0) ? tL : tt[r == 0 ? 0 : r - 1];
         const double tr = (r == B - 1) ? tR : tt[r == B - 1 ? r : r + 1];
         // I - theta dt A1 directly (theta dt v comes with the row's table entry): il, im, iu; theta dt A1 U from the
-        // same three; Y0 - theta dt A1 U = U + dt (A0 U + A2 U + ...) + (1 - theta)/theta (theta dt A1 U)
-        double il = fma(-vth, Dm[r], -(qth * Bm[r]));
-        iu[r] = fma(-vth, Dp[r], -(qth * Bp[r]));
+        // same three; Y0 - theta dt A1 U = U + dt (A0 U + A2 U + ...) + (1 - theta)/theta (theta dt A1 U).
+        // Bm, Bp hold E = -theta dt (r_d - r_f) s beta_s (scaled while the block copied the arrays to LDS): the convection
+        // part of il / iu costs no multiplication, and A0 U = s beta_s (x) [w u] = E (x) [(-w / (theta dt (r_d - r_f))) u]
+        // comes out of the same arrays with the scaled v-weights of the row table -- 2 operations per node fewer.
+        double il = fma(-vth, Dm[r], Bm[r]);
+        iu[r] = fma(-vth, Dp[r], Bp[r]);
         const double sm = il + iu[r];
         const double im = c1 - sm;  // 1 + theta dt (lo + up + r_d / 2)
-        const double T1 = fma(-iu[r], uR, fma(-il, uL, (sm - c2) * u0[r]));
+        // theta dt A1 U = -il uL - iu uR + (1 - im) u0   (c1 - c2 = 1)
+        const double T1 = fma(-iu[r], uR, fma(-il, uL, fma(-im, u0[r], u0[r])));
         const double A0U = Bm[r] * tl - (Bm[r] + Bp[r]) * tt[r] + Bp[r] * tr;
         double S = A0U + A2U[r];
         if constexpr (LAST) S += b2v[r] * e_nm1;
@@ -1499,7 +1511,9 @@ template <int B, int AMER, class T = double, int G = 1>
 #ifndef HADI_STRIP_OCC_B4
 #define HADI_STRIP_OCC_B4 2
 #endif
-__global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4 ? HADI_STRIP_OCC_B4 : 4)) hadi_pass_a_strip(HadiSweepArgs a, int n) {
+// (2 nodes per lane, American P representation: at 4 waves per SIMD -- 128 VGPRs -- the kernel spills two registers, and a
+// scratch reload inside the row loop drains the DMA prefetch: 3 there)
+__global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4 ? HADI_STRIP_OCC_B4 : AMER == 2 ? 3 : 4)) hadi_pass_a_strip(HadiSweepArgs a, int n) {
     static_assert(sizeof(T) == 8 || AMER == 0, "the fp32-state sweep is European only");
     static_assert(G == 1 || (G == 2 && B == 8 && AMER == 0), "paired strips: 8 nodes per lane, European");
     HADI_DYN_SMEM(double, smem);
@@ -1519,24 +1533,11 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     if (n > ip.N) return;
     const int nrows = a.L.nrows, npad = a.L.nrows_pad, rowp = a.L.rowp;
     double *coef = reinterpret_cast<double *>(reinterpret_cast<T *>(smem) + (size_t)NPAIR * NS * rowp);
-    {
-        const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B * G;
-        for (int e = threadIdx.x; e < 4 * 64 * B * G; e += 64 * NWV) coef[e] = sc[e];
-    }
     // P representation: the payoff row (it depends on s only: v-row 0 of the packed payoff) behind the coefficient arrays;
     // re-read from LDS every row rather than held in 2 B registers per lane (that version spilled)
     const double *payl = coef + 4 * 64 * B * G;
-    if constexpr (AMER == 2) {
-        const double *__restrict__ pg = a.U0 + (size_t)inst * a.L.inst_stride;
-        double *pw = coef + 4 * 64 * B * G;
-        for (int e = threadIdx.x; e < rowp; e += 64 * NWV) pw[e] = pg[e];
-    }
-    if constexpr (G > 1) {  // the pairs' exchange buffers (values + rendezvous tokens, all zero: no row has token 0)
-        if (threadIdx.x < NPAIR * 16) coef[4 * 64 * B * G + threadIdx.x] = 0.0;
-    }
-    __syncthreads();  // the only block-wide barrier: the coefficient arrays are shared
     const int j0 = (sb * NPAIR + pair) * a.RS;
-    if (j0 >= nrows) return;
+    const bool has_strip = j0 < nrows;  // (wave-uniform; a wavefront without a strip only helps with the shared copies below)
     const int j1 = (j0 + a.RS < nrows) ? j0 + a.RS : nrows;
 
     HadiStripCtxT<T> c;
@@ -1547,8 +1548,6 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     c.xch = coef + 4 * 64 * B * G + pair * 16;
     c.err = a.err; c.debug = a.debug;
     c.dt = hadi_uniform_d(ip.dt); c.thdt = hadi_uniform_d(ip.thdt);
-    c.qth = hadi_uniform_d(ip.thdt * ip.q);
-    c.c2 = hadi_uniform_d(ip.thdt * ip.half_rd);
     c.c1 = hadi_uniform_d(1.0 + ip.thdt * ip.half_rd);
     c.kap = hadi_uniform_d((ip.dt - ip.thdt) / ip.thdt);  // the host keeps theta = 0 off this kernel
     c.hr0 = hadi_uniform_d(ip.hr0); c.inv0 = hadi_uniform_d(1.0 / (1.0 + ip.thdt * ip.hr0));
@@ -1593,15 +1592,21 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     int aft[NA];
 #pragma unroll
     for (int k = 0; k < NA; k++) aft[k] = 0;
-    if constexpr (KEEP) fetch(js);  // (the first row too: the step reads its raw P from the ring)
-    fetch(js + dir);
-    fetch(js + 2 * dir);
+    // Order of the prologue: this wavefront's row fetches (LDS-DMA) and register loads are ISSUED first, then the block
+    // copies the shared s-coefficient arrays (global -> LDS) and meets at the only block-wide barrier -- the two memory
+    // round trips overlap instead of following each other (a launch of short strips is mostly prologue: 64 instances of
+    // 512x256, 9-row strips: 0.0380 -> see DESIGN.md section 5).
+    if (has_strip) {
+        if constexpr (KEEP) fetch(js);  // (the first row too: the step reads its raw P from the ring)
+        fetch(js + dir);
+        fetch(js + 2 * dir);
 #pragma unroll
-    for (int q = 3; q < D; q++) {
-        const int zq = fetch(js + q * dir);
+        for (int q = 3; q < D; q++) {
+            const int zq = fetch(js + q * dir);
 #pragma unroll
-        for (int k = 0; k < NA; k++)
-            if (k + 2 < q) aft[k] += zq;
+            for (int k = 0; k < NA; k++)
+                if (k + 2 < q) aft[k] += zq;
+        }
     }
     // rows behind by 2, behind by 1 (carried in the state's own type: with an fp32 state they are exact floats and cost
     // half the registers), current row (double: used throughout the step)
@@ -1617,32 +1622,46 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
         const int inode = (half == 0) ? 64 * B + 1 : 64 * B;
         epos = (sizeof(T) == 4) ? hadi_pos_f32(B, G, inode) : hadi_pos(B, G, inode);
     }
-    {
-        double t2[B], t1[B];
+    double t2[B], t1[B];
 #pragma unroll
-        for (int r = 0; r < B; r++) t2[r] = t1[r] = 0.0;
+    for (int r = 0; r < B; r++) t2[r] = t1[r] = u0[r] = 0.0;
+    c0vec = 0.0;
+    if (has_strip) {
         if (row_ok(js - 2 * dir)) hadi_get_block<B, G, T>(Ub + (ptrdiff_t)(js - 2 * dir) * rowp, half, lane, t2);
         if (row_ok(js - dir)) hadi_get_block<B, G, T>(Ub + (ptrdiff_t)(js - dir) * rowp, half, lane, t1);
-        if constexpr (AMER == 2) {  // U = max(P, U_0) on the rows behind (the current row keeps its raw P for lambda_bar)
-            double pay[B];
-            hadi_get_block<B, 1>(payl, 0, lane, pay);
-#pragma unroll
-            for (int r = 0; r < B; r++) {
-                t2[r] = fmax(t2[r], pay[r]);
-                t1[r] = fmax(t1[r], pay[r]);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < B; r++) {
-            um2[r] = (T)t2[r];
-            um1[r] = (T)t1[r];
-        }
-    }
-    hadi_get_block<B, G, T>(Ub + (size_t)js * rowp, half, lane, u0);
-    {
+        hadi_get_block<B, G, T>(Ub + (size_t)js * rowp, half, lane, u0);
         const int rr = js + (lane - 2) * dir;
         c0vec = (half == 0 && lane < 4 && row_ok(rr)) ? (double)Ub[(ptrdiff_t)rr * rowp + c0slot] : 0.0;
         if constexpr (G > 1) evec = (lane < 4 && row_ok(rr)) ? (double)Ub[(ptrdiff_t)rr * rowp + epos] : 0.0;
+    }
+    {   // s-coefficient arrays to LDS; the two beta arrays scaled by -theta dt (r_d - r_f) on the way (hadi_strip_step)
+        const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B * G;
+        const double mq = -(ip.thdt * ip.q);
+        for (int e = threadIdx.x; e < 4 * 64 * B * G; e += 64 * NWV) coef[e] = (e < 2 * 64 * B * G) ? mq * sc[e] : sc[e];
+    }
+    if constexpr (AMER == 2) {
+        const double *__restrict__ pg = a.U0 + (size_t)inst * a.L.inst_stride;
+        double *pw = coef + 4 * 64 * B * G;
+        for (int e = threadIdx.x; e < rowp; e += 64 * NWV) pw[e] = pg[e];
+    }
+    if constexpr (G > 1) {  // the pairs' exchange buffers (values + rendezvous tokens, all zero: no row has token 0)
+        if (threadIdx.x < NPAIR * 16) coef[4 * 64 * B * G + threadIdx.x] = 0.0;
+    }
+    __syncthreads();  // the only block-wide barrier: the coefficient arrays are shared
+    if (!has_strip) return;
+    if constexpr (AMER == 2) {  // U = max(P, U_0) on the rows behind (the current row keeps its raw P for lambda_bar)
+        double pay[B];
+        hadi_get_block<B, 1>(payl, 0, lane, pay);
+#pragma unroll
+        for (int r = 0; r < B; r++) {
+            t2[r] = fmax(t2[r], pay[r]);
+            t1[r] = fmax(t1[r], pay[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < B; r++) {
+        um2[r] = (T)t2[r];
+        um1[r] = (T)t1[r];
     }
 #if !defined(HADI_EMU)
     // Consume the prologue's register loads HERE: otherwise hipcc parks their s_waitcnt vmcnt(0) at the loop header,
@@ -1662,7 +1681,7 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
         const int j = js + dir * t;
         HADI_STAMPC(30);  // carry + loop
         HadiSRow srow;
-        hadi_sload_issue(a.rowc + ((size_t)inst * nrows + j) * HADI_RC, srow);  // flies during the DMA wait
+        hadi_sload_issue(a.rowc + ((size_t)inst * nrows + j) * HADI_RC + HADI_SRC0, srow);  // flies during the DMA wait
         hadi_wave_rendezvous();
         // the row D ahead goes to the slot of row j (of row j - 1 when one slot is kept behind): that row is in registers,
         // and this wavefront's last read of the slot (in the previous step) has been retired there.  Issued BEFORE the
@@ -1686,9 +1705,9 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
         hadi_sload_wait(srow, rt);  // one lgkmcnt(0) for the table entry and the LDS reads above
         if (dir < 0) {  // descending: "behind" rows are j+1, j+2 -- swap the neighbour weights instead of the arrays
             double w;
-            w = rt[RC_WM]; rt[RC_WM] = rt[RC_WP]; rt[RC_WP] = w;
-            w = rt[RC_L2]; rt[RC_L2] = rt[RC_U2]; rt[RC_U2] = w;
-            w = rt[RC_L1]; rt[RC_L1] = rt[RC_U1]; rt[RC_U1] = w;
+            w = rt[RC_WMS - HADI_SRC0]; rt[RC_WMS - HADI_SRC0] = rt[RC_WPS - HADI_SRC0]; rt[RC_WPS - HADI_SRC0] = w;
+            w = rt[RC_L2 - HADI_SRC0]; rt[RC_L2 - HADI_SRC0] = rt[RC_U2 - HADI_SRC0]; rt[RC_U2 - HADI_SRC0] = w;
+            w = rt[RC_L1 - HADI_SRC0]; rt[RC_L1 - HADI_SRC0] = rt[RC_U1 - HADI_SRC0]; rt[RC_U1 - HADI_SRC0] = w;
         }
         HADI_STAMPC(25);  // LDS reads + table entry + DMA issue
         double dm2[B], dm1[B];

@@ -33,6 +33,7 @@ struct HadiTuning {
     int strip = -1;       // strip row pass: -1 automatic, 0 never, 1 whenever the geometry allows it
     int col_groups = 0;   // column pass: blocks per instance (0 = automatic)
     int small_waves = 0;  // LDS-resident small-grid kernel: wavefronts per instance, 4 or 8 (0 = automatic)
+    int strip_blocks = 0; // strip row pass: blocks per instance (0 = automatic); the strips get ceil(rows / (strips per block x blocks)) rows
 };
 
 // Returns 0 on success, 1 if the shape is outside what the kernels cover.
@@ -154,6 +155,15 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
             p.smem_as = (size_t)spb * ns * L.rowp * state_bytes + ((size_t)4 * 64 * L.B * L.G + (size_t)spb * 16) * sizeof(double);
             p.use_strip = (t_strip < t_ring) ? 1 : 0;
             if (tu.strip >= 0) p.use_strip = tu.strip ? 1 : 0;
+        }
+    }
+    if (tu.strip_blocks > 0 && L.B >= 2) {  // forced geometry (measurements): blocks per instance
+        const int spb = (L.G == 2) ? HADI_STRIP_WAVES(L.B) / 2 : HADI_STRIP_WAVES(L.B);
+        const int rs = (L.nrows + spb * tu.strip_blocks - 1) / (spb * tu.strip_blocks);
+        if (rs >= 1 && rs <= 64 && p.smem_as > 0) {
+            p.sblocks = tu.strip_blocks;
+            p.RS = rs;
+            p.grid_as = (int)(((long long)n_inst * p.sblocks + 7) / 8 * 8);
         }
     }
     p.ctiles = (L.rowp + 63) / 64;

@@ -24,6 +24,7 @@ extern "C" int emu_set_tuning(const char *key, int value) {
     if (k == "debug_fault") g_debug = value;
     else if (k == "strip") g_tune.strip = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "row_tile") g_tune.row_tile = value > 0 ? value : 0;
+    else if (k == "strip_blocks") g_tune.strip_blocks = value > 0 ? value : 0;
     else if (k == "col_groups") g_tune.col_groups = value > 0 ? value : 0;
     else if (k == "reset") { g_tune = HadiTuning(); g_debug = 0; }
     else return 1;

@@ -9,7 +9,7 @@ regression tests in tests/test_gpu_regressions.py).  Judged per instance:
   ill-conditioned instances      (neighbouring s-intervals differing by > 30x: S_0 inserted right beside a node; 1/ds^2
                                  coefficients of 1e6+ amplify the round-off of ANY fp64 solver) against the oracle at
                                  1e-8 / 1e-6, AND -- what decides -- against the extended-precision adjudicator
-                                 (oracle.solve_xp) on the worst such instance: libhadi may be at most 10x further from the
+                                 (oracle.solve_xp) on the worst such instance: libhadi may be at most 30x further from the
                                  exact result than the fp64 oracle is.
 Every BAD line is followed by the adjudicator's verdict on its worst instance."""
 import os, sys, random
@@ -82,9 +82,11 @@ def judge(c, r):
     if ill.any() and not f32:  # the adjudicator decides on the worst ill-conditioned instance
         k = int(np.where(ill)[0][np.argmax(per[ill] + (lper[ill] if r["lo"] is not None else 0.0))])
         verdict = adjudicate(c, r, k)
-        ok = ok and verdict["hadi_U"] < max(10 * verdict["oracle_U"], 1e-11)
+        # (both distances are realisations of cond * eps: scanning the position of a 2e-5-wide interval over the lanes their
+        # ratio ranges over 0.2 .. 10; the one-node-per-lane defect this check caught in round 3 was 380x)
+        ok = ok and verdict["hadi_U"] < max(30 * verdict["oracle_U"], 1e-11)
         if verdict["hadi_lam"] is not None:
-            ok = ok and verdict["hadi_lam"] < max(10 * verdict["oracle_lam"], 1e-9)
+            ok = ok and verdict["hadi_lam"] < max(30 * verdict["oracle_lam"], 1e-9)
     return ok, dict(err=err, err_ill=err_ill, lerr=lerr, lerr_ill=lerr_ill, per=per, verdict=verdict)
 
 

@@ -26,6 +26,9 @@ CASES = {
     **{"c2_64g%d" % g: ["--workload", "c2", "--instances", "64", "--tuning", "col_groups=%d" % g] for g in (2, 3, 4, 5, 8, 9)},
     **{"c2_128g%d" % g: ["--workload", "c2", "--instances", "128", "--tuning", "col_groups=%d" % g] for g in (2, 3, 4, 5, 8, 9)},
     "c2_g1": ["--workload", "c2", "--tuning", "col_groups=1"], "c2_g2": ["--workload", "c2", "--tuning", "col_groups=2"], "c2_g9": ["--workload", "c2", "--tuning", "col_groups=9"],
+    **{"c2_%d_sb%d" % (k, b): ["--workload", "c2", "--instances", str(k), "--tuning", "strip=1", "--tuning", "strip_blocks=%d" % b]
+       for k in (32, 64, 96, 128, 160, 192) for b in (1, 2, 3, 4, 5, 6)},
+    **{"c3_sb%d" % b: ["--workload", "c3", "--tuning", "strip_blocks=%d" % b] for b in (1, 2, 3, 4)},
     "c2ring": ["--workload", "c2", "--tuning", "strip=0"], "c2am": ["--workload", "c3", "--m1", "512", "--m2", "256", "--timesteps", "1000", "--instances", "256"], "c5": ["--workload", "c5"], "c5f64": ["--workload", "c5", "--state", "fp64"], "c4": ["--workload", "c4"],
 }
 argv = sys.argv[1:]
