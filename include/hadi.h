@@ -183,9 +183,17 @@ int hadi_get_timing(const hadi_ctx *ctx, hadi_timing *out);
  *   "device_vgrid" v-grids of compute_base_prices / compute_jacobian rebuilt per instance on the device (default 1;
  *                 0 = built once on the host with glibc sinh/asinh and broadcast -- bit-identical to the reference's
  *                 host-side Grid, needs one shared V_0)
+ *   "team_launch" instance-resident execution of batches of up to 8 large European instances (128 < m1 <= 512, m2 <= 263):
+ *                 the whole time loop in ONE launch, every instance kept in the L2 of one XCD by a team of 32 blocks
+ *                 (hadi_team_kernel): -1 automatic (default), 0 never, 1 whenever the shape allows it.  If the team
+ *                 protocol fails (it is bounded everywhere) the batch is solved again on the two-launches-per-step path
+ *                 and the automatic choice stays away from it for the rest of the handle's life (get: -2)
  *   "debug_fault" TEST HOOK, 0 in production: 1 = the high half of every two-wavefront row (m1 > 512) withholds its
  *                 rendezvous token on v-row 1, so that the partner's bounded poll runs out (~0.2 s) -- the call must then
- *                 return HADI_ERR_INTERNAL instead of a field solved with stale exchange values */
+ *                 return HADI_ERR_INTERNAL instead of a field solved with stale exchange values; 128 = one block of every
+ *                 team of an instance-resident launch deserts before the first team barrier -- the launch must time out,
+ *                 and the call must still return the right field (from the two-launches-per-step path); 16 / 32 / 64 =
+ *                 timing diagnostics of that launch (row phase / column phase / barriers skipped: results are wrong) */
 int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value);
 int hadi_get_tuning(const hadi_ctx *ctx, const char *key, int *value);
 /* Device the handle runs on: name, CU count, gcn arch string (for bench reports). */

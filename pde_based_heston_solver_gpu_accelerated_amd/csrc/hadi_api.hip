@@ -64,6 +64,10 @@ struct Ctx {
     // entry point ends with -- no copy, no extra launch -- and turns a non-zero word into HADI_ERR_INTERNAL.
     int *err_host = nullptr, *err_dev = nullptr;
     int debug_fault = 0;  // test hook (hadi_set_tuning "debug_fault"): HADI_DEBUG_* bits handed to the sweep kernels
+    // instance-resident launch (hadi_team_kernel): -1 automatic, 0 never, 1 whenever the shape allows it; team_failed is set
+    // when a team could not form or a team barrier timed out once on this handle (the automatic choice then stays away)
+    int team_launch = -1, team_failed = 0;
+    DevBuf team;
 };
 
 // Every GPU entry point runs on the handle's device whatever the caller's current device is (a torch rank that
@@ -218,6 +222,8 @@ hipError_t raise_all_lds_limits() {
     if ((e = raise_lds_limit(hadi_pass_a_strip<8, 2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_a_strip<4, 2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_a_strip<2, 2>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_team_kernel<8>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_team_kernel<4>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_seq_kernel<1>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_seq_kernel<2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_kernel<1, 4, false>)) != hipSuccess) return e;
@@ -667,6 +673,39 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     }
     c->last_nsub = nsub;
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    // ---- instance-resident launch: up to 8 large European instances, one per XCD, whole time loop in one kernel ----------
+    // (hadi_team_kernel; the reference runs every instance's time loop inside one kernel, device_solver.hpp:83-88,226-265).
+    // Chosen automatically for batches of up to 8 instances on the full 256-CU device; any failure of the team protocol is
+    // recorded by the kernel, checked here, and the batch is solved again on the streaming path below.
+    const bool team_shape = d.n <= 8 && L.G == 1 && (L.B == 8 || L.B == 4) && L.P <= 8 && d.variant == HADI_EU && !cs && !f32 &&
+                            !d.debug && !prof && d.theta > 0.0 && d.r_d != d.r_f && c->cu_count == 256;
+    if (team_shape && (c->team_launch > 0 || (c->team_launch < 0 && !c->team_failed))) {
+        if ((rc = ensure(c, c->team, 512 * sizeof(int)))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->team.p, 0, 512 * sizeof(int), s));
+        HadiTeamArgs ta;
+        ta.form = ptr<int>(c->team); ta.bar = ptr<int>(c->team) + 64; ta.nb = c->cu_count / 8; ta.N = d.Nmax;
+        ta.stamps = reinterpret_cast<unsigned long long *>(ptr<int>(c->team) + 384);
+        const size_t smem = ((size_t)4 * 64 * L.B + (size_t)L.P * 2 * 4 * 64 + (size_t)L.P * 16 * L.P + (size_t)L.P * HADI_LC * HADI_PBW) * sizeof(double) + 64;
+        if (L.B == 8) hipLaunchKernelGGL((hadi_team_kernel<8>), dim3(c->cu_count), dim3(512), smem, s, a, ta);
+        else hipLaunchKernelGGL((hadi_team_kernel<4>), dim3(c->cu_count), dim3(512), smem, s, a, ta);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(s));
+        const int deverr = __atomic_exchange_n(c->err_host, 0, __ATOMIC_ACQ_REL);
+        if (!deverr) {
+            char buf[200];
+            std::snprintf(buf, sizeof buf, "hadi_team_kernel<%d>: whole time loop in one launch, every instance resident in one XCD's L2 (teams of %d blocks)",
+                          L.B, ta.nb);
+            c->last_path = buf;
+            HIP_TRY(c, hipEventRecord(c->ev[2], s));
+            return HADI_OK;
+        }
+        if (deverr & ~HADI_DEVERR_TEAM) __atomic_fetch_or(c->err_host, deverr & ~HADI_DEVERR_TEAM, __ATOMIC_RELAXED);  // (not ours: keep it for finish_timing)
+        c->team_failed = 1;
+        // start again from the caller's initial condition on the streaming path
+        hipLaunchKernelGGL(hadi_pack_kernel, dim3(grid1d(tot)), dim3(256), 0, s, L, d.n, d.n_src, d.d_natU, ptr<double>(c->U));
+        HIP_TRY(c, hipMemsetAsync(c->Y.p, 0, st, s));
+        c->last_path += " (after a failed instance-resident launch)";
+    }
     // Small batches are launch-bound (2*N dependent launches of a few microseconds each): replay the loop
     // from a cached hipGraph.  Every kernel argument is baked into the nodes, so the key is everything they
     // depend on; the library's own buffers are stable between calls.
@@ -1082,7 +1121,7 @@ void release_handle(Ctx *c) {
                       &c->rinv, &c->rwork, &c->ipar, &c->par8, &c->g_s, &c->g_v, &c->g_ds, &c->g_dv, &c->src_v,
                       &c->src_dv, &c->sel_a, &c->sel_b, &c->v0_i, &c->natU, &c->natU0, &c->natOut, &c->prices,
                       &c->status, &c->div_flag, &c->div_amt, &c->div_pct, &c->V, &c->R1, &c->C2, &c->pay_mis, &c->Uf, &c->Yf,
-                      &c->order, &c->lm31};
+                      &c->order, &c->lm31, &c->team};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto &g : c->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
@@ -1101,6 +1140,15 @@ void release_handle(Ctx *c) {
 extern "C" {
 
 int hadi_version(void) { return HADI_VERSION_MAJOR * 100 + HADI_VERSION_MINOR; }
+
+#if defined(HADI_TEAM_STAMPS)
+// diagnostic build only (tools/team_stamps.py): the 16 phase stamps of the last instance-resident launch
+int hadi_debug_team_stamps(hadi_ctx *ctx, unsigned long long *out16) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c || !c->team.p) return 1;
+    return hipMemcpy(out16, ptr<int>(c->team) + 384, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess;
+}
+#endif
 
 #if defined(HADI_STAMPS)
 // diagnostic build only (tools/stamps.py)
@@ -1191,6 +1239,7 @@ int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value) {
     else if (!std::strcmp(key, "sub_batch")) c->sub_batch = value ? 1 : 0;
     else if (!std::strcmp(key, "strip")) c->tune.strip = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "debug_fault")) c->debug_fault = value;
+    else if (!std::strcmp(key, "team_launch")) { c->team_launch = value < 0 ? -1 : (value ? 1 : 0); c->team_failed = 0; }
     else if (!std::strcmp(key, "row_tile")) c->tune.row_tile = value > 0 ? value : 0;
     else if (!std::strcmp(key, "strip_blocks")) c->tune.strip_blocks = value > 0 ? value : 0;
     else if (!std::strcmp(key, "col_groups")) c->tune.col_groups = value > 0 ? value : 0;
@@ -1212,6 +1261,7 @@ int hadi_get_tuning(const hadi_ctx *ctx, const char *key, int *value) {
     else if (!std::strcmp(key, "sub_batch")) *value = c->sub_batch;
     else if (!std::strcmp(key, "strip")) *value = c->tune.strip;
     else if (!std::strcmp(key, "debug_fault")) *value = c->debug_fault;
+    else if (!std::strcmp(key, "team_launch")) *value = c->team_failed ? -2 : c->team_launch;
     else if (!std::strcmp(key, "row_tile")) *value = c->tune.row_tile;
     else if (!std::strcmp(key, "strip_blocks")) *value = c->tune.strip_blocks;
     else if (!std::strcmp(key, "col_groups")) *value = c->tune.col_groups;

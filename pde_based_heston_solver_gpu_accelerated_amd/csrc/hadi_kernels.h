@@ -52,6 +52,12 @@ struct HadiSweepArgs {
 #define HADI_DEVERR_RENDEZVOUS 1  // a pair rendezvous of the two-wavefront rows ran out of polls: the partner's token never came
 // Test hooks (bits of HadiSweepArgs.debug)
 #define HADI_DEBUG_WITHHOLD_TOKEN 1  // the high half of every two-wavefront row withholds its token on v-row 1
+#define HADI_DEBUG_TEAM_NO_ROWS 16   // hadi_team_kernel, timing diagnostics (results are wrong): skip the row phase's work
+#define HADI_DEBUG_TEAM_NO_COLS 32   // ... skip the column phase's work
+#define HADI_DEBUG_TEAM_NO_BARRIER 64  // ... skip the team barriers
+#define HADI_DEBUG_TEAM_DESERT 128     // hadi_team_kernel: block 1 of every team leaves before the first barrier (the others must
+                                       // time out, report HADI_DEVERR_TEAM, and the host must solve the batch on the streaming path)
+
 
 // Bounded poll of the pair rendezvous: ~0.2 s on the GPU (a resident partner answers within microseconds; under the
 // host-thread emulator every poll is a sched_yield of one of 512 threads).  With the test hook set the bound is short,
@@ -1794,6 +1800,7 @@ struct HadiPassBCtx {
     int pay1d;          // the payoff does not depend on v: one load per column instead of one per node
     double inv_dt;      // 1/dt (P representation)
     double tab[5];      // this chunk's table (33 rows x 9 scalars) spread over the lanes: lane l holds entries l + 64 q
+    const double *tabl; // hadi_pb_solve<true>: the chunk's table rows in LDS, [HADI_LC][HADI_PBW] (instance-resident kernel)
     const double *Ri;   // this wavefront's four rows of the reduced inverse in LDS, [4P][4]: for column m the
                         // coefficients of (left-neighbour last two, right-neighbour first two)
     double *zsh;        // LDS exchange, 2 buffers of P*4*64
@@ -1848,7 +1855,18 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_load(const HadiPassBCtx &c, int ctile, do
 }
 
 // Chunk-local solve + interface exchange + spike correction of one 64-column tile held in y (no memory traffic).
+// LDSTAB: the table scalars come from an LDS copy (broadcast reads) instead of v_readlane on the register image.  The
+// streaming kernels stream tiles through eight wavefronts and are short of LDS bandwidth, not of VALU slots: readlanes there.
+// The instance-resident kernel solves ONE tile per step and waits for it: there the 594 readlanes per tile (two VALU slots
+// per scalar) are a third of the phase's instruction chain, and 165 broadcast reads replace them.
+template <bool LDSTAB = false>
 HADI_DEV HADI_FORCEINLINE void hadi_pb_solve(const HadiPassBCtx &c, int parity, double (&y)[HADI_LC], int younger = 0) {
+#undef HADI_PB_T
+#if defined(HADI_EMU)
+#define HADI_PB_T(c, k, m) (LDSTAB ? (c).tabl[(k) * HADI_PBW + (m)] : emu::t_wave->pub[((k) * 9 + (m)) >> 6][((k) * 9 + (m)) & 63])
+#else
+#define HADI_PB_T(c, k, m) (LDSTAB ? (c).tabl[(k) * HADI_PBW + (m)] : hadi_read_lane((c).tab[((k) * 9 + (m)) >> 6], ((k) * 9 + (m)) & 63))
+#endif
     HADI_STAMP_DECL(c.stamp_acc_)
     HADI_STAMPB_WAIT(younger);
     HADI_STAMPB(16);  // this tile's loads have landed
@@ -2089,6 +2107,7 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
     c.american = a.american;
     c.pos_m1 = a.pos_m1;
     c.dt = ip.dt;
+    c.tabl = nullptr;
     int t0, t1;
     hadi_pb_tile_range(a, grp, t0, t1);
 
@@ -2207,6 +2226,7 @@ __global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, in
     c.american = a.american;
     c.pos_m1 = a.pos_m1;
     c.dt = ip.dt;
+    c.tabl = nullptr;
     int t0, t1;
     hadi_pb_tile_range(a, grp, t0, t1);
 
@@ -2245,6 +2265,238 @@ __global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, in
     if (HADI_STAMPS == 3 && c.lane == 0)
         for (int k = 16; k < 24; k++) atomicAdd(&g_hadi_stamps[k], stamp_store_[k]);
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Instance-resident execution: the WHOLE time loop of up to 8 large instances in ONE launch (European Douglas sweeps, fp64,
+// one wavefront per v-row: 128 < m1 <= 512, m2 <= 263) -- what the reference's team kernel does for every instance
+// (device_solver.hpp:83-88, 226-265: all N steps inside one kernel).  The batched path above needs 2 N dependent launches;
+// for ONE 512x256 instance each of them is a few microseconds of work on a sliver of the chip behind a ~1.5 us kernel
+// boundary, 17.6 ms per 1000 steps.  Here a TEAM of `nb` blocks, all on the same XCD, keeps the instance in that XCD's L2:
+//   row phase     the team's 8 nb wavefronts take the v-rows round-robin: five rows of U straight to registers (L1-bypassing
+//                 loads), hadi_strip_step, Y stored;
+//   team barrier  every wavefront drains its stores (they are in the XCD's L2 then), one lane per block adds to a
+//                 monotonic counter in L2 and polls it;
+//   column phase  block t of the team takes column tile t: hadi_pb_load / hadi_pb_solve / hadi_pb_store as in hadi_pass_b;
+//   team barrier.
+// Which XCD a block runs on is READ from the hardware (HW_REG_XCC_ID), not inferred from blockIdx: blocks that read the
+// same id share an L2, so the stores one of them has retired are what the L1-bypassing loads of the others return -- no L2
+// write-back, no invalidate, which is what makes the barrier cost ~1 us instead of the 4-5 us of a chip-wide one.  Team k
+// = the blocks on XCD k, instance k.  Every wait is bounded; a team that does not fill up (the dispatcher owes nobody a
+// round-robin placement), a barrier that runs out of polls, or a block that finds itself on another XCD after a barrier
+// (wave save / restore by the driver) records HADI_DEVERR_TEAM in the handle's error word, and the host solves the batch
+// again on the streaming path.
+struct HadiTeamArgs {
+    int *form;   // [8] arrival counters, one per XCD (zeroed before the launch)
+    int *bar;    // [8] monotonic barrier counters, one per XCD (zeroed before the launch), each on a cache line of its own
+    int nb;      // blocks per team
+    int N;       // time steps
+    unsigned long long *stamps;  // diagnostic build only (HADI_TEAM_STAMPS): [16]
+};
+#define HADI_DEVERR_TEAM 2  // instance-resident launch: a team did not form, a team barrier timed out, or a block moved
+#define HADI_TEAM_POLLS (1 << 18)
+
+// Diagnostic build only (-DHADI_TEAM_STAMPS, tools/team_stamps.py): shader-clock stamps of the phases of time step
+// HADI_TEAM_STAMPS, written by wavefront 0 of the team's blocks 0 (a column-phase block) and nb - 1 (a row-phase-only block).
+#if defined(HADI_TEAM_STAMPS) && !defined(HADI_EMU)
+#define HADI_TSTAMP(k, drain) do { if (n == HADI_TEAM_STAMPS && wave == 0 && (rank == 0 || rank == nb - 1)) { \
+    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+    unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    if (lane == 0) ta.stamps[(rank == 0 ? 0 : 8) + (k)] = t_; } } while (0)
+#else
+#define HADI_TSTAMP(k, drain)
+#endif
+
+HADI_DEV HADI_FORCEINLINE int hadi_xcc_id() {
+#if defined(HADI_EMU)
+    return (int)(blockIdx.x & 7);
+#else
+    return (int)(__builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((4 - 1) << 11)) & 7);
+#endif
+}
+// this lane's B values of a row-layout global row, bypassing the vector L1 (another CU of the team wrote them)
+template <int B>
+HADI_DEV HADI_FORCEINLINE void hadi_get_block_l2(const double *row, int lane, double (&u)[B]) {
+#if !defined(HADI_EMU)
+    typedef double hadi_d2 __attribute__((ext_vector_type(2)));
+#endif
+#pragma unroll
+    for (int q = 0; q < B / 2; q++) {
+#if defined(HADI_EMU)
+        u[2 * q] = row[q * 128 + 2 * lane]; u[2 * q + 1] = row[q * 128 + 2 * lane + 1];
+#else
+        const hadi_d2 t = __builtin_nontemporal_load(reinterpret_cast<const hadi_d2 *>(row + q * 128 + 2 * lane));
+        u[2 * q] = t.x; u[2 * q + 1] = t.y;
+#endif
+    }
+}
+HADI_DEV HADI_FORCEINLINE double hadi_get_l2(const double *p) {
+#if defined(HADI_EMU)
+    return *p;
+#else
+    return __builtin_nontemporal_load(p);
+#endif
+}
+// Barrier of the team's blocks.  `dead` (LDS) is set when the wait ran out of polls or the block has moved; returns false then.
+HADI_DEV HADI_FORCEINLINE bool hadi_team_barrier(int *ctr, int target, int xcc_team, int *dead, int *err) {
+#if !defined(HADI_EMU)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's stores have been acknowledged by the L2
+#endif
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#if defined(HADI_EMU)
+        __atomic_fetch_add(ctr, 1, __ATOMIC_SEQ_CST);
+        int guard = 0;
+        while (__atomic_load_n(ctr, __ATOMIC_SEQ_CST) < target && ++guard < HADI_TEAM_POLLS) sched_yield();
+#else
+        __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int guard = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++guard < HADI_TEAM_POLLS)
+            __builtin_amdgcn_s_sleep(2);
+#endif
+        if (guard >= HADI_TEAM_POLLS || hadi_xcc_id() != xcc_team) {
+            hadi_report(err, HADI_DEVERR_TEAM);
+            *dead = 1;
+        }
+    }
+    __syncthreads();
+    return *dead == 0;
+}
+
+template <int B>
+__global__ void __launch_bounds__(512, 2) hadi_team_kernel(HadiSweepArgs a, HadiTeamArgs ta) {
+    HADI_DYN_SMEM(double, smem);
+    constexpr int c0slot = 64 * B;
+    const int lane = threadIdx.x & 63;
+    const int wave = HADI_UNIFORM((int)(threadIdx.x >> 6));
+    const int xcc = hadi_xcc_id();
+    if (xcc >= a.n_inst) return;  // (block-uniform: a workgroup lives on one XCD)
+    // LDS: [4 coefficient arrays of 64 B] [2 exchange buffers of P 4 64] [P wavefronts x 4 rows of the reduced inverse]
+    //      [P chunk tables of the column pass] [flags]
+    const int P = a.L.P, n4 = 4 * P;
+    double *coef = smem;
+    double *zsh = coef + 4 * 64 * B;
+    double *tsh = zsh + (size_t)P * 2 * 4 * 64;
+    double *tabl = tsh + (size_t)P * 4 * n4;  // the column-pass chunk tables, [P][HADI_LC][HADI_PBW]
+    int *flags = reinterpret_cast<int *>(tabl + (size_t)P * HADI_LC * HADI_PBW);  // [0] rank of this block in its team, [1] dead
+    if (threadIdx.x == 0) {
+#if defined(HADI_EMU)
+        flags[0] = __atomic_fetch_add(ta.form + xcc, 1, __ATOMIC_SEQ_CST);
+#else
+        flags[0] = __hip_atomic_fetch_add(ta.form + xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+        flags[1] = 0;
+    }
+    __syncthreads();
+    const int rank = HADI_UNIFORM(flags[0]);
+    const int nb = ta.nb;
+    if (rank >= nb) return;  // more blocks of the grid landed on this XCD than the team takes
+    if ((a.debug & HADI_DEBUG_TEAM_DESERT) && rank == 1) return;  // (test hook)
+    const int inst = xcc;
+    const HadiInstPar ip = a.ipar[inst];
+    const int nrows = a.L.nrows, rowp = a.L.rowp;
+    {   // s-coefficient arrays, the beta pair scaled as in hadi_pass_a_strip; this wavefront's rows of the reduced inverse
+        const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B;
+        const double mq = -(ip.thdt * ip.q);
+        for (int e = threadIdx.x; e < 4 * 64 * B; e += 512) coef[e] = (e < 2 * 64 * B) ? mq * sc[e] : sc[e];
+        if (wave < P) {
+            const double *__restrict__ Rg = a.rinv + (size_t)inst * 16 * P * P;
+            double *__restrict__ rw = tsh + (size_t)wave * 4 * n4;
+            const int rl0 = (wave > 0) ? 4 * (wave - 1) + 2 : 0, rr0 = (wave < P - 1) ? 4 * (wave + 1) : 0;
+            for (int e = lane; e < 4 * n4; e += 64) {
+                const int m = e >> 2, q = e & 3;
+                rw[e] = Rg[(size_t)((q < 2) ? rl0 + q : rr0 + (q - 2)) * n4 + m];
+            }
+        }
+        const double *__restrict__ pg = a.pb + (size_t)inst * a.L.nrows_pad * HADI_PBW;
+        for (int e = threadIdx.x; e < P * HADI_LC * HADI_PBW; e += 512) tabl[e] = pg[e];
+    }
+    __syncthreads();
+
+    HadiStripCtxT<double> c;
+    c.lane = lane; c.rowp = rowp; c.coef = coef; c.half = 0; c.xch = nullptr; c.err = a.err; c.debug = 0;
+    c.dt = hadi_uniform_d(ip.dt); c.thdt = hadi_uniform_d(ip.thdt);
+    c.c1 = hadi_uniform_d(1.0 + ip.thdt * ip.half_rd);
+    c.kap = hadi_uniform_d((ip.dt - ip.thdt) / ip.thdt);
+    c.hr0 = hadi_uniform_d(ip.hr0); c.inv0 = hadi_uniform_d(1.0 / (1.0 + ip.thdt * ip.hr0));
+    double *const Ui = a.U + (size_t)inst * a.L.inst_stride;
+    c.Yi = a.Y + (size_t)inst * a.L.inst_stride;
+    c.Li = nullptr;
+    c.b2r = a.b2row + (size_t)inst * rowp;
+    c.inv_dt = 0.0; c.m1_lane = -1; c.m1_r = -1;
+
+    HadiPassBCtx cb;
+    cb.lane = lane; cb.wave = wave; cb.P = P; cb.zsh = zsh; cb.Ri = tsh + (size_t)wave * 4 * n4;
+    cb.nrows = nrows; cb.rowp = rowp; cb.ja = wave * HADI_LC;
+    cb.Yi = c.Yi; cb.Ui = Ui;
+    cb.Yb = hadi_make_buf(c.Yi, (size_t)a.L.inst_stride * sizeof(double));
+    cb.Ub = hadi_make_buf(Ui, (size_t)a.L.inst_stride * sizeof(double));
+    cb.Li = nullptr; cb.Lb = hadi_make_buf(nullptr, 0); cb.P0i = nullptr; cb.pay1d = 0; cb.inv_dt = 0.0;
+    cb.american = 0; cb.pos_m1 = a.pos_m1; cb.dt = ip.dt;
+    cb.tabl = tabl + (size_t)wave * HADI_LC * HADI_PBW;
+    if (wave < P) hadi_pb_load_table(cb, a.pb + ((size_t)inst * a.L.nrows_pad + cb.ja) * HADI_PBW);
+
+    const int wt = rank * 8 + wave, nwt = nb * 8;  // this wavefront's number in the team
+    int *const bar = ta.bar + 32 * xcc;
+    int arrivals = 0;
+    const int N = ip.N < ta.N ? ip.N : ta.N;
+    // boundary time factors e_n = exp(bc_rate dt n) (device_solver.hpp:238,246): one exp per step (e_{n-1} is last step's
+    // e_n, the same bits), none for the call with r_f = 0 (exp(0) = 1 exactly)
+    const bool unit_e = (ip.bc_rate == 0.0);
+    double e_cur = 1.0;  // exp(bc_rate dt 0)
+    for (int n = 1; n <= N; n++) {
+        c.e_nm1 = hadi_uniform_d(e_cur);
+        if (!unit_e) e_cur = exp(ip.bc_rate * ip.dt * n);
+        c.e_n = hadi_uniform_d(e_cur);
+        HADI_TSTAMP(0, false);
+        // ---- row phase ---------------------------------------------------------------------------------------------
+        for (int j = (a.debug & HADI_DEBUG_TEAM_NO_ROWS) ? nrows : wt; j < nrows; j += nwt) {
+            HadiSRow srow;
+            hadi_sload_issue(a.rowc + ((size_t)inst * nrows + j) * HADI_RC + HADI_SRC0, srow);
+            double um2[B], um1[B], u0[B], up1[B], up2[B], un[B], praw[B];
+#pragma unroll
+            for (int r = 0; r < B; r++) um2[r] = um1[r] = up1[r] = up2[r] = praw[r] = 0.0;
+            double c0m2 = 0.0, c0m1 = 0.0, c0p1 = 0.0, c0p2 = 0.0;
+            const double *r0 = Ui + (size_t)j * rowp;
+            if (j >= 2) { hadi_get_block_l2<B>(r0 - 2 * rowp, lane, um2); c0m2 = hadi_get_l2(r0 - 2 * rowp + c0slot); }
+            if (j >= 1) { hadi_get_block_l2<B>(r0 - rowp, lane, um1); c0m1 = hadi_get_l2(r0 - rowp + c0slot); }
+            hadi_get_block_l2<B>(r0, lane, u0);
+            const double c00 = hadi_get_l2(r0 + c0slot);
+            if (j + 1 < nrows) { hadi_get_block_l2<B>(r0 + rowp, lane, up1); c0p1 = hadi_get_l2(r0 + rowp + c0slot); }
+            if (j + 2 < nrows) { hadi_get_block_l2<B>(r0 + 2 * rowp, lane, up2); c0p2 = hadi_get_l2(r0 + 2 * rowp + c0slot); }
+            double rt[HADI_RCL];
+            hadi_sload_wait(srow, rt);
+            hadi_wave_rendezvous();
+            if (j == nrows - 1)
+                hadi_strip_step<B, 0, true, double, 1>(c, j, rt, um2, um1, u0, up1, up2, hadi_uniform_d(c0m2), hadi_uniform_d(c0m1), hadi_uniform_d(c00),
+                                                       hadi_uniform_d(c0p1), hadi_uniform_d(c0p2), praw, 0.0, coef, un);
+            else
+                hadi_strip_step<B, 0, false, double, 1>(c, j, rt, um2, um1, u0, up1, up2, hadi_uniform_d(c0m2), hadi_uniform_d(c0m1), hadi_uniform_d(c00),
+                                                        hadi_uniform_d(c0p1), hadi_uniform_d(c0p2), praw, 0.0, coef, un);
+        }
+        HADI_TSTAMP(1, false);
+        arrivals += nb;
+        if (!(a.debug & HADI_DEBUG_TEAM_NO_BARRIER) && !hadi_team_barrier(bar, arrivals, xcc, flags + 1, a.err)) return;
+        HADI_TSTAMP(2, false);
+        // ---- column phase: tile t on block t of the team ---------------------------------------------------------------
+        for (int t = (a.debug & HADI_DEBUG_TEAM_NO_COLS) ? a.ctiles : rank; t < a.ctiles; t += nb) {
+            if (wave < P) {
+                double y[HADI_LC];
+                hadi_pb_load<double>(cb, t, y);
+                HADI_TSTAMP(3, true);   // (diagnostic build: waits for the loads)
+                hadi_pb_solve<false>(cb, 0, y, 0);
+                HADI_TSTAMP(4, false);
+                hadi_pb_store<0, false, double>(cb, t, y);
+                HADI_TSTAMP(5, false);
+            } else if (P > 1) {
+                __syncthreads();  // (the exchange barrier inside hadi_pb_solve)
+            }
+            __syncthreads();  // the exchange buffer is free again (one buffer is used: parity 0)
+        }
+        arrivals += nb;
+        if (!(a.debug & HADI_DEBUG_TEAM_NO_BARRIER) && !hadi_team_barrier(bar, arrivals, xcc, flags + 1, a.err)) return;
+        HADI_TSTAMP(6, false);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -384,3 +384,14 @@ def test_rendezvous_timeout_sets_the_error_word(emu):
         assert run() == 0  # the word is sticky until read, not beyond
     finally:
         emu.emu_set_tuning(b"reset", 0)
+
+
+def test_instance_resident_team_kernel(emu):
+    """hadi_team_kernel: the whole time loop of up to 8 European instances in one launch (row phase: hadi_strip_step on rows
+    loaded straight to registers; column phase: hadi_pb_* on the team's blocks; team barriers in between).  Under the
+    emulator a team is ONE block (blocks run one after the other), which still exercises every index of the two phases: 8 and 4
+    nodes per lane, 1 / 2 / 4 / 8 column chunks, more and fewer rows than team wavefronts, two instances, r_f != 0, put data."""
+    _run(emu, 300, 40, 3, [100.0, 93.0], O.EU, 8, small=4)           # 8 nodes per lane, 2 chunks
+    _run(emu, 200, 100, 2, [100.0], O.EU, 8, r_f=0.01, small=4)      # 4 nodes per lane, 4 chunks
+    _run(emu, 260, 20, 3, [100.0], O.EU, 8, small=4, put=True)       # one chunk: no exchange barrier
+    _run(emu, 512, 256, 1, [100.0], O.EU, 8, small=4)                # the benchmarked shape: 257 rows, 8 chunks, 9 column tiles

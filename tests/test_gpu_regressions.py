@@ -123,3 +123,82 @@ def test_rendezvous_timeout_fails_the_call(solver, strip):
     finally:
         solver.set_tuning("debug_fault", 0)
         solver.set_tuning("strip", -1)
+
+
+# ---- instance-resident launch (hadi_team_kernel) ----------------------------------------------------------------------------
+def _team_case(m1, m2, N, strikes, put=False, r_f=0.0):
+    grids = H.GridViewsBatch.for_strikes(m1, m2, Cm.S_0, Cm.V_0, strikes)
+    U0 = grids.put_payoff(strikes) if put else grids.call_payoff(strikes)
+    from oracle import oracle as O
+    p = O.make_params(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, r_f, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, O.EU,
+                      option_type=O.PUT if put else O.CALL, strikes=np.array(strikes) if put else None)
+    Uo, _, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0)
+    kw = dict(option_type=H.PUT, strikes=strikes) if put else {}
+    return grids, U0, Uo, kw
+
+
+@pytest.mark.parametrize("m1,m2,N,n,put,r_f", [(512, 256, 12, 1, False, 0.0), (512, 256, 6, 8, False, 0.01), (300, 140, 10, 3, True, 0.0),
+                                               (256, 128, 10, 5, False, 0.0), (200, 30, 8, 2, False, 0.02), (400, 263, 5, 2, True, 0.01)])
+def test_instance_resident_launch_vs_oracle_and_streaming_path(solver, m1, m2, N, n, put, r_f):
+    """Batches of up to 8 large European instances run their whole time loop in ONE launch, every instance kept in the L2 of
+    one XCD by a team of 32 blocks (hadi_team_kernel; the reference runs all N steps of an instance inside one kernel,
+    device_solver.hpp:83-88,226-265).  Full field against the oracle (1e-10) and against the two-launches-per-step path
+    (1e-12: same operators, the row step of the strip kernels against the shared-ring one); 8 and 4 nodes per lane, 1 .. 8
+    column chunks, call and put boundary data, r_f != 0 (the boundary time factors then need an exp per step)."""
+    strikes = Cm.strikes_for(n)
+    grids, U0, Uo, kw = _team_case(m1, m2, N, strikes, put, r_f)
+    res = {}
+    for mode in (1, 0):
+        solver.set_tuning("team_launch", mode)
+        try:
+            U = U0.copy()
+            solver.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, r_f, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U, **kw)
+            res[mode] = (U, solver.describe_last_sweep(), solver.get_tuning("team_launch"))
+        finally:
+            solver.set_tuning("team_launch", -1)
+    assert "hadi_team_kernel" in res[1][1] and res[1][2] == 1, res[1][1:]   # it ran, and the team protocol did not fail
+    assert "hadi_team_kernel" not in res[0][1]
+    scale = np.abs(Uo).max()
+    assert np.abs(res[1][0] - Uo).max() < 1e-10 * scale
+    assert np.abs(res[1][0] - res[0][0]).max() < 1e-12 * scale
+
+
+def test_instance_resident_launch_is_the_default_for_small_batches_of_large_grids(solver):
+    strikes = Cm.strikes_for(2)
+    grids, U0, Uo, kw = _team_case(512, 256, 4, strikes)
+    U = U0.copy()
+    solver.DO_timestepping(512, 256, 4, Cm.T / 4, Cm.THETA, Cm.R_D, 0.0, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U)
+    assert "hadi_team_kernel<8>" in solver.describe_last_sweep()
+    assert np.abs(U - Uo).max() < 1e-10 * np.abs(Uo).max()
+    # nine instances, American sweeps, theta = 0: the streaming kernels
+    for kw2, nn in ((dict(), 9), (dict(variant=H.AM, U_0=None), 2)):
+        ks = Cm.strikes_for(nn)
+        g2 = H.GridViewsBatch.for_strikes(512, 256, Cm.S_0, Cm.V_0, ks)
+        U2 = g2.call_payoff(ks)
+        if "variant" in kw2:
+            kw2 = dict(variant=H.AM, U_0=U2.copy())
+        solver.DO_timestepping(512, 256, 2, Cm.T / 2, Cm.THETA, Cm.R_D, 0.0, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, g2, U2, **kw2)
+        assert "hadi_team_kernel" not in solver.describe_last_sweep()
+
+
+def test_a_failed_team_launch_falls_back_to_the_streaming_path():
+    """Every wait of the instance-resident launch is bounded.  Test hook: one block of every team deserts before the first
+    barrier -> the others run out of polls (~0.1 s), the kernel records HADI_DEVERR_TEAM, and the SAME call returns the right
+    field from the two-launches-per-step path; the automatic choice then stays away from the launch on this handle."""
+    s = H.HestonADI(0)
+    try:
+        strikes = Cm.strikes_for(2)
+        grids, U0, Uo, kw = _team_case(300, 140, 5, strikes)
+        s.set_tuning("debug_fault", 128)
+        U = U0.copy()
+        s.DO_timestepping(300, 140, 5, Cm.T / 5, Cm.THETA, Cm.R_D, 0.0, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U)
+        assert "after a failed instance-resident launch" in s.describe_last_sweep()
+        assert s.get_tuning("team_launch") == -2
+        assert np.abs(U - Uo).max() < 1e-10 * np.abs(Uo).max()
+        s.set_tuning("debug_fault", 0)
+        U = U0.copy()
+        s.DO_timestepping(300, 140, 5, Cm.T / 5, Cm.THETA, Cm.R_D, 0.0, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U)
+        assert "hadi_team_kernel" not in s.describe_last_sweep()  # stays away
+        assert np.abs(U - Uo).max() < 1e-10 * np.abs(Uo).max()
+    finally:
+        s.close()
