@@ -260,8 +260,10 @@ hipError_t raise_all_lds_limits() {
 int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     const int state_bytes = d.prec == HADI_STATE_FP32 ? 4 : 8;
     if (hadi_make_plan(d.m1, d.m2, d.n, 8 * c->cu_count, &pl, c->tune, state_bytes))
-        return fail(c, HADI_ERR_UNSUPPORTED, "grid %dx%d not supported (need 2 <= m1 <= 1024, 3 <= m2 <= %d)", d.m1, d.m2,
-                    HADI_MAX_P * HADI_LC - 1);
+        return fail(c, HADI_ERR_UNSUPPORTED, "grid %dx%d not supported (need m1 >= 2, m2 >= 3 and (m1 + 16)(m2 + 1) < 2^28)", d.m1, d.m2);
+    const bool seq_shape = pl.row_seq || pl.col_seq;  // shapes beyond the streaming kernels: the sequential passes
+    if (seq_shape && (d.scheme != HADI_SCHEME_DOUGLAS || d.prec != HADI_STATE_FP64))
+        return fail(c, HADI_ERR_UNSUPPORTED, "grids with m1 > 1024 or m2 > %d run Douglas sweeps with the fp64 state only", HADI_MAX_P * HADI_LC - 1);
     // Large batches on grids where ONE round of the one-block-per-CU kernels (cu_count instances) already moves more than
     // the 256 MB memory-side cache holds: the two passes of a step then re-use each other's data only while the batch is
     // one round deep (measured at 512x256: 512 instances at once ran the column pass 6 % slower per instance than 256;
@@ -306,6 +308,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     const bool f32 = d.prec == HADI_STATE_FP32;  // European Douglas (with or without dividends) only (validated)
     if (f32 && ((rc = ensure(c, c->Uf, st / 2)) || (rc = ensure(c, c->Yf, st / 2)))) return rc;
     if (cs && ((rc = ensure(c, c->V, st)) || (rc = ensure(c, c->R1, st)) || (rc = ensure(c, c->C2, st)))) return rc;
+    if (pl.row_seq && (rc = ensure(c, c->R1, st))) return rc;  // (hadi_pass_a_seq parks the Thomas multipliers there)
     const size_t n = d.n;
     if ((rc = ensure(c, c->scoef, pl.n_scoef * n * 8))) return rc;
     if ((rc = ensure(c, c->b2row, pl.n_b2row * n * 8))) return rc;
@@ -372,7 +375,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     // One small device-to-host copy per solve decides it.
     bool amp = false;
     const bool takes_small_path = c->use_small && !c->profiling && !cs && !f32 && !d.debug && (american ? pl.smem_small_am : pl.smem_small_eu) > 0;
-    if (american && c->use_amp && !cs && !takes_small_path && !d.debug) {
+    if (american && c->use_amp && !cs && !takes_small_path && !d.debug && !seq_shape) {
         std::vector<int> mis(d.n);
         HIP_TRY(c, hipMemcpyAsync(mis.data(), c->pay_mis.p, sizeof(int) * n, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
@@ -400,7 +403,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     a.american = american ? 1 : 0; a.pos_m1 = pl.pos_m1;
     a.RS = pl.RS; a.sblocks = pl.sblocks;
     a.err = c->err_dev; a.debug = c->debug_fault;
-    a.R1 = cs ? ptr<double>(c->R1) : nullptr;
+    a.R1 = (cs || pl.row_seq) ? ptr<double>(c->R1) : nullptr;
     a.C2 = cs ? ptr<double>(c->C2) : nullptr;
     // Craig-Sneyd: the predictor's column pass writes V (= Y2), the corrector's row pass reads V
     HadiSweepArgs av = a;
@@ -468,6 +471,12 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
             }
             if (prof) HIP_TRY(c, hipEventRecord(c->kev[ev0 + 4 * (nstep - 1) + 0], q));
             auto row_pass = [&](const HadiSweepArgs &ar, int mode) {
+                if (pl.row_seq) {  // more than 1024 s-intervals: one lane per v-row, sequential along s
+                    const dim3 g((unsigned)(nsb * ((L.nrows + 63) / 64))), b(64);
+                    if (american) hipLaunchKernelGGL((hadi_pass_a_seq<1>), g, b, 0, q, ar, nstep);
+                    else hipLaunchKernelGGL((hadi_pass_a_seq<0>), g, b, 0, q, ar, nstep);
+                    return;
+                }
                 if (amp && !xstep && pl.use_strip && mode == 0) {  // P representation on barrier-free strips
                     const dim3 g(pl.grid_as), b(64 * HADI_STRIP_WAVES(L.B));
                     const size_t sm = pl.smem_as + (size_t)L.rowp * sizeof(double);  // + the payoff row
@@ -536,6 +545,12 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                 // 1024-thread block leaves 128 VGPRs per lane, which only the single-buffer kernel fits
                 // (measured at 1024x512: 0.250 vs 0.382 ms/launch for the double-buffered code, which spills)
                 const dim3 g(pl.grid_b), b(pl.block_b);
+                if (pl.col_seq) {  // more than 16 chunks of v-rows: one lane per storage column, sequential along v
+                    const dim3 gs((unsigned)(nsb * pl.ctiles)), bs(64);
+                    if (american) hipLaunchKernelGGL((hadi_pass_b_seq<1>), gs, bs, 0, q, ar, nstep);
+                    else hipLaunchKernelGGL((hadi_pass_b_seq<0>), gs, bs, 0, q, ar, nstep);
+                    return;
+                }
                 if (amp && !xstep) {
                     if (L.P <= 8) hipLaunchKernelGGL((hadi_pass_b<8, 2>), g, b, pl.smem_b, q, ar, nstep);
                     else hipLaunchKernelGGL((hadi_pass_b1<16, 2>), g, b, pl.smem_b, q, ar, nstep);
@@ -657,8 +672,12 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         else if (pl.use_strip && !cs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<%d,%s> (strips of %d rows)", L.B, american ? "AM" : "EU", pl.RS);
         else std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,%s%s> (tiles of %d rows)", L.B, L.G, pl.W, pl.NG, pl.PD,
                            american ? "AM" : "EU", cs ? ",CS" : "", pl.R);
-        std::snprintf(buf, sizeof buf, "row pass %s; column pass %s<%d,%s> (%d chunks of %d rows, %d column tiles per block)", rowk,
-                      L.P <= 8 ? "hadi_pass_b" : "hadi_pass_b1", L.P <= 8 ? 8 : 16, amp ? "AM-P" : american ? "AM" : "EU", L.P, HADI_LC, pl.btpw);
+        if (pl.row_seq) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_seq<%s> (one lane per v-row, sequential along s)", american ? "AM" : "EU");
+        if (pl.col_seq)
+            std::snprintf(buf, sizeof buf, "row pass %s; column pass hadi_pass_b_seq<%s> (one lane per column, sequential along v)", rowk, american ? "AM" : "EU");
+        else
+            std::snprintf(buf, sizeof buf, "row pass %s; column pass %s<%d,%s> (%d chunks of %d rows, %d column tiles per block)", rowk,
+                          L.P <= 8 ? "hadi_pass_b" : "hadi_pass_b1", L.P <= 8 ? 8 : 16, amp ? "AM-P" : american ? "AM" : "EU", L.P, HADI_LC, pl.btpw);
         c->last_path = buf;
         if (nsub > 1) {
             bool same = true;
@@ -679,7 +698,10 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     // recorded by the kernel, checked here, and the batch is solved again on the streaming path below.
     const bool team_shape = d.n <= 8 && L.G == 1 && (L.B == 8 || L.B == 4) && L.P <= 8 && d.variant == HADI_EU && !cs && !f32 &&
                             !d.debug && !prof && d.theta > 0.0 && d.r_d != d.r_f && c->cu_count == 256;
-    if (team_shape && (c->team_launch > 0 || (c->team_launch < 0 && !c->team_failed))) {
+    // (a caller who pins the streaming kernels' geometry -- hadi_set_tuning "strip", "row_tile", "col_groups", "strip_blocks" --
+    // gets those kernels)
+    const bool pinned = c->tune.strip >= 0 || c->tune.row_tile > 0 || c->tune.col_groups > 0 || c->tune.strip_blocks > 0;
+    if (team_shape && (c->team_launch > 0 || (c->team_launch < 0 && !c->team_failed && !pinned))) {
         if ((rc = ensure(c, c->team, 512 * sizeof(int)))) return rc;
         HIP_TRY(c, hipMemsetAsync(c->team.p, 0, 512 * sizeof(int), s));
         HadiTeamArgs ta;
@@ -716,7 +738,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         {  // field by field: struct padding is not initialised
             const void *ptrs[] = {a.pay_mis, a.U, a.Y, a.LAM, a.U0, a.scoef, a.b2row, a.rowc, a.pb, a.rinv, a.ipar, a.R1, a.C2, av.U, a.err};
             const int ints[] = {a.debug, a.L.m1, a.L.m2, a.L.B, a.L.G, a.L.P, a.n_inst, a.R, a.ntiles, a.ctiles, a.btpw, a.bgroups,
-                                a.american, a.pos_m1, d.scheme, d.prec, (int)amp, pl.use_strip, pl.RS, pl.sblocks, pl.grid_as, pl.grid_a, pl.grid_b, pl.block_b, pl.W, (int)pl.smem_a, (int)pl.smem_b};
+                                a.american, a.pos_m1, d.scheme, d.prec, (int)amp, pl.row_seq, pl.col_seq, pl.use_strip, pl.RS, pl.sblocks, pl.grid_as, pl.grid_a, pl.grid_b, pl.block_b, pl.W, (int)pl.smem_a, (int)pl.smem_b};
             put(ptrs, sizeof(ptrs));
             put(ints, sizeof(ints));
         }
@@ -845,8 +867,7 @@ int check_problem(Ctx *c, const hadi_problem *p, bool need_U, bool need_vgrid) {
         HadiPlan tmp;
         if (p->m1 < 2 || p->m2 < 3 ||
             hadi_make_plan(p->m1, p->m2, p->n_instances, 8 * c->cu_count, &tmp, c->tune, p->state_precision == HADI_STATE_FP32 ? 4 : 8))
-            return fail(c, HADI_ERR_UNSUPPORTED, "grid %dx%d not supported (need 2 <= m1 <= 1024, 3 <= m2 <= %d)", p->m1, p->m2,
-                        HADI_MAX_P * HADI_LC - 1);
+            return fail(c, HADI_ERR_UNSUPPORTED, "grid %dx%d not supported (need m1 >= 2, m2 >= 3 and (m1 + 16)(m2 + 1) < 2^28)", p->m1, p->m2);
     }
     const bool dividend = p->variant == HADI_DIV || p->variant == HADI_AM_DIV;
     if (dividend && p->num_dividends > 0 && (!p->dividend_dates || !p->dividend_amounts || !p->dividend_percentages))

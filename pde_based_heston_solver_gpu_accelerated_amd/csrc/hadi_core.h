@@ -35,6 +35,8 @@ struct HadiLayout {
     int G;              // wavefronts per v-row in the row pass: wave g owns i = 1 + 64*B*g + B*lane + r
     int rowp;           // row pitch in doubles: 64*B*G + 8 (slot 64*B*G holds i = 0, 7 zero pads)
     int P;              // chunks per column in the column pass
+    int lc;             // rows per chunk: HADI_LC, or nrows (one chunk: P = 1) for the sequential column pass of grids with
+                        // more than HADI_MAX_P * HADI_LC v-rows (hadi_pass_b_seq)
     long long inst_stride;  // rowp * nrows_pad
 };
 
@@ -73,13 +75,16 @@ HADI_HD inline int hadi_slot_to_i(const HadiLayout &L, int slot) {
 
 // Row-pass shape for m1 s-intervals.  One wavefront per row up to 512 nodes (8 per lane); measured on
 // MI355X at m1 = 512: (B, G) = (8, 1) at 2 waves/SIMD runs 0.183 ms/launch, (4, 2) at 4 waves/SIMD 0.249 ms
-// (the split solve costs 1.75x the instructions).  Two wavefronts per row above 512 nodes.
+// (the split solve costs 1.75x the instructions).  Two wavefronts per row above 512 nodes.  Above 1024 nodes the row is kept
+// in natural order (B = 1: slot of node i >= 1 is i - 1) with as many 64-slot groups as it needs, for the sequential row
+// pass (hadi_pass_a_seq: lane <-> v-row).
 HADI_HD inline void hadi_pick_shape(int m1, int *B, int *G) {
     if (m1 <= 64) { *B = 1; *G = 1; }
     else if (m1 <= 128) { *B = 2; *G = 1; }
     else if (m1 <= 256) { *B = 4; *G = 1; }
     else if (m1 <= 512) { *B = 8; *G = 1; }
-    else { *B = 8; *G = 2; }
+    else if (m1 <= 1024) { *B = 8; *G = 2; }
+    else { *B = 1; *G = (m1 + 63) / 64; }
 }
 
 struct HadiInstPar {
@@ -291,7 +296,7 @@ HADI_HD inline void hadi_setup_instance(const HadiLayout &L, const HadiSetupIn &
                  *u2 = t.a2i + 4 * npad;
     const int P = L.P;
     for (int p = tid; p < P; p += nth) {
-        const int ja = p * HADI_LC, len = HADI_LC;
+        const int ja = p * L.lc, len = L.lc;
         double c1 = 0.0, c21 = 0.0;  // c, c2 of row k-1
         double c0 = 0.0, c20 = 0.0;  // c, c2 of row k-2
         for (int k = 0; k < len; k++) {
@@ -316,7 +321,7 @@ HADI_HD inline void hadi_setup_instance(const HadiLayout &L, const HadiSetupIn &
     //   W = M_pp^-1 [coupling to the next chunk's first two unknowns x[jb], x[jb+1]]
     for (int pw = tid; pw < 4 * P; pw += nth) {
         const int p = pw >> 2, w = pw & 3;
-        const int ja = p * HADI_LC, len = HADI_LC;
+        const int ja = p * L.lc, len = L.lc;
         if ((w < 2 && p == 0) || (w >= 2 && p == P - 1)) continue;
         const int jb = ja + len;
         // forward sweep with rhs given on the fly
@@ -356,7 +361,7 @@ HADI_HD inline void hadi_setup_instance(const HadiLayout &L, const HadiSetupIn &
         sync();
         for (int pq = tid; pq < n4; pq += nth) {
             const int p = pq >> 2, qd = pq & 3;
-            const int ja = p * HADI_LC, len = HADI_LC;
+            const int ja = p * L.lc, len = L.lc;
             const int lrow = (qd == 0) ? 0 : (qd == 1) ? 1 : (qd == 2) ? len - 2 : len - 1;
             const double *pb = t.pb + (size_t)(ja + lrow) * HADI_PBW;
             if (p > 0) {

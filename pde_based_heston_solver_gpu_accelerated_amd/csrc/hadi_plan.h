@@ -24,6 +24,9 @@ struct HadiPlan {
     size_t n_scoef, n_b2row, n_rowc, n_a2i, n_pb, n_rinv, n_rwork;
     // small-grid path: whole instance in LDS, one launch for the whole time loop (0 = not applicable)
     size_t smem_small_eu, smem_small_am;
+    // Shapes beyond the streaming kernels: more than 1024 s-intervals -> sequential row pass (hadi_pass_a_seq, one lane per
+    // v-row); more than HADI_MAX_P * HADI_LC v-rows -> sequential column pass (hadi_pass_b_seq, one lane per column)
+    int row_seq, col_seq;
 };
 
 // Execution-path choices a caller may override through hadi_set_tuning (tests force kernel variants with them; results
@@ -41,16 +44,24 @@ struct HadiTuning {
 inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan *out, const HadiTuning &tu = HadiTuning(),
                           int state_bytes = 8) {
     if (m1 < 2 || m2 < 3 || n_inst < 1) return 1;
-    if (m1 > 1024) return 1;         // row pass: 2 waves x 64 lanes x 8 nodes
+    if (m1 > (1 << 20) || m2 > (1 << 20)) return 1;  // (index arithmetic in 32 bits; memory runs out long before)
     HadiPlan p;
     HadiLayout &L = p.L;
     L.m1 = m1; L.m2 = m2; L.nrows = m2 + 1;
     hadi_pick_shape(m1, &L.B, &L.G);
     L.rowp = 64 * L.B * L.G + HADI_ROW_PAD(L.B, state_bytes);
     L.P = (L.nrows + HADI_LC - 1) / HADI_LC;
-    if (L.P > HADI_MAX_P) return 1;
-    L.nrows_pad = L.P * HADI_LC;
+    L.lc = HADI_LC;
+    p.row_seq = (m1 > 1024) ? 1 : 0;
+    p.col_seq = 0;
+    if (L.P > HADI_MAX_P) {  // one chunk of all rows: the column pass sweeps each column sequentially (hadi_pass_b_seq)
+        p.col_seq = 1;
+        L.P = 1;
+        L.lc = L.nrows;
+    }
+    L.nrows_pad = L.P * L.lc;
     L.inst_stride = (long long)L.rowp * L.nrows_pad;
+    if (L.inst_stride * 8 >= (1ll << 31)) return 1;  // (the column pass addresses an instance through a 32-bit buffer offset)
     // Row tiles: as tall as possible (halo re-reads cost 4/R) while the launch still has a few blocks per CU
     // (target_waves = 8 per CU), a multiple of W rows each.
     p.W = 4;

@@ -41,6 +41,13 @@ static void run_pass_a(const HadiPlan &pl, const HadiSweepArgs &a, int n, int mo
 }
 
 static int run_row_pass(const HadiPlan &pl, const HadiSweepArgs &a, int n, int mode) {
+    if (pl.row_seq) {  // same choice as hadi_api.hip
+        if (mode) return 2;
+        const unsigned g = a.n_inst * ((pl.L.nrows + 63) / 64);
+        if (a.american) emu::launch(g, 64, [&]() { hadi_pass_a_seq<1>(a, n); });
+        else emu::launch(g, 64, [&]() { hadi_pass_a_seq<0>(a, n); });
+        return 0;
+    }
     if (pl.use_strip && mode == 0 && pl.L.G == 2 && !a.american) {  // paired strips
         emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<8, false, double, 2>(a, n); }, pl.smem_as);
         return 0;
@@ -122,6 +129,12 @@ static int run_sweep_amp(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
 }
 
 static void run_col_pass(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
+    if (pl.col_seq) {  // same choice as hadi_api.hip
+        const unsigned g = a.n_inst * pl.ctiles;
+        if (a.american) emu::launch(g, 64, [&]() { hadi_pass_b_seq<1>(a, n); });
+        else emu::launch(g, 64, [&]() { hadi_pass_b_seq<0>(a, n); });
+        return;
+    }
     if (pl.L.P <= 8) {  // same choice as hadi_api.hip
         if (a.american) emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b<8, true>(a, n); }, pl.smem_b);
         else emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b<8, false>(a, n); }, pl.smem_b);
@@ -200,7 +213,8 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
     std::vector<int> pay_mis(n_inst, 0);
     a.pay_mis = american ? pay_mis.data() : nullptr;
     if (american) emu::launch(8, 64, [&]() { hadi_payoff_shape_kernel(L, n_inst, dU0.data(), pay_mis.data()); });
-    a.R1 = cs ? dR1.data() : nullptr; a.C2 = cs ? dC2.data() : nullptr;
+    std::vector<double> dW(pl.row_seq ? st : 0);
+    a.R1 = cs ? dR1.data() : pl.row_seq ? dW.data() : nullptr; a.C2 = cs ? dC2.data() : nullptr;
     HadiSweepArgs av = a;
     if (cs) av.U = dV.data();
 

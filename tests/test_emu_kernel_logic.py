@@ -244,8 +244,8 @@ def test_plan_invariants_over_shapes_and_batch_sizes(emu):
                 assert grid_b == (n * bgroups + 7) // 8 * 8 and smem_b <= LDS and P <= 16
     assert seen_strip == {2, 4, 8, 16}
     assert emu.emu_plan_full(100, 101, 1, 8, o) == 0  # m2 > m1 is covered (two b1 entries on the v-rows k*m1)
-    assert emu.emu_plan_full(1025, 100, 1, 8, o) != 0  # m1 too wide
-    assert emu.emu_plan_full(600, 528, 1, 8, o) != 0  # more than 16 chunks
+    assert emu.emu_plan_full(1025, 100, 1, 8, o) == 0 and o[0] == 1 and o[1] == 17  # beyond 1024: natural order, sequential row pass
+    assert emu.emu_plan_full(600, 528, 1, 8, o) == 0 and o[3] == 1 and o[5] == 529  # beyond 16 chunks: one chunk, sequential column pass
 
 
 def test_setup_tables_against_oracle_operators(emu):
@@ -395,3 +395,15 @@ def test_instance_resident_team_kernel(emu):
     _run(emu, 200, 100, 2, [100.0], O.EU, 8, r_f=0.01, small=4)      # 4 nodes per lane, 4 chunks
     _run(emu, 260, 20, 3, [100.0], O.EU, 8, small=4, put=True)       # one chunk: no exchange barrier
     _run(emu, 512, 256, 1, [100.0], O.EU, 8, small=4)                # the benchmarked shape: 257 rows, 8 chunks, 9 column tiles
+
+
+def test_sequential_passes_for_shapes_beyond_the_streaming_kernels(emu):
+    """m1 > 1024 (hadi_pass_a_seq: lane <-> v-row, rows in natural order) and m2 > 527 (hadi_pass_b_seq: lane <-> column,
+    unchunked factorisation) -- the reference bounds a grid by its total size only.  Each alone with the streaming kernel of
+    the other direction, both together, American and dividend variants, put data, r_f != 0, m1 a multiple of 64."""
+    _run(emu, 1100, 12, 2, [100.0], O.EU, 8, r_f=0.01)        # sequential row pass + chunked column pass
+    _run(emu, 1088, 40, 2, [100.0, 93.0], O.AM, 8)            # m1 = 17 * 64: the i = 0 slot sits right behind node m1
+    _run(emu, 40, 540, 2, [100.0], O.EU, 8)                   # ring row pass + sequential column pass
+    _run(emu, 300, 600, 2, [104.0], O.AM_DIV, 8)              # 8 nodes per lane + sequential column pass, dividends
+    _run(emu, 1030, 530, 2, [100.0], O.AM, 8, r_f=0.02)       # both sequential
+    _run(emu, 1100, 20, 2, [100.0], O.DIV, 8, put=True)

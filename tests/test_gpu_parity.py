@@ -429,9 +429,13 @@ def test_error_conventions(solver):
         solver.parallel_DO_solve(1, 101.2345, Cm.V_0, m1, m2, N, Cm.T, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO,
                                  Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, ws)
     assert e.value.status == 4
-    g2, U2 = _batch(600, 528, [100.0])  # more than 16 chunks of 33 v-rows
+    g2, U2 = _batch(600, 528, [100.0])  # more than 16 chunks of 33 v-rows: the sequential column pass, Douglas / fp64 state only
     with pytest.raises(H.HadiError) as e:
-        solver.DO_timestepping(600, 528, N, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, g2, U2)
+        solver.CS_scheme(600, 528, N, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, g2, U2)
+    assert e.value.status == 2
+    with pytest.raises(H.HadiError) as e:
+        solver.DO_timestepping(600, 528, N, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, g2, U2,
+                               state_precision=H.STATE_FP32)
     assert e.value.status == 2
     for bad in ({"N_i": [0], "delta_t_i": [0.1]}, {"N_i": [3], "delta_t_i": [-0.1]}, {"N_i": [3], "delta_t_i": [float("nan")]}):
         with pytest.raises(H.HadiError) as e:  # per-instance overrides are validated entry by entry
