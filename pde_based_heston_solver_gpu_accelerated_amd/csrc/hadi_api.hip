@@ -696,7 +696,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     // (hadi_team_kernel; the reference runs every instance's time loop inside one kernel, device_solver.hpp:83-88,226-265).
     // Chosen automatically for batches of up to 8 instances on the full 256-CU device; any failure of the team protocol is
     // recorded by the kernel, checked here, and the batch is solved again on the streaming path below.
-    const bool team_shape = d.n <= 8 && L.G == 1 && (L.B == 8 || L.B == 4) && L.P <= 8 && d.variant == HADI_EU && !cs && !f32 &&
+    const bool team_shape = d.n <= 8 && L.G == 1 && (L.B == 8 || L.B == 4) && L.P <= 8 && !seq_shape && d.variant == HADI_EU && !cs && !f32 &&
                             !d.debug && !prof && d.theta > 0.0 && d.r_d != d.r_f && c->cu_count == 256;
     // (a caller who pins the streaming kernels' geometry -- hadi_set_tuning "strip", "row_tile", "col_groups", "strip_blocks" --
     // gets those kernels)

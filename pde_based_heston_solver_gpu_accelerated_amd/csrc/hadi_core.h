@@ -25,7 +25,7 @@
 // 1024x512 x64: 0.163 -> 0.143 ms, with the fp32 state 0.102 -> 0.082 ms; HBM reads of the pass 9.3 -> 8.7 B per point).
 // ES = bytes per element of the state arrays (8, or 4 for HADI_STATE_FP32).
 #define HADI_ROW_PAD(B, ES) ((B) < 4 ? 8 : ((ES) == 4 ? 32 : 16))
-#define HADI_B1_BOTH 2048  // row-table flag added to RC_B1COL: the row has a b1 entry at column 0 as well (m2 > m1 only)
+#define HADI_B1_BOTH (1 << 24)  // row-table flag added to RC_B1COL (a column index < 2^20): the row has a b1 entry at column 0 as well (m2 > m1 only)
 
 struct HadiLayout {
     int m1, m2, nrows;  // nrows = m2 + 1
