@@ -21,5 +21,9 @@ python3 bench.py > profiles/${TAG}_bench.json 2> $RAW/bench_full.err
 python3 bench.py --workload c3 > profiles/${TAG}_bench_c3.json 2> $RAW/bench_c3.err
 python3 bench.py --workload c5 > profiles/${TAG}_bench_c5.json 2> $RAW/bench_c5.err
 python3 bench.py --workload c4 --steps 5 > profiles/${TAG}_bench_c4.json 2> $RAW/bench_c4.err
+# PMC (HBM traffic, instruction mix) of the config-3 and config-5 kernels
+bash tools/profile_c5_pmc.sh all $TAG
+# the literal config 2 (ONE 512x256x1000 instance) and small batches: instance-resident launch against the streaming path
+python3 tools/team_ab.py 1 2 4 8 > profiles/${TAG}_team_ab.txt 2> $RAW/team_ab.err
 mkdir -p gpurun_out/profiles_out && cp profiles/${TAG}_* profiles/pmc_traffic.json gpurun_out/profiles_out/
 ls gpurun_out/profiles_out
