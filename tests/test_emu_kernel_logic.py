@@ -404,6 +404,6 @@ def test_sequential_passes_for_shapes_beyond_the_streaming_kernels(emu):
     _run(emu, 1100, 12, 2, [100.0], O.EU, 8, r_f=0.01)        # sequential row pass + chunked column pass
     _run(emu, 1088, 40, 2, [100.0, 93.0], O.AM, 8)            # m1 = 17 * 64: the i = 0 slot sits right behind node m1
     _run(emu, 40, 540, 2, [100.0], O.EU, 8)                   # ring row pass + sequential column pass
-    _run(emu, 300, 600, 2, [104.0], O.AM_DIV, 8)              # 8 nodes per lane + sequential column pass, dividends
-    _run(emu, 1030, 530, 2, [100.0], O.AM, 8, r_f=0.02)       # both sequential
+    _run(emu, 140, 540, 2, [104.0], O.AM_DIV, 8)              # 4 nodes per lane + sequential column pass, dividends
+    _run(emu, 1030, 530, 1, [100.0], O.AM, 8, r_f=0.02)       # both sequential
     _run(emu, 1100, 20, 2, [100.0], O.DIV, 8, put=True)
