@@ -176,6 +176,10 @@ int hadi_get_timing(const hadi_ctx *ctx, hadi_timing *out);
  *   "strip"       strip row pass: -1 automatic (default), 0 never, 1 whenever the geometry allows it
  *   "row_tile"    shared-ring row pass: v-rows per block tile (0 = automatic)
  *   "strip_blocks" strip row pass: blocks per instance (0 = automatic)
+ *   "model_strip_row_ns", "model_ring_row_ps", "model_ring_fixed_ns", "model_pstrip_row_ns", "model_pring_row_ps",
+ *   "model_pring_fixed_ns"  constants of the cost model that decides between strips and the shared ring at 8 nodes per lane
+ *                 (hadi_plan.h; defaults 2800 / 2330 / 12000 and, for two wavefronts per row, 3250 / 4300 / 15000: measured on
+ *                 one MI355X, the boxes of a pool differ by +-3 % on the kernels they model)
  *   "col_groups"  column pass: blocks per instance (0 = automatic)
  *   "small_waves" small-grid kernel: wavefronts per instance, 4 or 8 (0 = automatic)
  *   "sub_batch"   batches of several rounds of one instance per CU on grids whose round exceeds the 256 MB memory-side

@@ -1264,6 +1264,15 @@ int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value) {
     else if (!std::strcmp(key, "row_tile")) c->tune.row_tile = value > 0 ? value : 0;
     else if (!std::strcmp(key, "strip_blocks")) c->tune.strip_blocks = value > 0 ? value : 0;
     else if (!std::strcmp(key, "col_groups")) c->tune.col_groups = value > 0 ? value : 0;
+    else if (!std::strncmp(key, "model_", 6)) {  // constants of the plan's cost model (hadi_plan.h)
+        struct { const char *k; int HadiTuning::*f; } const tab[] = {
+            {"model_strip_row_ns", &HadiTuning::strip_row_ns}, {"model_ring_row_ps", &HadiTuning::ring_row_ps}, {"model_ring_fixed_ns", &HadiTuning::ring_fixed_ns},
+            {"model_pstrip_row_ns", &HadiTuning::pstrip_row_ns}, {"model_pring_row_ps", &HadiTuning::pring_row_ps}, {"model_pring_fixed_ns", &HadiTuning::pring_fixed_ns}};
+        bool hit = false;
+        for (auto &e : tab)
+            if (!std::strcmp(key, e.k)) { if (value < 1) return fail(c, HADI_ERR_INVALID, "%s must be positive", key); c->tune.*(e.f) = value; hit = true; }
+        if (!hit) return fail(c, HADI_ERR_INVALID, "unknown tuning key '%s'", key);
+    }
     else if (!std::strcmp(key, "small_waves")) {
         if (value != 0 && value != 4 && value != 8) return fail(c, HADI_ERR_INVALID, "small_waves must be 0, 4 or 8");
         c->tune.small_waves = value;
@@ -1286,6 +1295,12 @@ int hadi_get_tuning(const hadi_ctx *ctx, const char *key, int *value) {
     else if (!std::strcmp(key, "row_tile")) *value = c->tune.row_tile;
     else if (!std::strcmp(key, "strip_blocks")) *value = c->tune.strip_blocks;
     else if (!std::strcmp(key, "col_groups")) *value = c->tune.col_groups;
+    else if (!std::strcmp(key, "model_strip_row_ns")) *value = c->tune.strip_row_ns;
+    else if (!std::strcmp(key, "model_ring_row_ps")) *value = c->tune.ring_row_ps;
+    else if (!std::strcmp(key, "model_ring_fixed_ns")) *value = c->tune.ring_fixed_ns;
+    else if (!std::strcmp(key, "model_pstrip_row_ns")) *value = c->tune.pstrip_row_ns;
+    else if (!std::strcmp(key, "model_pring_row_ps")) *value = c->tune.pring_row_ps;
+    else if (!std::strcmp(key, "model_pring_fixed_ns")) *value = c->tune.pring_fixed_ns;
     else if (!std::strcmp(key, "small_waves")) *value = c->tune.small_waves;
     else return HADI_ERR_INVALID;
     return HADI_OK;

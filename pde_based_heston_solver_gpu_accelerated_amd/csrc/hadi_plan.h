@@ -37,6 +37,10 @@ struct HadiTuning {
     int col_groups = 0;   // column pass: blocks per instance (0 = automatic)
     int small_waves = 0;  // LDS-resident small-grid kernel: wavefronts per instance, 4 or 8 (0 = automatic)
     int strip_blocks = 0; // strip row pass: blocks per instance (0 = automatic); the strips get ceil(rows / (strips per block x blocks)) rows
+    // Constants of the strips-or-ring cost model below, measured on one MI355X (the boxes of a pool differ by +-3 % on the very
+    // kernels they model, and the crossover sits inside that band): adjustable per handle (hadi_set_tuning "model_*")
+    int strip_row_ns = 2800, ring_row_ps = 2330, ring_fixed_ns = 12000;       // 8 nodes per lane, one wavefront per row
+    int pstrip_row_ns = 3250, pring_row_ps = 4300, pring_fixed_ns = 15000;    // two wavefronts per row
 };
 
 // Returns 0 on success, 1 if the shape is outside what the kernels cover.
@@ -123,7 +127,7 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
                 if (!best_sb || cost < best_cost - 1e-9) { best_sb = sb; best_cost = cost; }
             }
             if (best_sb) {
-                const double t_strip = best_cost * 2.8e-3, t_ring = 2.33e-6 * (double)n_inst * L.nrows + 0.012;  // ms
+                const double t_strip = best_cost * tu.strip_row_ns * 1e-6, t_ring = tu.ring_row_ps * 1e-9 * (double)n_inst * L.nrows + tu.ring_fixed_ns * 1e-6;  // ms
                 p.sblocks = best_sb;
                 p.RS = (L.nrows + nwv * best_sb - 1) / (nwv * best_sb);
                 p.grid_as = (int)(((long long)n_inst * p.sblocks + 7) / 8 * 8);
@@ -159,7 +163,7 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
         if (best_sb) {
             // measured at 1024x512 (fp64 state), ms per launch, strips / ring: 8 instances 0.067 / 0.034, 16: 0.068 / 0.051,
             // 32: 0.071 / 0.085, 64: 0.127 / 0.143, 128: 0.254 / 0.309, 256: 0.498 / 0.562
-            const double t_strip = best_cost * 3.25e-3, t_ring = 4.3e-6 * (double)n_inst * L.nrows + 0.015;  // ms
+            const double t_strip = best_cost * tu.pstrip_row_ns * 1e-6, t_ring = tu.pring_row_ps * 1e-9 * (double)n_inst * L.nrows + tu.pring_fixed_ns * 1e-6;  // ms
             p.sblocks = best_sb;
             p.RS = (L.nrows + spb * best_sb - 1) / (spb * best_sb);
             p.grid_as = (int)(((long long)n_inst * p.sblocks + 7) / 8 * 8);

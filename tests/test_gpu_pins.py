@@ -528,3 +528,24 @@ def test_lm_partials_on_the_device(solver):
     assert np.allclose(a + b, got, rtol=1e-12, atol=1e-12 * np.abs(want).max())
     z = H.lm_partials_device(solver, J[:0].contiguous(), base[:0].contiguous(), market[:0].contiguous())
     assert np.all(z == 0.0)
+
+
+def test_plan_cost_model_constants_are_tuning_keys(solver):
+    """The strips-or-ring decision at 8 nodes per lane compares two modelled times whose constants were measured on one box
+    (hadi_plan.h); they are adjustable per handle.  Making a strip row step 10x dearer sends a 256-instance batch to the
+    shared ring, the default brings the strips back; results agree to round-off either way."""
+    m1, m2, N, n = 512, 256, 2, 256
+    strikes = Cm.strikes_for(n)
+    grids, U0 = _batch(m1, m2, strikes)
+    out = {}
+    default = solver.get_tuning("model_strip_row_ns")
+    assert default == 2800
+    for val in (default * 10, default):
+        solver.set_tuning("model_strip_row_ns", val)
+        U = U0.copy()
+        solver.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U)
+        out[val] = (U, solver.describe_last_sweep())
+    assert "hadi_pass_a<8,1" in out[default * 10][1] and "hadi_pass_a_strip<8,EU>" in out[default][1]
+    assert np.abs(out[default][0] - out[default * 10][0]).max() < 1e-12 * np.abs(out[default][0]).max()
+    with pytest.raises(H.HadiError):
+        solver.set_tuning("model_no_such_constant", 5)
