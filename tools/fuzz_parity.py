@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic (needs a GPU): random grid shapes / batch sizes / variants / parameters through libhadi against the oracle.
 
-    python tools/fuzz_parity.py SEED COUNT          (FUZZ_SMALL=1: LDS-resident shapes; FUZZ_WIDE=1: two wavefronts per row)
+    python tools/fuzz_parity.py SEED COUNT          (FUZZ_SMALL=1: LDS-resident shapes; FUZZ_WIDE=1: two wavefronts per row;
+                                                     FUZZ_ONLY=i,j: only these case indices)
 
 The cases come from tests/fuzz_cases.py (case INDEX of seed SEED is always the same problem; flagged cases become
 regression tests in tests/test_gpu_regressions.py).  Judged per instance:
@@ -109,7 +110,9 @@ def main():
     small, wide = bool(os.environ.get("FUZZ_SMALL")), bool(os.environ.get("FUZZ_WIDE"))
     s = H.HestonADI(0)
     worst, bad = 0.0, 0
+    only = [int(x) for x in os.environ.get("FUZZ_ONLY", "").split(",") if x]  # FUZZ_ONLY=i,j: just these case indices
     for c in F.cases(seed, count, small, wide):
+        if only and c["index"] not in only: continue
         r = run_case(s, c)
         ok, j = judge(c, r)
         if not c["f32"]: worst = max(worst, j["err"])
