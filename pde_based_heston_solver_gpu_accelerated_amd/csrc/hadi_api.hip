@@ -247,6 +247,8 @@ hipError_t raise_all_lds_limits() {
     if ((e = raise_lds_limit(hadi_pass_a_strip<8, false, float>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_a_strip<8, false, float, 2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_a_strip<8, false, double, 2>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a_strip<8, 1, double, 2>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a_strip<8, 2, double, 2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b<8, false, float>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b1<16, false, float>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_a<1, 1, 4, 1, 2, false, 0, float>)) != hipSuccess) return e;
@@ -287,8 +289,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     }
     const int nsub = (int)subs.size();
     if (!(d.theta > 0.0) ||  // the strip kernel scales the A1 action by (1 - theta) / theta
-        d.r_d == d.r_f ||    // ... and keeps the s-convection weights multiplied by theta dt (r_d - r_f) (hadi_strip_step)
-        (pl.L.G == 2 && (d.variant == HADI_AM || d.variant == HADI_AM_DIV))) {  // paired strips: European step only
+        d.r_d == d.r_f) {    // ... and keeps the s-convection weights multiplied by theta dt (r_d - r_f) (hadi_strip_step)
         pl.use_strip = 0;
         for (auto &sbt : subs) sbt.pl.use_strip = 0;
     }
@@ -480,6 +481,10 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                 if (amp && !xstep && pl.use_strip && mode == 0) {  // P representation on barrier-free strips
                     const dim3 g(pl.grid_as), b(64 * HADI_STRIP_WAVES(L.B));
                     const size_t sm = pl.smem_as + (size_t)L.rowp * sizeof(double);  // + the payoff row
+                    if (L.G == 2) {  // paired strips (two wavefronts per row)
+                        hipLaunchKernelGGL((hadi_pass_a_strip<8, 2, double, 2>), g, b, sm, q, ar, nstep);
+                        return;
+                    }
                     switch (L.B) {
                         case 8: hipLaunchKernelGGL((hadi_pass_a_strip<8, 2>), g, b, sm, q, ar, nstep); break;
                         case 4: hipLaunchKernelGGL((hadi_pass_a_strip<4, 2>), g, b, sm, q, ar, nstep); break;
@@ -516,8 +521,9 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                     }
                     return;
                 }
-                if (pl.use_strip && mode == 0 && L.G == 2) {  // paired strips (European Douglas step, two wavefronts per row)
-                    hipLaunchKernelGGL((hadi_pass_a_strip<8, false, double, 2>), dim3(pl.grid_as), dim3(512), pl.smem_as, q, ar, nstep);
+                if (pl.use_strip && mode == 0 && L.G == 2) {  // paired strips (Douglas step, two wavefronts per row)
+                    if (american) hipLaunchKernelGGL((hadi_pass_a_strip<8, 1, double, 2>), dim3(pl.grid_as), dim3(512), pl.smem_as, q, ar, nstep);
+                    else hipLaunchKernelGGL((hadi_pass_a_strip<8, false, double, 2>), dim3(pl.grid_as), dim3(512), pl.smem_as, q, ar, nstep);
                     return;
                 }
                 if (pl.use_strip && mode == 0) {  // barrier-free strips (Douglas step, one wavefront per row)
@@ -663,12 +669,13 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     {
         char buf[256];
         char rowk[96];
-        if (amp && pl.use_strip && !cs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<%d,AM-P> (strips of %d rows, no lambda_bar array)", L.B, pl.RS);
+        if (amp && pl.use_strip && !cs && L.G == 2) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,AM-P,double,2> (paired strips of %d rows, no lambda_bar array)", pl.RS);
+        else if (amp && pl.use_strip && !cs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<%d,AM-P> (strips of %d rows, no lambda_bar array)", L.B, pl.RS);
         else if (amp) std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,AM-P> (tiles of %d rows, no lambda_bar array)", L.B, L.G, pl.W, pl.NG, pl.PD, pl.R);
         else if (f32 && pl.use_strip && L.B == 8 && L.G == 2) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,EU,float,2> (paired strips of %d rows, fp32 state)", pl.RS);
         else if (f32 && pl.use_strip && L.B == 8) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,EU,float> (strips of %d rows, fp32 state)", pl.RS);
         else if (f32) std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,EU,float> (tiles of %d rows, fp32 state)", L.B, L.G, pl.W, pl.NG, pl.PD, pl.R);
-        else if (pl.use_strip && !cs && L.G == 2) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,EU,double,2> (paired strips of %d rows)", pl.RS);
+        else if (pl.use_strip && !cs && L.G == 2) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,%s,double,2> (paired strips of %d rows)", american ? "AM" : "EU", pl.RS);
         else if (pl.use_strip && !cs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<%d,%s> (strips of %d rows)", L.B, american ? "AM" : "EU", pl.RS);
         else std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,%s%s> (tiles of %d rows)", L.B, L.G, pl.W, pl.NG, pl.PD,
                            american ? "AM" : "EU", cs ? ",CS" : "", pl.R);

@@ -1213,10 +1213,20 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
                                                const double (&up1)[B], const double (&up2)[B], double c0m2, double c0m1,
                                                double c00, double c0p1, double c0p2, const double (&p_raw)[B],
                                                double lamc0_in, const T *next_row, double (&u_next)[B],
-                                               double eb = 0.0, double e0 = 0.0, double ea = 0.0, const T *raw_row = nullptr) {
-    static_assert(G == 1 || (G == 2 && AMER == 0), "paired strips cover the European step");
+                                               double eb = 0.0, double e0 = 0.0, double ea = 0.0, const T *raw_row = nullptr,
+                                               const double *pay_row = nullptr) {
+    static_assert(G == 1 || (G == 2 && (AMER == 0 || sizeof(T) == 8)), "paired strips: American sweeps with the fp64 state only");
     const int lane = c.lane, rowp = c.rowp;
     const int half = (G > 1) ? c.half : 0;
+    // P representation: where the raw P of row j comes from -- its ring slot again (8 nodes per lane, one wavefront per row:
+    // the kernel keeps that slot one step longer) or the caller's registers (the 3-slot ring of the paired strips has no
+    // slot to spare)
+    constexpr bool RAW_FROM_RING = (B >= HADI_AMP_KEEP_MIN_B && G == 1);
+    // P representation on paired strips: u0 ARRIVES RAW (P of row j) and U = max(P, U_0) is formed where it is used, from
+    // the payoff row in LDS (pay_row) -- once for the explicit operators, once more pair by pair inside the forward sweep,
+    // where lambda_bar = (U - P)/dt falls out of the same two values.  Carrying U and P (or lambda_bar) side by side is
+    // 16 registers more than the 256 this kernel has (hipcc spilled 8 of them into the row loop).
+    constexpr bool RAW_U0 = (AMER == 2 && !RAW_FROM_RING && G == 2);
     const bool first_half = (half == 0), last_half = (half == G - 1);
     constexpr int c0slot = 64 * B * G;
     constexpr int NB = B - 1;
@@ -1252,10 +1262,32 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
 
     // ---- explicit operators (same evaluation order as hadi_row_step) -------------------------------------
     double tt[B], A2U[B];
+    double u0_first = u0[0], u0_last = u0[B - 1];
+    if constexpr (RAW_U0) {
+        // (the payoff pair by pair, behind a compiler barrier: as one 16-register block it stayed live from the caller's
+        // max operations to the end of this loop and the kernel spilled 16 registers into the row loop)
+        double payx[B];
 #pragma unroll
-    for (int r = 0; r < B; r++) {
-        tt[r] = wm * um1[r] + wz * u0[r] + wp * up1[r];
-        A2U[r] = a2l1 * um1[r] + a2m * u0[r] + a2u1 * up1[r];
+        for (int r = 0; r < B; r++) {
+            if ((r & 1) == 0) {
+#if !defined(HADI_EMU)
+                asm volatile("" ::: "memory");
+#endif
+                const double2 pp = *reinterpret_cast<const double2 *>(pay_row + (r >> 1) * 128 * G + 128 * half + 2 * lane);
+                payx[r] = pp.x; payx[r + 1 < B ? r + 1 : r] = pp.y;
+            }
+            const double um = fmax(u0[r], payx[r]);
+            tt[r] = wm * um1[r] + wz * um + wp * up1[r];
+            A2U[r] = a2l1 * um1[r] + a2m * um + a2u1 * up1[r];
+            if (r == 0) u0_first = um;
+            if (r == B - 1) u0_last = um;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < B; r++) {
+            tt[r] = wm * um1[r] + wz * u0[r] + wp * up1[r];
+            A2U[r] = a2l1 * um1[r] + a2m * u0[r] + a2u1 * up1[r];
+        }
     }
     // The second neighbours j-2, j+2 enter A2 only on the upwind rows (v_j > 1: hes_a2_shuffled_kernels.hpp:131-140) and on
     // row 0 (the gamma stencil): three rows in four have both weights zero -- a wave-uniform branch (the weights sit in
@@ -1267,8 +1299,8 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
         for (int r = 0; r < B; r++) A2U[r] = fma(a2u2, up2[r], A2U[r]);
     }
     // s-neighbours of the block: last node of lane-1, first node of lane+1; lane 0 borders i = 0, lane 63 the pad (0)
-    double u0L = hadi_lane_prev(u0[B - 1]), tL = hadi_lane_prev(tt[B - 1]);
-    double u0R = hadi_lane_next(u0[0]), tR = hadi_lane_next(tt[0]);
+    double u0L = hadi_lane_prev(u0_last), tL = hadi_lane_prev(tt[B - 1]);
+    double u0R = hadi_lane_next(u0_first), tR = hadi_lane_next(tt[0]);
     if (lane == 0 && first_half) {
         u0L = c00;
         tL = wm * c0m1 + wz * c00 + wp * c0p1;
@@ -1283,20 +1315,23 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
     const double b1l = (lane == b1lane) ? b1val * cb1 : 0.0;  // this row's b1 entry, in the lane that owns its node
 
     double lam[B], b2v[B];
-    if constexpr (AMER == 1) hadi_get_block<B, 1>(c.Li + (size_t)j * rowp, 0, lane, lam);
+    if constexpr (AMER == 1) hadi_get_block<B, G>(c.Li + (size_t)j * rowp, half, lane, lam);
     if constexpr (AMER == 2) {
         // 8 nodes per lane: the raw P of row j is read again from its ring slot, which stays intact through this step (the
         // kernel keeps one slot behind the prefetch for it) -- carried in 16 more registers the kernel spilled
         double praw8[B];
-        if constexpr (B >= HADI_AMP_KEEP_MIN_B) hadi_get_block<B, 1, T>(raw_row, 0, lane, praw8);
+        if constexpr (RAW_FROM_RING) hadi_get_block<B, 1, T>(raw_row, 0, lane, praw8);
         else {
 #pragma unroll
             for (int r = 0; r < B; r++) praw8[r] = 0.0;
         }
 #pragma unroll
         for (int r = 0; r < B; r++) {
-            lam[r] = (u0[r] - (B >= HADI_AMP_KEEP_MIN_B ? praw8[r] : p_raw[r])) * c.inv_dt;  // exactly max(0, (U_0 - P) / dt): U = max(P, U_0)
-            if (lane == c.m1_lane && r == c.m1_r) lam[r] = 0.0;  // s_max keeps lambda_bar = 0, as in hadi_row_step
+            if constexpr (RAW_U0) lam[r] = 0.0;  // (formed inside the sweep)
+            else {
+                lam[r] = (u0[r] - (RAW_FROM_RING ? praw8[r] : p_raw[r])) * c.inv_dt;  // exactly max(0, (U_0 - P) / dt): U = max(P, U_0)
+                if (lane == c.m1_lane && r == c.m1_r) lam[r] = 0.0;  // s_max keeps lambda_bar = 0, as in hadi_row_step
+            }
         }
     }
     if constexpr (LAST) hadi_get_block<B, G>(c.b2r, half, lane, b2v);
@@ -1308,6 +1343,12 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
     double Bm[B], Bp[B], Dm[B], Dp[B];
     double ys[B], ps[B], gs[B], iu[B], cp[B];
     double il_last = 0.0, im_last = 1.0, d_last = 0.0;
+    double um[B];  // RAW_U0: U = max(P, U_0) of this row, two nodes ahead of the sweep
+    if constexpr (RAW_U0) {
+        const double2 pp = *reinterpret_cast<const double2 *>(pay_row + 128 * half + 2 * lane);
+        um[0] = fmax(u0[0], pp.x);
+        um[1] = fmax(u0[1], pp.y);
+    }
 #pragma unroll
     for (int r = 0; r < B; r++) {
         if ((r & 1) == 0) {
@@ -1316,6 +1357,13 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
 #endif
             const int q = r >> 1;
             const int co = q * 128 * G + 128 * half + 2 * lane;
+            if constexpr (RAW_U0) {
+                if (r + 2 < B) {
+                    const double2 pp = *reinterpret_cast<const double2 *>(pay_row + co + 128 * G);
+                    um[r + 2 < B ? r + 2 : 0] = fmax(u0[r + 2 < B ? r + 2 : 0], pp.x);
+                    um[r + 3 < B ? r + 3 : 0] = fmax(u0[r + 3 < B ? r + 3 : 0], pp.y);
+                }
+            }
             const double2 t0 = *reinterpret_cast<const double2 *>(c.coef + 0 * 64 * B * G + co);
             const double2 t1 = *reinterpret_cast<const double2 *>(c.coef + 1 * 64 * B * G + co);
             const double2 t2 = *reinterpret_cast<const double2 *>(c.coef + 2 * 64 * B * G + co);
@@ -1325,10 +1373,15 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
             Dm[r] = t2.x; Dm[r + 1] = t2.y;
             Dp[r] = t3.x; Dp[r + 1] = t3.y;
         }
-        const double uL = (r == 0) ? u0L : u0[r == 0 ? 0 : r - 1];
-        const double uR = (r == B - 1) ? u0R : u0[r == B - 1 ? r : r + 1];
+        const double u0r = RAW_U0 ? um[r] : u0[r];
+        const double uL = (r == 0) ? u0L : (RAW_U0 ? um[r == 0 ? 0 : r - 1] : u0[r == 0 ? 0 : r - 1]);
+        const double uR = (r == B - 1) ? u0R : (RAW_U0 ? um[r == B - 1 ? r : r + 1] : u0[r == B - 1 ? r : r + 1]);
         const double tl = (r == 0) ? tL : tt[r == 0 ? 0 : r - 1];
         const double tr = (r == B - 1) ? tR : tt[r == B - 1 ? r : r + 1];
+        if constexpr (RAW_U0) {
+            lam[r] = (u0r - u0[r]) * c.inv_dt;  // exactly max(0, (U_0 - P) / dt)
+            if (lane == c.m1_lane && r == c.m1_r) lam[r] = 0.0;
+        }
         // I - theta dt A1 directly (theta dt v comes with the row's table entry): il, im, iu; theta dt A1 U from the
         // same three; Y0 - theta dt A1 U = U + dt (A0 U + A2 U + ...) + (1 - theta)/theta (theta dt A1 U).
         // Bm, Bp hold E = -theta dt (r_d - r_f) s beta_s (scaled while the block copied the arrays to LDS): the convection
@@ -1339,12 +1392,12 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
         const double sm = il + iu[r];
         const double im = c1 - sm;  // 1 + theta dt (lo + up + r_d / 2)
         // theta dt A1 U = -il uL - iu uR + (1 - im) u0   (c1 - c2 = 1)
-        const double T1 = fma(-iu[r], uR, fma(-il, uL, fma(-im, u0[r], u0[r])));
+        const double T1 = fma(-iu[r], uR, fma(-il, uL, fma(-im, u0r, u0r)));
         const double A0U = Bm[r] * tl - (Bm[r] + Bp[r]) * tt[r] + Bp[r] * tr;
         double S = A0U + A2U[r];
         if constexpr (LAST) S += b2v[r] * e_nm1;
         if constexpr (AMER) S += lam[r];
-        double y = fma(dt, S, u0[r]);
+        double y = fma(dt, S, u0r);
         y = fma(kap, T1, y);
         y = fma(b1l, (r == b1r) ? 1.0 : 0.0, y);  // wave-uniform selector: one FMA with a scalar operand (a scalar branch
                                                   // around a single add measured slower: 0.1108 vs 0.1099 ms per launch)
@@ -1521,7 +1574,7 @@ template <int B, int AMER, class T = double, int G = 1>
 // scratch reload inside the row loop drains the DMA prefetch: 3 there)
 __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4 ? HADI_STRIP_OCC_B4 : AMER == 2 ? 3 : 4)) hadi_pass_a_strip(HadiSweepArgs a, int n) {
     static_assert(sizeof(T) == 8 || AMER == 0, "the fp32-state sweep is European only");
-    static_assert(G == 1 || (G == 2 && B == 8 && AMER == 0), "paired strips: 8 nodes per lane, European");
+    static_assert(G == 1 || (G == 2 && B == 8), "paired strips: 8 nodes per lane");
     HADI_DYN_SMEM(double, smem);
     constexpr int NS = HADI_STRIP_NS(B, G, (int)sizeof(T)), NWV = HADI_STRIP_WAVES(B), NPAIR = NWV / G, c0slot = 64 * B * G;
     // American P representation at 8 nodes per lane: one slot stays BEHIND the prefetch -- row j itself, whose raw P the step
@@ -1551,7 +1604,8 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     c.rowp = rowp;
     c.coef = coef;
     c.half = half;
-    c.xch = coef + 4 * 64 * B * G + pair * 16;
+    double *const xch0 = coef + 4 * 64 * B * G + (AMER == 2 ? rowp : 0);  // the pairs' exchange buffers (behind the payoff row)
+    c.xch = xch0 + pair * 16;
     c.err = a.err; c.debug = a.debug;
     c.dt = hadi_uniform_d(ip.dt); c.thdt = hadi_uniform_d(ip.thdt);
     c.c1 = hadi_uniform_d(1.0 + ip.thdt * ip.half_rd);
@@ -1567,8 +1621,11 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     c.inv_dt = 0.0; c.m1_lane = -1; c.m1_r = -1;
     if constexpr (AMER == 2) {
         c.inv_dt = hadi_uniform_d(1.0 / ip.dt);
-        c.m1_lane = (a.L.m1 - 1) / B;
-        c.m1_r = (a.L.m1 - 1) - c.m1_lane * B;
+        const int e1 = a.L.m1 - 1;  // node i = m1 is element m1 - 1 of the row's 64 B G interior nodes
+        if (e1 / (64 * B) == half) {
+            c.m1_lane = (e1 - half * 64 * B) / B;
+            c.m1_r = (e1 - half * 64 * B) % B;
+        }
     }
 
     T *ring = reinterpret_cast<T *>(smem) + (size_t)pair * NS * rowp;
@@ -1651,13 +1708,13 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
         for (int e = threadIdx.x; e < rowp; e += 64 * NWV) pw[e] = pg[e];
     }
     if constexpr (G > 1) {  // the pairs' exchange buffers (values + rendezvous tokens, all zero: no row has token 0)
-        if (threadIdx.x < NPAIR * 16) coef[4 * 64 * B * G + threadIdx.x] = 0.0;
+        if (threadIdx.x < NPAIR * 16) xch0[threadIdx.x] = 0.0;
     }
     __syncthreads();  // the only block-wide barrier: the coefficient arrays are shared
     if (!has_strip) return;
     if constexpr (AMER == 2) {  // U = max(P, U_0) on the rows behind (the current row keeps its raw P for lambda_bar)
         double pay[B];
-        hadi_get_block<B, 1>(payl, 0, lane, pay);
+        hadi_get_block<B, G>(payl, half, lane, pay);
 #pragma unroll
         for (int r = 0; r < B; r++) {
             t2[r] = fmax(t2[r], pay[r]);
@@ -1716,12 +1773,6 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
             w = rt[RC_L1 - HADI_SRC0]; rt[RC_L1 - HADI_SRC0] = rt[RC_U1 - HADI_SRC0]; rt[RC_U1 - HADI_SRC0] = w;
         }
         HADI_STAMPC(25);  // LDS reads + table entry + DMA issue
-        double dm2[B], dm1[B];
-#pragma unroll
-        for (int r = 0; r < B; r++) {
-            dm2[r] = (double)um2[r];
-            dm1[r] = (double)um1[r];
-        }
         double praw[B], lamc0 = 0.0;
         const double c0m2 = hadi_read_lane(c0vec, 0), c0m1 = hadi_read_lane(c0vec, 1), c00 = hadi_read_lane(c0vec, 2);
         const double c0p1 = hadi_read_lane(c0vec, 3), c0p2 = hadi_read_lane(c0vec, 4);
@@ -1730,12 +1781,17 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
         for (int r = 0; r < B; r++) praw[r] = 0.0;
         if constexpr (AMER == 2) {
             double pay[B];
-            hadi_get_block<B, 1>(payl, 0, lane, pay);
+            hadi_get_block<B, G>(payl, half, lane, pay);
             const double pay_c0 = payl[c0slot];
 #pragma unroll
             for (int r = 0; r < B; r++) {
-                if constexpr (!KEEP) praw[r] = u0[r];  // the raw P of row j: lambda_bar comes from it inside the step
-                u0[r] = fmax(u0[r], pay[r]);
+                if constexpr (G == 2) {
+                    // paired strips: u0 stays the raw P (hadi_strip_step, RAW_U0); the row behind was carried raw as well
+                    um1[r] = (T)fmax((double)um1[r], pay[r]);
+                } else {
+                    if constexpr (!KEEP) praw[r] = u0[r];  // the raw P of row j: lambda_bar comes from it inside the step
+                    u0[r] = fmax(u0[r], pay[r]);
+                }
                 up1[r] = fmax(up1[r], pay[r]);
                 up2[r] = fmax(up2[r], pay[r]);
             }
@@ -1743,13 +1799,23 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
             e0m2 = fmax(c0m2, pay_c0); e0m1 = fmax(c0m1, pay_c0); e00 = fmax(c00, pay_c0);
             e0p1 = fmax(c0p1, pay_c0); e0p2 = fmax(c0p2, pay_c0);
         }
+        double dm2[B], dm1[B];
+#pragma unroll
+        for (int r = 0; r < B; r++) {
+            dm2[r] = (double)um2[r];
+            dm1[r] = (double)um1[r];
+        }
         double un[B];
         double xb_ = 0.0, x0_ = 0.0, xa_ = 0.0;  // the partner's boundary node on the rows behind / at / ahead (G = 2)
         if constexpr (G > 1) {
             xb_ = hadi_read_lane(evec, 1); x0_ = hadi_read_lane(evec, 2); xa_ = hadi_read_lane(evec, 3);
+            if constexpr (AMER == 2) {  // (the carried values stay raw P: U = max(P, U_0) on the partner's node too)
+                const double pay_e = payl[epos];
+                xb_ = fmax(xb_, pay_e); x0_ = fmax(x0_, pay_e); xa_ = fmax(xa_, pay_e);
+            }
         }
-        if (j == nrows - 1) hadi_strip_step<B, AMER, true, T, G>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_, slot(j));
-        else hadi_strip_step<B, AMER, false, T, G>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_, slot(j));
+        if (j == nrows - 1) hadi_strip_step<B, AMER, true, T, G>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_, slot(j), payl);
+        else hadi_strip_step<B, AMER, false, T, G>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_, slot(j), payl);
 #pragma unroll
         for (int k = 0; k < NA; k++) aft[k] += hadi_put_block_stores<B, T>();  // the row's vector stores (the i = 0 store is not counted: lower bound)
         double enew = 0.0;

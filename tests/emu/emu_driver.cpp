@@ -48,8 +48,9 @@ static int run_row_pass(const HadiPlan &pl, const HadiSweepArgs &a, int n, int m
         else emu::launch(g, 64, [&]() { hadi_pass_a_seq<0>(a, n); });
         return 0;
     }
-    if (pl.use_strip && mode == 0 && pl.L.G == 2 && !a.american) {  // paired strips
-        emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<8, false, double, 2>(a, n); }, pl.smem_as);
+    if (pl.use_strip && mode == 0 && pl.L.G == 2) {  // paired strips
+        if (a.american) emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<8, 1, double, 2>(a, n); }, pl.smem_as);
+        else emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<8, false, double, 2>(a, n); }, pl.smem_as);
         return 0;
     }
     if (pl.use_strip && mode == 0 && pl.L.G == 1) {  // same choice as hadi_api.hip
@@ -107,7 +108,9 @@ static void run_pass_a_amp(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
                 pl.smem_a + (size_t)pl.L.rowp * sizeof(double));
 }
 static int run_sweep_amp(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
-    if (pl.use_strip && pl.L.G == 1) {  // same choice as hadi_api.hip
+    if (pl.use_strip && pl.L.G == 2) {  // paired strips
+        emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<8, 2, double, 2>(a, n); }, pl.smem_as + (size_t)pl.L.rowp * sizeof(double));
+    } else if (pl.use_strip && pl.L.G == 1) {  // same choice as hadi_api.hip
         const unsigned nt = 64 * HADI_STRIP_WAVES(pl.L.B);
         const size_t sm = pl.smem_as + (size_t)pl.L.rowp * sizeof(double);
         switch (pl.L.B) {

@@ -162,7 +162,14 @@ def test_paired_strip_row_pass(emu):
         _run(emu, 700, 70, 2, [104.0], O.DIV, 1)          # 71 rows -> 4 strips of 18
         _run(emu, 600, 40, 3, [100.0], O.EU, 1, scheme=2)  # fp32 state
         _run(emu, 640, 30, 2, [100.0], O.EU, 1, put=True)
-        _run(emu, 530, 30, 2, [100.0], O.AM, 1)            # American stays on the shared ring
+        # American sweeps on paired strips (round 3): explicit (U, lambda_bar) pair, with dividends, put data; the P
+        # representation (u0 carried raw, U = max(P, U_0) rebuilt inside the step; explicit steps in between for dividends)
+        _run(emu, 530, 30, 3, [100.0], O.AM, 1)
+        _run(emu, 700, 40, 4, [96.0], O.AM_DIV, 1, r_f=0.01)
+        _run(emu, 640, 30, 3, [100.0], O.AM, 1, put=True)
+        _run(emu, 600, 40, 4, [100.0, 93.0], O.AM, 1, r_f=0.01, scheme=3)
+        _run(emu, 1024, 20, 3, [100.0], O.AM, 1, scheme=3, put=True)
+        _run(emu, 700, 70, 6, [104.0], O.AM_DIV, 1, scheme=3)
     finally:
         emu.emu_set_tuning(b"reset", 0)
 

@@ -645,15 +645,40 @@ def test_paired_strip_row_pass_vs_oracle(solver, forced_strips, fp32, variant, n
         _assert_field(U, Uo)
 
 
-def test_american_sweeps_of_wide_grids_stay_on_the_shared_ring(solver, forced_strips):
-    """The paired strips cover the European step; with strips forced an American sweep at m1 > 512 must still run (and
-    meet the oracle) on the shared-ring kernel."""
+@pytest.mark.parametrize("m1,m2,N", [(600, 40, 5), (700, 300, 4), (1024, 512, 3)])
+@pytest.mark.parametrize("variant", ["AM", "AM_DIV"])
+@pytest.mark.parametrize("american_p", [1, 0])
+def test_american_sweeps_of_wide_grids_on_paired_strips(solver, forced_strips, m1, m2, N, variant, american_p):
+    """512 < m1 <= 1024, American and American-with-dividends sweeps on the paired strips (round 3; until then they fell back
+    to the shared ring): the P representation (u0 carried raw, U = max(P, U_0) rebuilt inside the step, explicit steps on the
+    first step and on dividend dates) and the explicit (U, lambda_bar) pair; U and lambda_bar of every instance against the
+    oracle (device_solver.hpp:274-374, 650-942)."""
+    n = 2
+    strikes = Cm.strikes_for(n)
+    solver.set_tuning("american_p", american_p)
+    try:
+        grids, U0, U, lam = _hadi_solve(solver, m1, m2, N, strikes, getattr(H, variant), r_f=0.01, want_lambda=True)
+        d = solver.describe_last_sweep()
+    finally:
+        solver.set_tuning("american_p", 1)
+    assert ("hadi_pass_a_strip<8,AM-P,double,2>" if american_p else "hadi_pass_a_strip<8,AM,double,2>") in d, d
+    p = Cm.oracle_params(m1, m2, N, variant, r_f=0.01)
+    Uo, lo, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0, want_lambda=True)
+    _assert_field(U, Uo)
+    assert np.abs(lam - lo).max() <= 1e-8 * max(1.0, np.abs(lo).max())
+
+
+def test_craig_sneyd_sweeps_of_wide_grids_stay_on_the_shared_ring(solver, forced_strips):
+    """The strips run the Douglas step only: with strips forced a Craig-Sneyd sweep at m1 > 512 must still run (and meet the
+    oracle) on the shared-ring kernel."""
     m1, m2, N, n = 600, 40, 5, 2
     strikes = Cm.strikes_for(n)
-    grids, U0, U, lam = _hadi_solve(solver, m1, m2, N, strikes, H.AM, r_f=0.01, want_lambda=True)
+    grids, U0 = _batch(m1, m2, strikes)
+    U = U0.copy()
+    solver.CS_scheme(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U)
     assert "strip" not in solver.describe_last_sweep()
-    p = Cm.oracle_params(m1, m2, N, "AM", r_f=0.01)
-    Uo, lo, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0, want_lambda=True)
+    p = O.make_params(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, O.EU, None, scheme=1)
+    Uo, _, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0)
     _assert_field(U, Uo)
 
 

@@ -29,6 +29,10 @@ CASES = {
     **{"c2_%d_sb%d" % (k, b): ["--workload", "c2", "--instances", str(k), "--tuning", "strip=1", "--tuning", "strip_blocks=%d" % b]
        for k in (32, 64, 96, 128, 160, 192) for b in (1, 2, 3, 4, 5, 6)},
     **{"c3_sb%d" % b: ["--workload", "c3", "--tuning", "strip_blocks=%d" % b] for b in (1, 2, 3, 4)},
+    # American puts with dividends on the 1024x512 grid, 64 instances: paired strips / shared ring, P representation / explicit pair
+    **{"w_am%s%s" % (t, u): ["--workload", "c3", "--m1", "1024", "--m2", "512", "--timesteps", "300", "--instances", "64",
+                            "--tuning", "strip=%d" % v, "--tuning", "american_p=%d" % w]
+       for t, v in (("s", 1), ("r", 0)) for u, w in (("", 1), ("x", 0))},
     "c2ring": ["--workload", "c2", "--tuning", "strip=0"], "c2am": ["--workload", "c3", "--m1", "512", "--m2", "256", "--timesteps", "1000", "--instances", "256"], "c5": ["--workload", "c5"], "c5f64": ["--workload", "c5", "--state", "fp64"], "c4": ["--workload", "c4"],
 }
 argv = sys.argv[1:]
