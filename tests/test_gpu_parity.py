@@ -893,6 +893,9 @@ STRICT_CASES = [
     (700, 300, 4, 1, H.EU, {"strip": 1}, False),   # paired strips, 3-slot ring
     (1024, 100, 4, 2, H.EU, {"strip": 1}, True),   # paired strips, 4-slot ring of floats
     (1024, 512, 3, 1, H.EU, {"strip": 1}, False),
+    (700, 300, 4, 2, H.AM, {"strip": 1, "american_p": 0}, False),   # paired strips, explicit (U, lambda_bar) pair
+    (700, 300, 4, 2, H.AM_DIV, {"strip": 1}, False),                # paired strips, P representation (+ explicit steps)
+    (1024, 512, 3, 1, H.AM, {"strip": 1}, False),
 ]
 
 
