@@ -25,7 +25,7 @@ Extra objects on the JSON line:
                 Douglas step.  Algorithmic bytes per point: fp64 European 16 + 16; fp32 state 8 + 8; American in the
                 P representation 16 (row pass) + 24 (column pass: Y, P_old in, P out) = 40 -- what this algorithm has to
                 move; SURVEY.md 8(d) budgets 48 for an explicit lambda_bar array.
-  batch_sweep   (c2, one GPU) the same workload at 64 / 256 / 512 instances
+  batch_sweep   (c2, one GPU) the same workload at 64 / 160 / 192 / 256 / 512 instances
   cpu_baseline  the CPU oracle (plain-C port of the reference's algorithm, OpenMP over instances) timed on this box's
                 host cores on a bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -319,8 +319,11 @@ def main():
         if wl == "c2" and n_gpus == 1 and not args.skip_single:
             # ---- the same workload at the batch sizes of SURVEY.md 8(d) C2 (one warm-up + one timed pass each) -----
             sweep_obj = {}
-            for nb in (64, 256, 512):
+            # (160 and 192: batches that leave a partial round of CUs idle, also with hadi_set_tuning("streams", 2) -- two
+            # halves side by side on two streams; an opt-in)
+            for nb, streams in ((64, 1), (160, 1), (160, 2), (192, 1), (192, 2), (256, 1), (512, 1)):
                 ks = [85.0 + 30.0 * k / (nb - 1) for k in range(nb)]
+                solver.set_tuning("streams", streams)
                 gb = H.GridViewsBatch.for_strikes(m1, m2, S_0, V_0, ks)
                 ub0 = torch.from_numpy(gb.call_payoff(ks)).to(dev)
                 gbd, ub = gb.to(dev), torch.empty_like(ub0)
@@ -333,7 +336,8 @@ def main():
                     dt_ = time.perf_counter() - t1
                     if rep > 0 and dt_ < best:
                         best, sw = dt_, solver.timing()["sweep_ms"]
-                sweep_obj[str(nb)] = {"value": nb * m * N / best, "sweep_only": nb * m * N / (sw * 1e-3),
+                solver.set_tuning("streams", 1)
+                sweep_obj[str(nb) + ("_two_streams" if streams == 2 else "")] = {"value": nb * m * N / best, "sweep_only": nb * m * N / (sw * 1e-3),
                                       "sweep_frac": round(nb * m * N / (sw * 1e-3) * B_STEP / 1e9 / HBM_PEAK_GBS, 4),
                                       "kernels": solver.describe_last_sweep().split(";")[0].replace("row pass ", "")}
                 del gbd, ub, ub0

@@ -184,6 +184,11 @@ int hadi_get_timing(const hadi_ctx *ctx, hadi_timing *out);
  *   "small_waves" small-grid kernel: wavefronts per instance, 4 or 8 (0 = automatic)
  *   "sub_batch"   batches of several rounds of one instance per CU on grids whose round exceeds the 256 MB memory-side
  *                 cache run sub-batch by sub-batch through the time loop (default 1; instances are independent)
+ *   "streams"     1 (default) or 2: with 2 the sub-batches of a Douglas sweep run side by side on two streams (a batch that is
+ *                 one sub-batch is cut in two halves; per-launch profiling switches it off).  Same kernels, same results
+ *                 to round-off.  It pays where the launches of the whole batch leave a partial round of CUs idle -- 512x256:
+ *                 160 instances +7 %, 192: +16 %, 24..32: +14..22 %, config 3 (512 x 256x128 American): +5 % -- and costs
+ *                 2..12 % where they fill whole rounds (64, 128, 256, 512 instances); DESIGN.md section 5
  *   "device_vgrid" v-grids of compute_base_prices / compute_jacobian rebuilt per instance on the device (default 1;
  *                 0 = built once on the host with glibc sinh/asinh and broadcast -- bit-identical to the reference's
  *                 host-side Grid, needs one shared V_0)

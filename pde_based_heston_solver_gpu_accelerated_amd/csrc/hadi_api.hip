@@ -51,6 +51,9 @@ struct Ctx {
     int use_amp = 1;    // American sweeps without the lambda_bar array when the payoff depends on s only
     int device_vgrid = 1;  // compute_base_prices / compute_jacobian: v-grids rebuilt per instance on the device
     int sub_batch = 1;     // large batches run sub-batch by sub-batch (run_sweep)
+    int streams = 1;       // sub-batches run on this many streams side by side (1 or 2; hadi_set_tuning "streams")
+    hipStream_t stream2 = nullptr;                 // the second stream of a two-stream sweep
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     int last_nsub = 1;
     HadiTuning tune;    // kernel-selection overrides (hadi_set_tuning)
     hipEvent_t wait_ev = nullptr;  // hadi_wait_stream
@@ -287,6 +290,20 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     } else {
         subs.push_back(SubBatch{0, d.n, pl});
     }
+    // Two streams: the sub-batches run side by side, so that the ramp-up and the tail of one sub-batch's launches are filled
+    // by the other's (instances are independent; the two passes of a step stay ordered within their own stream).  A batch that
+    // is one sub-batch is cut in two halves for it.
+    const bool two_streams = c->streams == 2 && d.scheme == HADI_SCHEME_DOUGLAS && !d.debug && !c->profiling && d.n >= 2;
+    if (two_streams && subs.size() == 1) {
+        const int h0 = (d.n + 1) / 2;
+        subs.clear();
+        subs.push_back(SubBatch{0, h0, pl});
+        subs.push_back(SubBatch{h0, d.n - h0, pl});
+        for (auto &sbt : subs)
+            if (hadi_make_plan(d.m1, d.m2, sbt.cnt, 8 * c->cu_count, &sbt.pl, c->tune, state_bytes))
+                return fail(c, HADI_ERR_UNSUPPORTED, "plan failed");
+        pl = subs[0].pl;
+    }
     const int nsub = (int)subs.size();
     if (!(d.theta > 0.0) ||  // the strip kernel scales the A1 action by (1 - theta) / theta
         d.r_d == d.r_f) {    // ... and keeps the s-convection weights multiplied by theta dt (r_d - r_f) (hadi_strip_step)
@@ -442,9 +459,14 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         return x;
     };
     const HadiSweepArgs a_all = a, av_all = av;
-    auto enqueue_loop = [&](hipStream_t q) -> int {
+    auto enqueue_loop = [&](hipStream_t q0) -> int {
       const int n_first = d.debug ? d.debug_step : 1, n_last = d.debug ? d.debug_step : d.Nmax;
-      for (int sb = 0; sb < nsub; sb++) {  // one sub-batch after the other, each through its whole time loop
+      if (two_streams) {  // fork: the second stream starts behind everything enqueued so far
+          HIP_TRY(c, hipEventRecord(c->fork_ev, q0));
+          HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->fork_ev, 0));
+      }
+      for (int sb = 0; sb < nsub; sb++) {  // one sub-batch after the other (per stream), each through its whole time loop
+        hipStream_t q = (two_streams && (sb & 1)) ? c->stream2 : q0;
         const int o = subs[sb].off, nsb = subs[sb].cnt;
         const HadiPlan &pl = subs[sb].pl;  // (shadows the whole-batch plan: launch geometry of THIS sub-batch)
         const size_t so = (size_t)o * L.inst_stride;
@@ -598,6 +620,10 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         if (amp)  // explicit U and lambda_bar for the outputs
             hipLaunchKernelGGL(hadi_am_materialise_kernel, dim3(grid1d(tot)), dim3(256), 0, q, L, nsb, a.ipar, U0b, Ub, LAMb, pl.pos_m1);
       }
+      if (two_streams) {  // join
+          HIP_TRY(c, hipEventRecord(c->join_ev, c->stream2));
+          HIP_TRY(c, hipStreamWaitEvent(q0, c->join_ev, 0));
+      }
       return HADI_OK;
     };
 
@@ -695,6 +721,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                 for (auto &sbt : subs) c->last_path += " " + std::to_string(sbt.cnt);
                 c->last_path += " instances (each with the geometry of its own size)";
             }
+            if (two_streams) c->last_path += ", side by side on two streams";
         }
     }
     c->last_nsub = nsub;
@@ -745,7 +772,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         {  // field by field: struct padding is not initialised
             const void *ptrs[] = {a.pay_mis, a.U, a.Y, a.LAM, a.U0, a.scoef, a.b2row, a.rowc, a.pb, a.rinv, a.ipar, a.R1, a.C2, av.U, a.err};
             const int ints[] = {a.debug, a.L.m1, a.L.m2, a.L.B, a.L.G, a.L.P, a.n_inst, a.R, a.ntiles, a.ctiles, a.btpw, a.bgroups,
-                                a.american, a.pos_m1, d.scheme, d.prec, (int)amp, pl.row_seq, pl.col_seq, pl.use_strip, pl.RS, pl.sblocks, pl.grid_as, pl.grid_a, pl.grid_b, pl.block_b, pl.W, (int)pl.smem_a, (int)pl.smem_b};
+                                a.american, a.pos_m1, d.scheme, d.prec, (int)amp, (int)two_streams, nsub, pl.row_seq, pl.col_seq, pl.use_strip, pl.RS, pl.sblocks, pl.grid_as, pl.grid_a, pl.grid_b, pl.block_b, pl.W, (int)pl.smem_a, (int)pl.smem_b};
             put(ptrs, sizeof(ptrs));
             put(ints, sizeof(ints));
         }
@@ -1157,6 +1184,9 @@ void release_handle(Ctx *c) {
     for (auto e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->wait_ev) (void)hipEventDestroy(c->wait_ev);
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    if (c->join_ev) (void)hipEventDestroy(c->join_ev);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->err_host) (void)hipHostFree(c->err_host);
     delete c;
@@ -1220,6 +1250,9 @@ int hadi_create(hadi_ctx **out, int device_id) {
     c->name = prop.name;
     c->arch = prop.gcnArchName;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) == hipSuccess;
     ok = ok && raise_all_lds_limits() == hipSuccess;
     for (auto &e : c->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming) == hipSuccess;
@@ -1265,6 +1298,7 @@ int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value) {
     else if (!std::strcmp(key, "american_p")) c->use_amp = value ? 1 : 0;
     else if (!std::strcmp(key, "device_vgrid")) c->device_vgrid = value ? 1 : 0;
     else if (!std::strcmp(key, "sub_batch")) c->sub_batch = value ? 1 : 0;
+    else if (!std::strcmp(key, "streams")) c->streams = value == 2 ? 2 : 1;
     else if (!std::strcmp(key, "strip")) c->tune.strip = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "debug_fault")) c->debug_fault = value;
     else if (!std::strcmp(key, "team_launch")) { c->team_launch = value < 0 ? -1 : (value ? 1 : 0); c->team_failed = 0; }
@@ -1296,6 +1330,7 @@ int hadi_get_tuning(const hadi_ctx *ctx, const char *key, int *value) {
     else if (!std::strcmp(key, "american_p")) *value = c->use_amp;
     else if (!std::strcmp(key, "device_vgrid")) *value = c->device_vgrid;
     else if (!std::strcmp(key, "sub_batch")) *value = c->sub_batch;
+    else if (!std::strcmp(key, "streams")) *value = c->streams;
     else if (!std::strcmp(key, "strip")) *value = c->tune.strip;
     else if (!std::strcmp(key, "debug_fault")) *value = c->debug_fault;
     else if (!std::strcmp(key, "team_launch")) *value = c->team_failed ? -2 : c->team_launch;

@@ -233,6 +233,44 @@ def test_sub_batches_do_not_change_results(solver):
         assert np.array_equal(out[(variant, 1)][1], out[(variant, 0)][1])
 
 
+@pytest.mark.parametrize("m1,m2,N,n,variant,fp32", [(512, 256, 6, 12, "EU", False), (512, 256, 5, 160, "EU", False),
+                                                     (256, 128, 30, 37, "AM_DIV", False), (600, 40, 6, 9, "DIV", True)])
+def test_two_stream_sweep_matches_one_stream(solver, m1, m2, N, n, variant, fp32):
+    """hadi_set_tuning("streams", 2): the batch is cut in two halves that run their time loops side by side on two streams
+    (fork / join by events, also inside a captured graph).  Same kernels on independent instances: equal to the one-stream
+    run to round-off (the halves have the launch geometry of their own size), per-sub-batch dividend jumps and
+    representation changes included; and the first / last instances of both halves against the oracle."""
+    strikes = Cm.strikes_for(n)
+    grids, U0 = _batch(m1, m2, strikes)
+    v = getattr(H, variant)
+    american = v in (H.AM, H.AM_DIV)
+    dt = Cm.T / 500
+    out = {}
+    for streams in (1, 2, 2):  # (twice on two streams: the second call replays the cached graph where there is one)
+        solver.set_tuning("streams", streams)
+        try:
+            U, lam = U0.copy(), np.zeros_like(U0)
+            solver.DO_timestepping(m1, m2, N, dt, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U, variant=v,
+                                   U_0=U0, lambda_bar=lam if american else None,
+                                   dividends=H.Dividends(*Cm.DIVS) if v in (H.DIV, H.AM_DIV) else None,
+                                   state_precision=H.STATE_FP32 if fp32 else H.STATE_FP64)
+            assert ("two streams" in solver.describe_last_sweep()) == (streams == 2), solver.describe_last_sweep()
+        finally:
+            solver.set_tuning("streams", 1)
+        if streams in out:
+            assert np.array_equal(out[streams][0], U) and np.array_equal(out[streams][1], lam)
+        out[streams] = (U, lam)
+    tol = 2e-7 * N if fp32 else 1e-12
+    assert np.abs(out[1][0] - out[2][0]).max() <= tol * np.abs(out[1][0]).max()
+    assert np.abs(out[1][1] - out[2][1]).max() <= 1e-9 * max(1.0, np.abs(out[1][1]).max())
+    rows = np.array(sorted({0, (n + 1) // 2 - 1, (n + 1) // 2, n - 1}))
+    p = O.make_params(m1, m2, N, dt, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, getattr(O, variant),
+                      Cm.DIVS if v in (H.DIV, H.AM_DIV) else None, state_fp32=1 if fp32 else 0)
+    Uo, lo, _ = O.solve_batch(p, grids.Vec_s[rows], grids.Vec_v[rows], grids.Delta_s[rows], grids.Delta_v[rows], U0[rows], U0[rows],
+                              want_lambda=american)
+    assert _field_err(out[2][0][rows], Uo) < (2e-7 * N if fp32 else FIELD_RTOL)
+
+
 @pytest.mark.parametrize("put", [False, True], ids=["call", "put"])
 def test_config3_batch_geometry_field_vs_oracle(solver, put):
     """BASELINE config 3 as benchmarked: 512 American options with dividends on 256x128, 30 of the 500 steps (step size of

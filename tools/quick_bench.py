@@ -33,6 +33,21 @@ CASES = {
     **{"w_am%s%s" % (t, u): ["--workload", "c3", "--m1", "1024", "--m2", "512", "--timesteps", "300", "--instances", "64",
                             "--tuning", "strip=%d" % v, "--tuning", "american_p=%d" % w]
        for t, v in (("s", 1), ("r", 0)) for u, w in (("", 1), ("x", 0))},
+    **{"c2_%d_t2" % k: ["--workload", "c2", "--instances", str(k), "--tuning", "streams=2"] for k in (32, 64, 96, 128, 160, 192, 256, 320, 384, 512)},
+    **{"c2_%d_t1" % k: ["--workload", "c2", "--instances", str(k)] for k in (32, 64, 96, 128, 160, 192, 256, 320, 384, 512)},
+    "c3_t2": ["--workload", "c3", "--tuning", "streams=2"], "c5f64_t2": ["--workload", "c5", "--state", "fp64", "--tuning", "streams=2"], "c5_t2": ["--workload", "c5", "--tuning", "streams=2"],
+    **{"%s_t%d" % (nm, t): base + (["--tuning", "streams=2"] if t == 2 else [])
+       for t in (1, 2) for nm, base in {
+           "g256": ["--workload", "c2", "--m1", "256", "--m2", "128", "--timesteps", "500", "--instances", "1024"],
+           "g256_300": ["--workload", "c2", "--m1", "256", "--m2", "128", "--timesteps", "500", "--instances", "300"],
+           "g200": ["--workload", "c2", "--m1", "200", "--m2", "100", "--timesteps", "400", "--instances", "700"],
+           "g128": ["--workload", "c2", "--m1", "128", "--m2", "64", "--timesteps", "400", "--instances", "2000"],
+           "g100": ["--workload", "c2", "--m1", "100", "--m2", "50", "--timesteps", "400", "--instances", "3000"],
+           "c2_16": ["--workload", "c2", "--instances", "16"], "c2_48": ["--workload", "c2", "--instances", "48"],
+           "c2_24": ["--workload", "c2", "--instances", "24"], "c2_96": ["--workload", "c2", "--instances", "96"],
+           "c2_192": ["--workload", "c2", "--instances", "192"], "c2_320": ["--workload", "c2", "--instances", "320"],
+           "c3_256": ["--workload", "c3", "--instances", "256"], "c3_1024": ["--workload", "c3", "--instances", "1024"],
+       }.items()},
     "c2ring": ["--workload", "c2", "--tuning", "strip=0"], "c2am": ["--workload", "c3", "--m1", "512", "--m2", "256", "--timesteps", "1000", "--instances", "256"], "c5": ["--workload", "c5"], "c5f64": ["--workload", "c5", "--state", "fp64"], "c4": ["--workload", "c4"],
 }
 argv = sys.argv[1:]
