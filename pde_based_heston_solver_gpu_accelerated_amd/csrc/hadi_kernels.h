@@ -1161,6 +1161,9 @@ __global__ void __launch_bounds__(64 * W * G * NG, (B >= 8 ? 2 : B == 4 ? HADI_R
 // (kept one step longer) instead of being carried in registers.  At 8 nodes per lane that ends the spilling (256 VGPRs + 12
 // spilled -> 228; 512x256 x256 American: row pass 0.140 -> 0.121 ms per launch); at 4 the kernel fits either way and the
 // shorter prefetch costs more than the registers gain (256x128 x512 American puts: 0.0841 -> 0.0866).
+#ifndef HADI_STRIP_CREG_MAX_B
+#define HADI_STRIP_CREG_MAX_B 4  // strips of at most this many nodes per lane keep the s-coefficients in registers
+#endif
 #ifndef HADI_AMP_KEEP_MIN_B
 #define HADI_AMP_KEEP_MIN_B 8
 #endif
@@ -1207,14 +1210,14 @@ HADI_DEV HADI_FORCEINLINE int hadi_flag_load(int *f) {
 // the values, on the rows behind / at / ahead of j, of the one node next to this half that belongs to the partner; the
 // tridiagonal system is split at the boundary exactly as in hadi_row_step (second right-hand side through the cyclic
 // reduction, 2x2 system exchanged through LDS), with a rendezvous of the two wavefronts only.
-template <int B, int AMER, bool LAST, class T = double, int G = 1>
+template <int B, int AMER, bool LAST, class T = double, int G = 1, int CREG = 0>
 HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j, const double (&rt)[HADI_RCL],
                                                const double (&um2)[B], const double (&um1)[B], const double (&u0)[B],
                                                const double (&up1)[B], const double (&up2)[B], double c0m2, double c0m1,
                                                double c00, double c0p1, double c0p2, const double (&p_raw)[B],
                                                double lamc0_in, const T *next_row, double (&u_next)[B],
                                                double eb = 0.0, double e0 = 0.0, double ea = 0.0, const T *raw_row = nullptr,
-                                               const double *pay_row = nullptr) {
+                                               const double *pay_row = nullptr, const double *cf = nullptr) {
     static_assert(G == 1 || (G == 2 && (AMER == 0 || sizeof(T) == 8)), "paired strips: American sweeps with the fp64 state only");
     const int lane = c.lane, rowp = c.rowp;
     const int half = (G > 1) ? c.half : 0;
@@ -1364,14 +1367,24 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
                     um[r + 3 < B ? r + 3 : 0] = fmax(u0[r + 3 < B ? r + 3 : 0], pp.y);
                 }
             }
-            const double2 t0 = *reinterpret_cast<const double2 *>(c.coef + 0 * 64 * B * G + co);
-            const double2 t1 = *reinterpret_cast<const double2 *>(c.coef + 1 * 64 * B * G + co);
-            const double2 t2 = *reinterpret_cast<const double2 *>(c.coef + 2 * 64 * B * G + co);
-            const double2 t3 = *reinterpret_cast<const double2 *>(c.coef + 3 * 64 * B * G + co);
-            Bm[r] = t0.x; Bm[r + 1] = t0.y;
-            Bp[r] = t1.x; Bp[r + 1] = t1.y;
-            Dm[r] = t2.x; Dm[r + 1] = t2.y;
-            Dp[r] = t3.x; Dp[r + 1] = t3.y;
+            if constexpr (CREG) {
+                // 2 and 4 nodes per lane: the lane's s-coefficients stay in registers for the whole strip (cf: [4][B], the
+                // kernel has the registers to spare) -- the LDS pipe, shared by all wavefronts of the CU, is what these row
+                // widths run out of first (hadi_pass_a_strip)
+                Bm[r] = cf[0 * B + r]; Bm[r + 1] = cf[0 * B + r + 1];
+                Bp[r] = cf[1 * B + r]; Bp[r + 1] = cf[1 * B + r + 1];
+                Dm[r] = cf[2 * B + r]; Dm[r + 1] = cf[2 * B + r + 1];
+                Dp[r] = cf[3 * B + r]; Dp[r + 1] = cf[3 * B + r + 1];
+            } else {
+                const double2 t0 = *reinterpret_cast<const double2 *>(c.coef + 0 * 64 * B * G + co);
+                const double2 t1 = *reinterpret_cast<const double2 *>(c.coef + 1 * 64 * B * G + co);
+                const double2 t2 = *reinterpret_cast<const double2 *>(c.coef + 2 * 64 * B * G + co);
+                const double2 t3 = *reinterpret_cast<const double2 *>(c.coef + 3 * 64 * B * G + co);
+                Bm[r] = t0.x; Bm[r + 1] = t0.y;
+                Bp[r] = t1.x; Bp[r + 1] = t1.y;
+                Dm[r] = t2.x; Dm[r + 1] = t2.y;
+                Dp[r] = t3.x; Dp[r + 1] = t3.y;
+            }
         }
         const double u0r = RAW_U0 ? um[r] : u0[r];
         const double uL = (r == 0) ? u0L : (RAW_U0 ? um[r == 0 ? 0 : r - 1] : u0[r == 0 ? 0 : r - 1]);
@@ -1712,6 +1725,20 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     }
     __syncthreads();  // the only block-wide barrier: the coefficient arrays are shared
     if (!has_strip) return;
+    constexpr int CREG = (B <= HADI_STRIP_CREG_MAX_B && G == 1) ? 1 : 0;
+    double cf[4 * B];
+    if constexpr (CREG) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            double t[B];
+            hadi_get_block<B, 1>(coef + q * 64 * B, 0, lane, t);
+#pragma unroll
+            for (int r = 0; r < B; r++) cf[q * B + r] = t[r];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4 * B; e++) cf[e] = 0.0;
+    }
     if constexpr (AMER == 2) {  // U = max(P, U_0) on the rows behind (the current row keeps its raw P for lambda_bar)
         double pay[B];
         hadi_get_block<B, G>(payl, half, lane, pay);
@@ -1814,8 +1841,8 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
                 xb_ = fmax(xb_, pay_e); x0_ = fmax(x0_, pay_e); xa_ = fmax(xa_, pay_e);
             }
         }
-        if (j == nrows - 1) hadi_strip_step<B, AMER, true, T, G>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_, slot(j), payl);
-        else hadi_strip_step<B, AMER, false, T, G>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_, slot(j), payl);
+        if (j == nrows - 1) hadi_strip_step<B, AMER, true, T, G, CREG>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_, slot(j), payl, cf);
+        else hadi_strip_step<B, AMER, false, T, G, CREG>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_, slot(j), payl, cf);
 #pragma unroll
         for (int k = 0; k < NA; k++) aft[k] += hadi_put_block_stores<B, T>();  // the row's vector stores (the i = 0 store is not counted: lower bound)
         double enew = 0.0;
