@@ -1367,7 +1367,15 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
                     um[r + 3 < B ? r + 3 : 0] = fmax(u0[r + 3 < B ? r + 3 : 0], pp.y);
                 }
             }
-            if constexpr (CREG) {
+            if constexpr (CREG >= 2) {  // (8 nodes per lane: the two diffusion arrays, or only the second, from registers)
+                const double2 t0 = *reinterpret_cast<const double2 *>(c.coef + 0 * 64 * B * G + co);
+                const double2 t1 = *reinterpret_cast<const double2 *>(c.coef + 1 * 64 * B * G + co);
+                Bm[r] = t0.x; Bm[r + 1] = t0.y;
+                Bp[r] = t1.x; Bp[r + 1] = t1.y;
+                if constexpr (CREG == 2) { Dm[r] = cf[2 * B + r]; Dm[r + 1] = cf[2 * B + r + 1]; }
+                else { const double2 t2 = *reinterpret_cast<const double2 *>(c.coef + 2 * 64 * B * G + co); Dm[r] = t2.x; Dm[r + 1] = t2.y; }
+                Dp[r] = cf[3 * B + r]; Dp[r + 1] = cf[3 * B + r + 1];
+            } else if constexpr (CREG) {
                 // 2 and 4 nodes per lane: the lane's s-coefficients stay in registers for the whole strip (cf: [4][B], the
                 // kernel has the registers to spare) -- the LDS pipe, shared by all wavefronts of the CU, is what these row
                 // widths run out of first (hadi_pass_a_strip)
@@ -1725,7 +1733,13 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     }
     __syncthreads();  // the only block-wide barrier: the coefficient arrays are shared
     if (!has_strip) return;
-    constexpr int CREG = (B <= HADI_STRIP_CREG_MAX_B && G == 1) ? 1 : 0;
+    // 8 nodes per lane, European fp64 (the headline kernel): two of the four arrays fit the registers left over (224 -> 250
+    // VGPRs, no spill): 8 of the 16 coefficient reads per row step less on the LDS pipe, +0.7 % on 512x256 x256 (three
+    // interleaved runs of each build on one box, gpurun_out/r03aa); 3: only the last array (no gain measured)
+#ifndef HADI_STRIP_CREG8
+#define HADI_STRIP_CREG8 2
+#endif
+    constexpr int CREG = (B <= HADI_STRIP_CREG_MAX_B && G == 1) ? 1 : (B == 8 && G == 1 && AMER == 0 && sizeof(T) == 8) ? HADI_STRIP_CREG8 : 0;
     double cf[4 * B];
     if constexpr (CREG) {
 #pragma unroll
