@@ -50,6 +50,10 @@ CASES = {
        }.items()},
     **{"c2_%d_t2s%d" % (k, b): ["--workload", "c2", "--instances", str(k), "--tuning", "streams=2", "--tuning", "strip=1"] + (["--tuning", "strip_blocks=%d" % b] if b else [])
        for k in (32, 48, 64, 96, 128) for b in (0, 1, 2, 3, 4, 6)},
+    "c2_t2b1": ["--workload", "c2", "--tuning", "streams=2", "--tuning", "strip_blocks=1"],
+    "c2_t2b1g3": ["--workload", "c2", "--tuning", "streams=2", "--tuning", "strip_blocks=1", "--tuning", "col_groups=3"],
+    "c2_t2b1g2": ["--workload", "c2", "--tuning", "streams=2", "--tuning", "strip_blocks=1", "--tuning", "col_groups=2"],
+    "c2_512_t2b1g3": ["--workload", "c2", "--instances", "512", "--tuning", "streams=2", "--tuning", "strip_blocks=1", "--tuning", "col_groups=3"],
     "c2ring": ["--workload", "c2", "--tuning", "strip=0"], "c2am": ["--workload", "c3", "--m1", "512", "--m2", "256", "--timesteps", "1000", "--instances", "256"], "c5": ["--workload", "c5"], "c5f64": ["--workload", "c5", "--state", "fp64"], "c4": ["--workload", "c4"],
 }
 argv = sys.argv[1:]
