@@ -180,6 +180,9 @@ int hadi_get_timing(const hadi_ctx *ctx, hadi_timing *out);
  *   "model_pring_fixed_ns"  constants of the cost model that decides between strips and the shared ring at 8 nodes per lane
  *                 (hadi_plan.h; defaults 2800 / 2330 / 12000 and, for two wavefronts per row, 3250 / 4300 / 15000: measured on
  *                 one MI355X, the boxes of a pool differ by +-3 % on the kernels they model)
+ *   "pair_strips" strip row pass at 4 nodes per lane (128 < m1 <= 256): two strips per wavefront on the 8-nodes-per-lane
+ *                 arithmetic (hadi_pass_a_pairs): -1 automatic (default: where the launch still has two blocks per CU and the
+ *                 strips keep 16 rows, e.g. 512 instances of 256x128), 0 never, 1 wherever the strips run
  *   "col_groups"  column pass: blocks per instance (0 = automatic)
  *   "small_waves" small-grid kernel: wavefronts per instance, 4 or 8 (0 = automatic)
  *   "sub_batch"   batches of several rounds of one instance per CU on grids whose round exceeds the 256 MB memory-side

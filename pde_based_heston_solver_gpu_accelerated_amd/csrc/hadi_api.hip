@@ -225,6 +225,9 @@ hipError_t raise_all_lds_limits() {
     if ((e = raise_lds_limit(hadi_pass_a_strip<8, 2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_a_strip<4, 2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_a_strip<2, 2>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a_pairs<0>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a_pairs<1>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_a_pairs<2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_team_kernel<8>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_team_kernel<4>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_seq_kernel<1>)) != hipSuccess) return e;
@@ -500,6 +503,13 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                     else hipLaunchKernelGGL((hadi_pass_a_seq<0>), g, b, 0, q, ar, nstep);
                     return;
                 }
+                if (pl.use_pairs && pl.use_strip && mode == 0 && !f32) {  // 4 nodes per lane: two strips per wavefront
+                    const dim3 g(pl.grid_as), b(64 * HADI_PAIR_WAVES);
+                    if (amp && !xstep) hipLaunchKernelGGL((hadi_pass_a_pairs<2>), g, b, pl.smem_pairs_amp, q, ar, nstep);
+                    else if (american) hipLaunchKernelGGL((hadi_pass_a_pairs<1>), g, b, pl.smem_pairs_eu, q, ar, nstep);
+                    else hipLaunchKernelGGL((hadi_pass_a_pairs<0>), g, b, pl.smem_pairs_eu, q, ar, nstep);
+                    return;
+                }
                 if (amp && !xstep && pl.use_strip && mode == 0) {  // P representation on barrier-free strips
                     const dim3 g(pl.grid_as), b(64 * HADI_STRIP_WAVES(L.B));
                     const size_t sm = pl.smem_as + (size_t)L.rowp * sizeof(double);  // + the payoff row
@@ -705,6 +715,9 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         else if (pl.use_strip && !cs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<%d,%s> (strips of %d rows)", L.B, american ? "AM" : "EU", pl.RS);
         else std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,%s%s> (tiles of %d rows)", L.B, L.G, pl.W, pl.NG, pl.PD,
                            american ? "AM" : "EU", cs ? ",CS" : "", pl.R);
+        if (pl.use_pairs && pl.use_strip && !cs && !f32)
+            std::snprintf(rowk, sizeof rowk, "hadi_pass_a_pairs<%s> (two strips of %d rows per wavefront%s)", amp ? "AM-P" : american ? "AM" : "EU", pl.RS,
+                          amp ? ", no lambda_bar array" : "");
         if (pl.row_seq) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_seq<%s> (one lane per v-row, sequential along s)", american ? "AM" : "EU");
         if (pl.col_seq)
             std::snprintf(buf, sizeof buf, "row pass %s; column pass hadi_pass_b_seq<%s> (one lane per column, sequential along v)", rowk, american ? "AM" : "EU");
@@ -772,7 +785,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         {  // field by field: struct padding is not initialised
             const void *ptrs[] = {a.pay_mis, a.U, a.Y, a.LAM, a.U0, a.scoef, a.b2row, a.rowc, a.pb, a.rinv, a.ipar, a.R1, a.C2, av.U, a.err};
             const int ints[] = {a.debug, a.L.m1, a.L.m2, a.L.B, a.L.G, a.L.P, a.n_inst, a.R, a.ntiles, a.ctiles, a.btpw, a.bgroups,
-                                a.american, a.pos_m1, d.scheme, d.prec, (int)amp, (int)two_streams, nsub, pl.row_seq, pl.col_seq, pl.use_strip, pl.RS, pl.sblocks, pl.grid_as, pl.grid_a, pl.grid_b, pl.block_b, pl.W, (int)pl.smem_a, (int)pl.smem_b};
+                                a.american, a.pos_m1, d.scheme, d.prec, (int)amp, (int)two_streams, nsub, pl.row_seq, pl.col_seq, pl.use_pairs, pl.use_strip, pl.RS, pl.sblocks, pl.grid_as, pl.grid_a, pl.grid_b, pl.block_b, pl.W, (int)pl.smem_a, (int)pl.smem_b};
             put(ptrs, sizeof(ptrs));
             put(ints, sizeof(ints));
         }
@@ -1304,6 +1317,7 @@ int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value) {
     else if (!std::strcmp(key, "team_launch")) { c->team_launch = value < 0 ? -1 : (value ? 1 : 0); c->team_failed = 0; }
     else if (!std::strcmp(key, "row_tile")) c->tune.row_tile = value > 0 ? value : 0;
     else if (!std::strcmp(key, "strip_blocks")) c->tune.strip_blocks = value > 0 ? value : 0;
+    else if (!std::strcmp(key, "pair_strips")) c->tune.pair_strips = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "col_groups")) c->tune.col_groups = value > 0 ? value : 0;
     else if (!std::strncmp(key, "model_", 6)) {  // constants of the plan's cost model (hadi_plan.h)
         struct { const char *k; int HadiTuning::*f; } const tab[] = {
@@ -1336,6 +1350,7 @@ int hadi_get_tuning(const hadi_ctx *ctx, const char *key, int *value) {
     else if (!std::strcmp(key, "team_launch")) *value = c->team_failed ? -2 : c->team_launch;
     else if (!std::strcmp(key, "row_tile")) *value = c->tune.row_tile;
     else if (!std::strcmp(key, "strip_blocks")) *value = c->tune.strip_blocks;
+    else if (!std::strcmp(key, "pair_strips")) *value = c->tune.pair_strips;
     else if (!std::strcmp(key, "col_groups")) *value = c->tune.col_groups;
     else if (!std::strcmp(key, "model_strip_row_ns")) *value = c->tune.strip_row_ns;
     else if (!std::strcmp(key, "model_ring_row_ps")) *value = c->tune.ring_row_ps;

@@ -1892,6 +1892,481 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
 }
 
 // ------------------------------------------------------------------------------------------------
+// Pair strips (128 < m1 <= 256): TWO strips per wavefront, 32 lanes x 8 nodes each.
+// At 4 nodes per lane the strip kernel spends as many instructions on a 256-node row as the 8-node kernel on a 512-node one
+// in everything that is per LANE rather than per node -- the six levels of cyclic reduction, the row scalars, the ring
+// bookkeeping: 380 VALU + 133 SALU + 70 LDS instructions per row and wavefront (PMC, profiles/r02_c3_pmc_summary.json)
+// against 513 + ~150 + ~90 for twice the nodes, and the SIMDs are issue-bound (two wavefronts, 108 % of the issue cycles
+// active).  Here a wavefront runs the 8-node arithmetic on TWO independent strips at once: lanes 0..31 walk strip A, lanes
+// 32..63 strip B of the same instance, lane h of a half owning the nodes 8h+1 .. 8h+8 of its strip's current row.  Same
+// storage layout as the 4-node kernels (row of 272 doubles: the column pass does not change), so a lane's nodes are two
+// 32-byte chunks of a row: {0,1,4,5} and {2,3,6,7}.
+//   cross-lane traffic   the distance-1 exchanges are the same wave shifts; what crosses the half boundary (lane 31 <-> 32)
+//                        is multiplied by a zero coefficient on either side (node 256 or a pad has no upper neighbour: Bp =
+//                        Dp = 0; the first node's coupling to i = 0 is moved to the right-hand side), so no fix-up is needed;
+//                        the cyclic reduction has five levels, its permutes stay inside the half
+//   row scalars          differ between the halves: both halves' table entries come through the scalar cache as before (two
+//                        sets of SGPRs, issued at the loop top) and are moved to per-lane registers under the halves' exec
+//                        masks -- 40 moves per step; vector loads of the entries (tried first) kept 48 more registers live
+//                        across the step and the kernel spilled
+//   ring                 a slot holds the two rows of a step interleaved in 512-byte pieces [piece][half] (one LDS-DMA
+//                        instruction moves a piece of BOTH rows: lanes 0..31 from row A, 32..63 from row B), the two 128-byte
+//                        tails adjacent: 4352 B per slot, 6 DMA instructions per step
+//   out-of-range rows    the strips of a wavefront are equally long or the second is shorter / empty; a finished or empty
+//                        half keeps computing on clamped rows and stores nothing.  Rows j-2 .. j+2 outside the grid are
+//                        clamped too: they only ever meet zero weights (as in hadi_small_seq_kernel)
+// Counted waits as in hadi_pass_a_strip: the row two ahead has landed, younger DMA batches and the result stores stay in flight.
+#define HADI_PAIR_SLOT 544   // doubles per ring slot
+#define HADI_PAIR_WAVES 4    // wavefronts (= 8 strips) per block
+
+HADI_DEV HADI_FORCEINLINE void hadi_pair_get(const double *p, int ch1, double (&u)[8]) {
+    const double2 a = *reinterpret_cast<const double2 *>(p), b = *reinterpret_cast<const double2 *>(p + 2);
+    const double2 c = *reinterpret_cast<const double2 *>(p + ch1), d = *reinterpret_cast<const double2 *>(p + ch1 + 2);
+    u[0] = a.x; u[1] = a.y; u[4] = b.x; u[5] = b.y; u[2] = c.x; u[3] = c.y; u[6] = d.x; u[7] = d.y;
+}
+HADI_DEV HADI_FORCEINLINE void hadi_pair_put(double *p, const double (&u)[8]) {  // global row: the chunks are 128 doubles apart
+    double2 a, b, c, d;
+    a.x = u[0]; a.y = u[1]; b.x = u[4]; b.y = u[5]; c.x = u[2]; c.y = u[3]; d.x = u[6]; d.y = u[7];
+    *reinterpret_cast<double2 *>(p) = a; *reinterpret_cast<double2 *>(p + 2) = b;
+    *reinterpret_cast<double2 *>(p + 128) = c; *reinterpret_cast<double2 *>(p + 130) = d;
+}
+// LDS-DMA of the two rows `grow` (per lane: the row of this lane's half) into ring slot `slot`.  6 vector-memory instructions.
+HADI_DEV HADI_FORCEINLINE void hadi_pair_fetch(const double *__restrict__ grow, double *slot, int lane) {
+    const int H = lane >> 5, h = lane & 31;
+#if defined(HADI_EMU)
+    for (int pc = 0; pc < 4; pc++)
+        for (int e = 0; e < 2; e++) slot[pc * 128 + H * 64 + 2 * h + e] = grow[64 * pc + 2 * h + e];
+    if (h < 8)
+        for (int e = 0; e < 2; e++) slot[512 + 16 * H + 2 * h + e] = grow[256 + 2 * h + e];
+#else
+    const double *gsrc = grow + 2 * h;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)slot);
+#pragma unroll
+    for (int pc = 0; pc < 4; pc++) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" HADI_DMA_POLICY "\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc + 64 * pc), "s"(lds0 + 1024u * pc) : "memory");
+    }
+    // the 128-byte tails (slot 256 = i = 0 and the pads): half A to bytes 4096.., half B right behind it (the hardware adds
+    // 16 x lane to M0: 512 for lane 32, hence the base 4096 + 128 - 512)
+    if (lane < 8) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" HADI_DMA_POLICY "\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc + 256), "s"(lds0 + 4096u) : "memory");
+    }
+    if (lane >= 32 && lane < 40) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" HADI_DMA_POLICY "\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc + 256), "s"(lds0 + 3712u) : "memory");
+    }
+#endif
+}
+#define HADI_PAIR_DMA 6
+
+// One step of both strips of the wavefront.  rv: this lane's row scalars (entries RC_L2 .. RC_WPS of its half's row); the
+// stencil rows as in hadi_strip_step (B = 8); c0*: the i = 0 column of the five rows of this lane's half; yrow: this half's
+// output row (global); act: this half still has rows (stores are skipped otherwise).
+template <int AMER, bool LAST>
+HADI_DEV HADI_FORCEINLINE void hadi_pair_step(const HadiStripCtxT<double> &c, int h, bool act, bool is_last, const double (&rv)[HADI_RCL],
+                                              const double (&um2)[8], const double (&um1)[8], const double (&u0)[8],
+                                              const double (&up1)[8], const double (&up2)[8], double c0m2, double c0m1, double c00,
+                                              double c0p1, double c0p2, double lamc0_in, const double *raw_chunk,
+                                              const double *next_chunk, double (&u_next)[8], double *yrow, const double *lrow) {
+    constexpr int B = 8, NB = 7, c0slot = 256;
+    const int lane = c.lane;
+    const bool first = (h == 0);
+    const double dt = c.dt, thdt = c.thdt, c1 = c.c1, kap = c.kap, e_nm1 = c.e_nm1, e_n = c.e_n;
+    const double vth = rv[RC_VTH - HADI_SRC0];
+    const double wm = rv[RC_WMS - HADI_SRC0], wz = rv[RC_WZS - HADI_SRC0], wp = rv[RC_WPS - HADI_SRC0];
+    const double a2l2 = rv[RC_L2 - HADI_SRC0], a2l1 = rv[RC_L1 - HADI_SRC0], a2m = rv[RC_M - HADI_SRC0], a2u1 = rv[RC_U1 - HADI_SRC0],
+                 a2u2 = rv[RC_U2 - HADI_SRC0];
+    const double b1val = rv[RC_B1VAL - HADI_SRC0];
+    const int b1raw = (int)rv[RC_B1COL - HADI_SRC0];
+    const bool b1_at0 = b1raw == 0 || b1raw >= HADI_B1_BOTH;
+    const int b1col = b1raw >= HADI_B1_BOTH ? b1raw - HADI_B1_BOTH : b1raw;
+    const int b1e = b1col - 1;
+    const int b1k = (b1col >= 1 && (b1e >> 3) == h) ? (b1e & 7) : -1;  // the node of this lane that carries the row's b1 entry
+
+    // ---- column i = 0 ----------------------------------------------------------------------------------
+    const double a2c0 = a2l2 * c0m2 + a2l1 * c0m1 + a2m * c00 + a2u1 * c0p1 + a2u2 * c0p2;
+    const double b1c0 = b1_at0 ? b1val : 0.0;
+    const double b2c0 = (LAST && is_last) ? c.b2r[c0slot] : 0.0;
+    const double lamc0 = (AMER == 1) ? lrow[c0slot] : (AMER == 2) ? lamc0_in : 0.0;
+    const double a1c0 = -c.hr0 * c00;
+    double y0c0 = c00 + dt * (a2c0 + a1c0 + (b1c0 + b2c0) * e_nm1 + lamc0);
+    y0c0 = y0c0 + thdt * (b1c0 * e_n - (a1c0 + b1c0 * e_nm1));
+    const double c2c0 = thdt * (b2c0 * e_n - (a2c0 + b2c0 * e_nm1));
+    const double x0 = y0c0 * c.inv0;
+    const double yout_c0 = x0 + c2c0;
+
+    // ---- explicit operators ---------------------------------------------------------------------------------
+    double tt[B], A2U[B];
+#pragma unroll
+    for (int r = 0; r < B; r++) {
+        tt[r] = wm * um1[r] + wz * u0[r] + wp * up1[r];
+        A2U[r] = a2l1 * um1[r] + a2m * u0[r] + a2u1 * up1[r];
+    }
+#pragma unroll
+    for (int r = 0; r < B; r++) A2U[r] = fma(a2l2, um2[r], A2U[r]);
+#pragma unroll
+    for (int r = 0; r < B; r++) A2U[r] = fma(a2u2, up2[r], A2U[r]);
+    double u0L = hadi_lane_prev(u0[B - 1]), tL = hadi_lane_prev(tt[B - 1]);
+    const double u0R = hadi_lane_next(u0[0]), tR = hadi_lane_next(tt[0]);  // (lane 31: lane 32's values, times Bp = Dp = 0)
+    if (first) {
+        u0L = c00;
+        tL = wm * c0m1 + wz * c00 + wp * c0p1;
+    }
+    const double b1add = b1val * (dt * e_nm1 + thdt * (e_n - e_nm1));
+
+    double lam[B], b2v[B];
+    if constexpr (AMER == 1) hadi_pair_get(lrow + 4 * h, 128, lam);
+    if constexpr (AMER == 2) {
+        double praw[B];
+        hadi_pair_get(raw_chunk, 256, praw);  // the raw P of row j, still intact in its ring slot
+#pragma unroll
+        for (int r = 0; r < B; r++) {
+            lam[r] = (u0[r] - praw[r]) * c.inv_dt;  // exactly max(0, (U_0 - P) / dt): U = max(P, U_0)
+            if (h == c.m1_lane && r == c.m1_r) lam[r] = 0.0;
+        }
+    }
+    if constexpr (LAST) {
+#pragma unroll
+        for (int r = 0; r < B; r++) b2v[r] = 0.0;
+        if (is_last) hadi_pair_get(c.b2r + 4 * h, 128, b2v);
+    }
+
+    hadi_set_prio(1);
+    double Bm[B], Bp[B], Dm[B], Dp[B];
+    double ys[B], ps[B], gs[B], iu[B], cp[B];
+    double il_last = 0.0, im_last = 1.0, d_last = 0.0;
+#pragma unroll
+    for (int r = 0; r < B; r++) {
+        if ((r & 3) == 0 || (r & 3) == 2) {
+#if !defined(HADI_EMU)
+            asm volatile("" ::: "memory");
+#endif
+            // nodes {0,1,4,5} sit in the lane's first chunk, {2,3,6,7} in the second (128 doubles on)
+            const int co = 4 * h + ((r & 2) ? 128 : 0) + ((r & 4) ? 2 : 0);
+            const double2 t0 = *reinterpret_cast<const double2 *>(c.coef + 0 * 256 + co);
+            const double2 t1 = *reinterpret_cast<const double2 *>(c.coef + 1 * 256 + co);
+            const double2 t2 = *reinterpret_cast<const double2 *>(c.coef + 2 * 256 + co);
+            const double2 t3 = *reinterpret_cast<const double2 *>(c.coef + 3 * 256 + co);
+            Bm[r] = t0.x; Bm[r + 1] = t0.y;
+            Bp[r] = t1.x; Bp[r + 1] = t1.y;
+            Dm[r] = t2.x; Dm[r + 1] = t2.y;
+            Dp[r] = t3.x; Dp[r + 1] = t3.y;
+        }
+        const double uL = (r == 0) ? u0L : u0[r == 0 ? 0 : r - 1];
+        const double uR = (r == B - 1) ? u0R : u0[r == B - 1 ? r : r + 1];
+        const double tl = (r == 0) ? tL : tt[r == 0 ? 0 : r - 1];
+        const double tr = (r == B - 1) ? tR : tt[r == B - 1 ? r : r + 1];
+        double il = fma(-vth, Dm[r], Bm[r]);  // (Bm, Bp hold -theta dt (r_d - r_f) s beta_s: hadi_strip_step)
+        iu[r] = fma(-vth, Dp[r], Bp[r]);
+        const double sm = il + iu[r];
+        const double im = c1 - sm;
+        const double T1 = fma(-iu[r], uR, fma(-il, uL, fma(-im, u0[r], u0[r])));
+        const double A0U = Bm[r] * tl - (Bm[r] + Bp[r]) * tt[r] + Bp[r] * tr;
+        double S = A0U + A2U[r];
+        if constexpr (LAST) S += b2v[r] * e_nm1;
+        if constexpr (AMER) S += lam[r];
+        double y = fma(dt, S, u0[r]);
+        y = fma(kap, T1, y);
+        y = fma(b1add, (b1k == r) ? 1.0 : 0.0, y);
+        if (r == 0 && first) {  // x_0 is known: move it to the right-hand side
+            y -= il * x0;
+            il = 0.0;
+        }
+        if (r < NB) {
+            if (r == 0) {
+                const double inv = hadi_rcp(im);
+                cp[0] = iu[0] * inv;
+                ys[0] = y * inv;
+                ps[0] = il * inv;
+            } else {
+                const double inv = hadi_rcp(fma(-il, cp[r - 1], im));
+                cp[r] = iu[r] * inv;
+                ys[r] = fma(-il, ys[r - 1], y) * inv;
+                ps[r] = -(il * ps[r - 1]) * inv;
+            }
+        } else {
+            il_last = il;
+            im_last = im;
+            d_last = y;
+        }
+    }
+    double ra, rb, rcc, rf;
+    {
+        gs[NB - 1] = cp[NB - 1];
+#pragma unroll
+        for (int r = NB - 2; r >= 0; r--) {
+            ys[r] = fma(-cp[r], ys[r + 1], ys[r]);
+            ps[r] = fma(-cp[r], ps[r + 1], ps[r]);
+            gs[r] = -cp[r] * gs[r + 1];
+        }
+        const double p0n = hadi_lane_next(ps[0]), g0n = hadi_lane_next(gs[0]), y0n = hadi_lane_next(ys[0]);
+        ra = -il_last * ps[NB - 1];
+        rb = im_last - il_last * gs[NB - 1] - iu[B - 1] * p0n;
+        rcc = -iu[B - 1] * g0n;
+        rf = d_last - il_last * ys[NB - 1] - iu[B - 1] * y0n;
+    }
+    {   // parallel cyclic reduction over the 32 interface unknowns of each half (normalised rows, see hadi_row_step)
+        hadi_set_prio(3);
+        const double rinv0 = hadi_rcp(rb);
+        ra *= rinv0;
+        rcc *= rinv0;
+        rf *= rinv0;
+#pragma unroll
+        for (int s = 1; s < 32; s <<= 1) {
+            const int up_lane = (lane & 32) | ((lane - s) & 31), dn_lane = (lane & 32) | ((lane + s) & 31);
+            double aL, cL, fL, aR, cR, fR;
+            if (s == 1) {
+                aL = hadi_lane_prev(ra); cL = hadi_lane_prev(rcc); fL = hadi_lane_prev(rf);
+                aR = hadi_lane_next(ra); cR = hadi_lane_next(rcc); fR = hadi_lane_next(rf);
+            } else if (s == 16) {  // h - 16 and h + 16 are the same lane (mod 32)
+                aL = aR = hadi_lane_get(ra, up_lane); cL = cR = hadi_lane_get(rcc, up_lane); fL = fR = hadi_lane_get(rf, up_lane);
+            } else {
+                aL = hadi_lane_get(ra, up_lane); cL = hadi_lane_get(rcc, up_lane); fL = hadi_lane_get(rf, up_lane);
+                aR = hadi_lane_get(ra, dn_lane); cR = hadi_lane_get(rcc, dn_lane); fR = hadi_lane_get(rf, dn_lane);
+            }
+            const double bn = fma(-rcc, aR, fma(-ra, cL, 1.0));
+            const double rn = hadi_rcp(bn);
+            rf = fma(-rcc, fR, fma(-ra, fL, rf)) * rn;
+            if (s < 16) {
+                const double an = -(ra * aL) * rn;
+                const double cn = -(rcc * cR) * rn;
+                ra = an;
+                rcc = cn;
+            }
+        }
+    }
+    hadi_set_prio(0);
+    hadi_pair_get(next_chunk, 256, u_next);  // the row ahead again from its ring slot (flies during the stores)
+    const double X = rf, XL = hadi_lane_prev(X);  // (lane 32: lane 31's X, times ps = 0)
+    double yo[B];
+#pragma unroll
+    for (int r = 0; r < B; r++) {
+        double x;
+        if (r < NB) x = ys[r] - XL * ps[r] - X * gs[r];
+        else x = X;
+        double corr;
+        if constexpr (LAST) corr = thdt * (b2v[r] * e_n - (A2U[r] + b2v[r] * e_nm1));
+        else corr = -thdt * A2U[r];
+        yo[r] = x + corr;
+    }
+    // (plain global stores: the counted waits need them in the same in-order queue as the LDS-DMA loads, hadi_strip_step)
+    if (act) {
+        hadi_pair_put(yrow + 4 * h, yo);
+        if (first) yrow[c0slot] = yout_c0;
+    }
+}
+#define HADI_PAIR_STORES 4  // vector stores per step counted by the waits (the i = 0 store is not: lower bound)
+
+// LDS: [4 wavefronts][NS slots][544] | 4 coefficient arrays of 256 | payoff row of 272 (AMER == 2) | i = 0 history [4][2][4].
+template <int AMER>
+__global__ void __launch_bounds__(64 * HADI_PAIR_WAVES, 2) hadi_pass_a_pairs(HadiSweepArgs a, int n) {
+    HADI_DYN_SMEM(double, smem);
+    // 4-slot ring.  European / explicit pair: the rows 1 .. 4 ahead in the ring (1, 2 landed, 3, 4 in flight); P representation:
+    // the slot of row j itself is kept for the step's re-read of the raw P, so the rows 1 .. 3 ahead.
+    constexpr int NS = 4, D = (AMER == 2) ? 3 : 4, NWV = HADI_PAIR_WAVES, c0slot = 256, ROWP = 272;
+    const int lane = threadIdx.x & 63;
+    const int wave = HADI_UNIFORM((int)(threadIdx.x >> 6));
+    const int H = lane >> 5, h = lane & 31;
+    const int total = a.n_inst * a.sblocks;
+    const int logical = hadi_xcd_remap(blockIdx.x, gridDim.x);
+    if (logical >= total) return;
+    const int inst = logical / a.sblocks, sb = logical - inst * a.sblocks;
+    const HadiInstPar ip = a.ipar[inst];
+    if (n > ip.N) return;
+    const int nrows = a.L.nrows;
+    double *ring = smem + (size_t)wave * NS * HADI_PAIR_SLOT;
+    double *coef = smem + (size_t)NWV * NS * HADI_PAIR_SLOT;
+    double *payl = coef + 4 * 256;
+    double *hist = payl + (AMER == 2 ? ROWP : 0) + (size_t)(wave * 2 + H) * 4;  // this half's last four i = 0 values
+    // the two strips of this wavefront: 2 (sb NWV + wave) and the next one; the second may be shorter or empty
+    const int sA = 2 * (sb * NWV + wave);
+    const int j0A = sA * a.RS, j0B = j0A + a.RS;
+    const int cntA = HADI_UNIFORM(j0A < nrows ? ((j0A + a.RS < nrows ? j0A + a.RS : nrows) - j0A) : 0);
+    const int cntB = HADI_UNIFORM(j0B < nrows ? ((j0B + a.RS < nrows ? j0B + a.RS : nrows) - j0B) : 0);
+    const int j0 = H ? j0B : j0A, cnt = H ? cntB : cntA;
+    const int dir = ((sb * NWV + wave) & 1) ? -1 : 1;  // (both strips of a wavefront walk the same way)
+    const int js = dir > 0 ? j0 : j0 + cnt - 1;
+
+    HadiStripCtxT<double> c;
+    c.lane = lane; c.rowp = ROWP; c.coef = coef; c.half = 0; c.xch = nullptr; c.err = a.err; c.debug = a.debug;
+    c.dt = hadi_uniform_d(ip.dt); c.thdt = hadi_uniform_d(ip.thdt);
+    c.c1 = hadi_uniform_d(1.0 + ip.thdt * ip.half_rd);
+    c.kap = hadi_uniform_d((ip.dt - ip.thdt) / ip.thdt);
+    c.hr0 = hadi_uniform_d(ip.hr0); c.inv0 = hadi_uniform_d(1.0 / (1.0 + ip.thdt * ip.hr0));
+    c.e_nm1 = hadi_uniform_d(exp(ip.bc_rate * ip.dt * (n - 1)));  // device_solver.hpp:238
+    c.e_n = hadi_uniform_d(exp(ip.bc_rate * ip.dt * n));          // device_solver.hpp:246
+    const double *__restrict__ Ub = a.U + (size_t)inst * a.L.inst_stride;
+    double *__restrict__ Yb = a.Y + (size_t)inst * a.L.inst_stride;
+    const double *__restrict__ Lb = (AMER == 1) ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
+    c.Yi = Yb; c.Li = Lb;
+    c.b2r = a.b2row + (size_t)inst * ROWP;
+    c.inv_dt = 0.0; c.m1_lane = -1; c.m1_r = -1;
+    if constexpr (AMER == 2) {
+        c.inv_dt = hadi_uniform_d(1.0 / ip.dt);
+        c.m1_lane = (a.L.m1 - 1) >> 3;
+        c.m1_r = (a.L.m1 - 1) & 7;
+    }
+    // rows of this lane's half, clamped to the grid (out-of-range rows only meet zero weights; a finished half stores nothing)
+    auto grow = [&](int jj) { return Ub + (size_t)(jj < 0 ? 0 : (jj >= nrows ? nrows - 1 : jj)) * ROWP; };
+    auto slot = [&](int q) { return ring + (size_t)(((q % NS) + NS) % NS) * HADI_PAIR_SLOT; };  // q = step index of the row (any sign)
+    const int chunk_off = (h >> 4) * 128 + H * 64 + (h & 15) * 4;  // this lane's first chunk inside a slot (doubles)
+    const int c0_off = 512 + 16 * H;
+    const double *__restrict__ rtab = a.rowc + (size_t)inst * nrows * HADI_RC + HADI_SRC0;
+    auto clampj = [&](int jj) { return jj < 0 ? 0 : (jj >= nrows ? nrows - 1 : jj); };
+    const int jsA = dir > 0 ? j0A : j0A + cntA - 1, jsB = dir > 0 ? j0B : j0B + cntB - 1;  // (wave-uniform)
+
+    // ---- prologue (memory round trips first, then the shared copies and the block's only barrier: hadi_pass_a_strip) ----
+    // step index t <-> row js + dir t; the ring slot of a row is its step index mod NS
+    double um2[8], um1[8], u0[8];
+    // aft[k] = vector-memory instructions issued after the DMA of the row 2 + k ahead (hadi_pass_a_strip)
+    constexpr int NA = D - 2;
+    int aft[NA];
+#pragma unroll
+    for (int k = 0; k < NA; k++) aft[k] = 0;
+    if (cntA > 0) {
+        if constexpr (AMER == 2) hadi_pair_fetch(grow(js), slot(0), lane);
+        hadi_pair_fetch(grow(js + dir), slot(1), lane);
+        hadi_pair_fetch(grow(js + 2 * dir), slot(2), lane);
+#pragma unroll
+        for (int q = 3; q < D; q++) {
+            hadi_pair_fetch(grow(js + q * dir), slot(q), lane);
+#pragma unroll
+            for (int k = 0; k < NA; k++)
+                if (k + 2 < q) aft[k] += HADI_PAIR_DMA;
+        }
+        hadi_pair_get(grow(js - 2 * dir) + 4 * h, 128, um2);
+        hadi_pair_get(grow(js - dir) + 4 * h, 128, um1);
+        hadi_pair_get(grow(js) + 4 * h, 128, u0);
+        if (h == 0) {  // the i = 0 values of the rows js - 2 .. js + 1 (steps -2 .. 1)
+#pragma unroll
+            for (int q = -2; q <= 1; q++) hist[(q + 4) & 3] = grow(js + q * dir)[c0slot];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; r++) um2[r] = um1[r] = u0[r] = 0.0;
+    }
+    {
+        const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 256;
+        const double mq = -(ip.thdt * ip.q);
+        for (int e = threadIdx.x; e < 4 * 256; e += 64 * NWV) coef[e] = (e < 2 * 256) ? mq * sc[e] : sc[e];
+    }
+    if constexpr (AMER == 2) {
+        const double *__restrict__ pg = a.U0 + (size_t)inst * a.L.inst_stride;
+        for (int e = threadIdx.x; e < ROWP; e += 64 * NWV) payl[e] = pg[e];
+    }
+    __syncthreads();
+    if (cntA == 0) return;
+    if constexpr (AMER == 2) {  // U = max(P, U_0) on the rows behind
+        double pay[8];
+        hadi_pair_get(payl + 4 * h, 128, pay);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            um2[r] = fmax(um2[r], pay[r]);
+            um1[r] = fmax(um1[r], pay[r]);
+        }
+    }
+#if !defined(HADI_EMU)
+#pragma unroll
+    for (int r = 0; r < 8; r++) asm volatile("" : "+v"(um2[r]), "+v"(um1[r]), "+v"(u0[r]));
+#endif
+    hadi_wave_rendezvous();
+
+    for (int t = 0; t < cntA; t++) {
+        const int j = js + dir * t;      // this half's row (meaningless once t >= cnt: clamped)
+        const bool act = t < cnt;
+        HadiSRow srA, srB;  // both halves' row-table entries through the scalar cache; they fly during the DMA wait
+        hadi_sload_issue(rtab + (size_t)clampj(jsA + dir * t) * HADI_RC, srA);
+        hadi_sload_issue(rtab + (size_t)clampj(jsB + dir * t) * HADI_RC, srB);
+        hadi_wave_rendezvous();
+        int z = 0;
+        if (t + D <= cntA + 1) {  // into the slot of the row that has just left the ring
+            hadi_pair_fetch(grow(j + D * dir), slot(t + D), lane);
+            z = HADI_PAIR_DMA;
+        }
+        hadi_wait_vmcnt((NA > 0 ? aft[0] : 0) + z);  // the row two ahead has landed
+#pragma unroll
+        for (int k = 0; k + 1 < NA; k++) aft[k] = aft[k + 1] + z;
+        if (NA > 0) aft[NA - 1] = 0;
+        hadi_wave_rendezvous();
+        double up1[8], up2[8];
+        hadi_pair_get(slot(t + 1) + chunk_off, 256, up1);
+        hadi_pair_get(slot(t + 2) + chunk_off, 256, up2);
+        const double c0p2r = slot(t + 2)[c0_off];
+        const double c0m2r = hist[(t + 2) & 3], c0m1r = hist[(t + 3) & 3], c00r = hist[t & 3], c0p1r = hist[(t + 1) & 3];
+        double rvs[HADI_RCL];
+        {
+            double rtA[HADI_RCL], rtB[HADI_RCL];
+            hadi_sload_wait(srA, rtA);
+            hadi_sload_wait(srB, rtB);
+            if (dir < 0) {  // descending: the rows behind are j+1, j+2 -- swap the neighbour weights (scalar registers)
+                double w;
+                w = rtA[RC_WMS - HADI_SRC0]; rtA[RC_WMS - HADI_SRC0] = rtA[RC_WPS - HADI_SRC0]; rtA[RC_WPS - HADI_SRC0] = w;
+                w = rtA[RC_L2 - HADI_SRC0]; rtA[RC_L2 - HADI_SRC0] = rtA[RC_U2 - HADI_SRC0]; rtA[RC_U2 - HADI_SRC0] = w;
+                w = rtA[RC_L1 - HADI_SRC0]; rtA[RC_L1 - HADI_SRC0] = rtA[RC_U1 - HADI_SRC0]; rtA[RC_U1 - HADI_SRC0] = w;
+                w = rtB[RC_WMS - HADI_SRC0]; rtB[RC_WMS - HADI_SRC0] = rtB[RC_WPS - HADI_SRC0]; rtB[RC_WPS - HADI_SRC0] = w;
+                w = rtB[RC_L2 - HADI_SRC0]; rtB[RC_L2 - HADI_SRC0] = rtB[RC_U2 - HADI_SRC0]; rtB[RC_U2 - HADI_SRC0] = w;
+                w = rtB[RC_L1 - HADI_SRC0]; rtB[RC_L1 - HADI_SRC0] = rtB[RC_U1 - HADI_SRC0]; rtB[RC_U1 - HADI_SRC0] = w;
+            }
+            // to per-lane registers under the halves' exec masks (RC_LAST is not needed: is_last below)
+#pragma unroll
+            for (int k = 0; k < HADI_RCL; k++) rvs[k] = 0.0;
+            if (H == 0) {
+#pragma unroll
+                for (int k = 0; k < HADI_RCL; k++)
+                    if (k != RC_LAST - HADI_SRC0) rvs[k] = rtA[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < HADI_RCL; k++)
+                    if (k != RC_LAST - HADI_SRC0) rvs[k] = rtB[k];
+            }
+        }
+        double e0m2 = c0m2r, e0m1 = c0m1r, e00 = c00r, e0p1 = c0p1r, e0p2 = c0p2r, lamc0 = 0.0;
+        if constexpr (AMER == 2) {
+            double pay[8];
+            hadi_pair_get(payl + 4 * h, 128, pay);
+            const double pay_c0 = payl[c0slot];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                u0[r] = fmax(u0[r], pay[r]);
+                up1[r] = fmax(up1[r], pay[r]);
+                up2[r] = fmax(up2[r], pay[r]);
+            }
+            lamc0 = fmax(0.0, (pay_c0 - c00r) * c.inv_dt);
+            e0m2 = fmax(c0m2r, pay_c0); e0m1 = fmax(c0m1r, pay_c0); e00 = fmax(c00r, pay_c0);
+            e0p1 = fmax(c0p1r, pay_c0); e0p2 = fmax(c0p2r, pay_c0);
+        }
+        const bool is_last = act && (j == nrows - 1);
+        double un[8];
+        double *yrow = Yb + (size_t)(act ? j : 0) * ROWP;
+        const double *lrow = (AMER == 1) ? Lb + (size_t)(j < 0 ? 0 : (j >= nrows ? nrows - 1 : j)) * ROWP : nullptr;
+        // ONE copy of the step, the b2 terms under the per-half predicate `is_last` (+16 registers, ~24 instructions per row).
+        // Two copies selected by "does any half sit on the last row" -- the first version -- were laid out by hipcc as "if (x) A;
+        // if (!x) B" with everything B's explicit stage reads (the five max'ed rows, both halves' row scalars) kept alive THROUGH
+        // A: 244 live registers in A against 146 in B, 44 - 60 of them spilled into the row loop, 2.4x slower than the kernel
+        // it was to replace (tools/experiments/README.md).
+        hadi_pair_step<AMER, true>(c, h, act, is_last, rvs, um2, um1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, lamc0,
+                                   slot(t) + chunk_off, slot(t + 1) + chunk_off, un, yrow, lrow);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            um2[r] = um1[r];
+            um1[r] = u0[r];
+            u0[r] = un[r];
+        }
+#pragma unroll
+        for (int k = 0; k < NA; k++) aft[k] += HADI_PAIR_STORES;
+        if (h == 0) hist[(t + 2) & 3] = c0p2r;  // (raw: step t + 1 reads it as c0p1, ... step t + 4 has overwritten it)
+#if !defined(HADI_EMU)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the ring re-reads are retired before the next step reuses the slot
+#endif
+        hadi_wave_rendezvous();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // pass B.  Block = P wavefronts (P*64 threads); wavefront p owns v-rows [p*HADI_LC, (p+1)*HADI_LC) of its
 // instance (rows past nrows are identity padding, so there are no tail branches) and
 // keeps one 64-column tile of them in registers.  A block walks over `btpw` consecutive column tiles

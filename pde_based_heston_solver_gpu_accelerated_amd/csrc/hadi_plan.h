@@ -27,6 +27,10 @@ struct HadiPlan {
     // Shapes beyond the streaming kernels: more than 1024 s-intervals -> sequential row pass (hadi_pass_a_seq, one lane per
     // v-row); more than HADI_MAX_P * HADI_LC v-rows -> sequential column pass (hadi_pass_b_seq, one lane per column)
     int row_seq, col_seq;
+    // 128 < m1 <= 256: the strips run two per wavefront (hadi_pass_a_pairs); RS / sblocks / grid_as then describe THAT geometry
+    // (8 strips per 4-wavefront block)
+    int use_pairs;
+    size_t smem_pairs_eu, smem_pairs_amp;
 };
 
 // Execution-path choices a caller may override through hadi_set_tuning (tests force kernel variants with them; results
@@ -37,6 +41,7 @@ struct HadiTuning {
     int col_groups = 0;   // column pass: blocks per instance (0 = automatic)
     int small_waves = 0;  // LDS-resident small-grid kernel: wavefronts per instance, 4 or 8 (0 = automatic)
     int strip_blocks = 0; // strip row pass: blocks per instance (0 = automatic); the strips get ceil(rows / (strips per block x blocks)) rows
+    int pair_strips = -1; // 4 nodes per lane: two strips per wavefront on the 8-node arithmetic (hadi_pass_a_pairs): -1 automatic, 0 never, 1 always
     // Constants of the strips-or-ring cost model below, measured on one MI355X (the boxes of a pool differ by +-3 % on the very
     // kernels they model, and the crossover sits inside that band): adjustable per handle (hadi_set_tuning "model_*")
     int strip_row_ns = 2800, ring_row_ps = 2330, ring_fixed_ns = 12000;       // 8 nodes per lane, one wavefront per row
@@ -172,6 +177,32 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
             if (tu.strip >= 0) p.use_strip = tu.strip ? 1 : 0;
         }
     }
+    // Pair strips at 4 nodes per lane: wherever the strips are chosen (or forced), unless the caller keeps the plain ones.
+    p.use_pairs = 0;
+    p.smem_pairs_eu = ((size_t)4 * 4 * 544 + 4 * 256 + 32) * sizeof(double);
+    p.smem_pairs_amp = ((size_t)4 * 4 * 544 + 4 * 256 + 272 + 32) * sizeof(double);
+    if (L.B == 4 && L.G == 1 && p.use_strip && tu.pair_strips != 0 && state_bytes == 8) {
+        // 8 strips per block; as many blocks per instance as keep the strips at 16 rows or more, while the launch still offers
+        // two blocks per CU
+        const int cus = target_waves / 8 > 0 ? target_waves / 8 : 1;
+        int sb = 1;
+        while ((long long)n_inst * sb < 2ll * cus && (L.nrows + 8 * (sb + 1) - 1) / (8 * (sb + 1)) >= 16) sb++;
+        const int rs = (L.nrows + 8 * sb - 1) / (8 * sb);
+        // A wavefront of pairs does the work of two, so the launch has half the wavefronts of the plain strips: it pays
+        // (measured, ms per launch pairs / plain: 256x128 x512 American P 0.079 / 0.0815, x1024 0.153 / 0.159, x1024 European
+        // 0.138 / 0.148) only where two 4-wavefront blocks per CU are still there and the strips keep 16 rows -- below that the
+        // plain strips win (x256: 0.059 / 0.047, 200x100 x700 with 13-row strips: 0.094 / 0.074).
+        if (tu.pair_strips == 1 || (rs >= 16 && (long long)n_inst * sb >= 2ll * cus)) {
+            p.use_pairs = 1;
+            p.sblocks = sb;
+            p.RS = rs;
+            p.grid_as = (int)(((long long)n_inst * sb + 7) / 8 * 8);
+        }
+    }
+    if (tu.strip_blocks > 0 && L.B >= 2 && p.use_pairs) {
+        const int rs = (L.nrows + 8 * tu.strip_blocks - 1) / (8 * tu.strip_blocks);
+        if (rs >= 1) { p.sblocks = tu.strip_blocks; p.RS = rs; p.grid_as = (int)(((long long)n_inst * p.sblocks + 7) / 8 * 8); }
+    } else
     if (tu.strip_blocks > 0 && L.B >= 2) {  // forced geometry (measurements): blocks per instance
         const int spb = (L.G == 2) ? HADI_STRIP_WAVES(L.B) / 2 : HADI_STRIP_WAVES(L.B);
         const int rs = (L.nrows + spb * tu.strip_blocks - 1) / (spb * tu.strip_blocks);

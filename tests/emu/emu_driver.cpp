@@ -25,6 +25,7 @@ extern "C" int emu_set_tuning(const char *key, int value) {
     else if (k == "strip") g_tune.strip = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "row_tile") g_tune.row_tile = value > 0 ? value : 0;
     else if (k == "strip_blocks") g_tune.strip_blocks = value > 0 ? value : 0;
+    else if (k == "pair_strips") g_tune.pair_strips = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "col_groups") g_tune.col_groups = value > 0 ? value : 0;
     else if (k == "reset") { g_tune = HadiTuning(); g_debug = 0; }
     else return 1;
@@ -46,6 +47,11 @@ static int run_row_pass(const HadiPlan &pl, const HadiSweepArgs &a, int n, int m
         const unsigned g = a.n_inst * ((pl.L.nrows + 63) / 64);
         if (a.american) emu::launch(g, 64, [&]() { hadi_pass_a_seq<1>(a, n); });
         else emu::launch(g, 64, [&]() { hadi_pass_a_seq<0>(a, n); });
+        return 0;
+    }
+    if (pl.use_pairs && pl.use_strip && mode == 0) {  // two strips per wavefront (4 nodes per lane)
+        if (a.american) emu::launch(pl.grid_as, 64 * HADI_PAIR_WAVES, [&]() { hadi_pass_a_pairs<1>(a, n); }, pl.smem_pairs_eu);
+        else emu::launch(pl.grid_as, 64 * HADI_PAIR_WAVES, [&]() { hadi_pass_a_pairs<0>(a, n); }, pl.smem_pairs_eu);
         return 0;
     }
     if (pl.use_strip && mode == 0 && pl.L.G == 2) {  // paired strips
@@ -108,7 +114,9 @@ static void run_pass_a_amp(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
                 pl.smem_a + (size_t)pl.L.rowp * sizeof(double));
 }
 static int run_sweep_amp(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
-    if (pl.use_strip && pl.L.G == 2) {  // paired strips
+    if (pl.use_pairs && pl.use_strip) {
+        emu::launch(pl.grid_as, 64 * HADI_PAIR_WAVES, [&]() { hadi_pass_a_pairs<2>(a, n); }, pl.smem_pairs_amp);
+    } else if (pl.use_strip && pl.L.G == 2) {  // paired strips
         emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<8, 2, double, 2>(a, n); }, pl.smem_as + (size_t)pl.L.rowp * sizeof(double));
     } else if (pl.use_strip && pl.L.G == 1) {  // same choice as hadi_api.hip
         const unsigned nt = 64 * HADI_STRIP_WAVES(pl.L.B);

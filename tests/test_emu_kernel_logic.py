@@ -414,3 +414,26 @@ def test_sequential_passes_for_shapes_beyond_the_streaming_kernels(emu):
     _run(emu, 140, 540, 2, [104.0], O.AM_DIV, 8)              # 4 nodes per lane + sequential column pass, dividends
     _run(emu, 1030, 530, 1, [100.0], O.AM, 8, r_f=0.02)       # both sequential
     _run(emu, 1100, 20, 2, [100.0], O.DIV, 8, put=True)
+
+
+def test_pair_strips_two_strips_per_wavefront(emu):
+    """128 < m1 <= 256 on strips: hadi_pass_a_pairs runs the 8-nodes-per-lane arithmetic on two strips at once (lanes 0..31
+    / 32..63), rows interleaved in the ring, row scalars per lane, five-level cyclic reduction inside each half.  Strips of
+    equal and unequal length, an empty second strip, ascending and descending wavefronts, full width m1 = 256 and a short
+    grid, r_f != 0 (the b1 node moves along the anti-diagonal through both halves), dividends, put data, American sweeps on
+    the explicit pair and in the P representation, the row that carries b2 in either half."""
+    emu.emu_set_tuning(b"strip", 1)
+    try:
+        _run(emu, 256, 70, 2, [100.0, 93.0], O.EU, 1, r_f=0.01)        # 71 rows: 8 strips of 9 (the last: 8)
+        _run(emu, 200, 40, 3, [100.0], O.EU, 1)                        # 41 rows: strips of 6, the eighth has 5... and r < m1 everywhere
+        _run(emu, 130, 20, 2, [104.0], O.DIV, 1, put=True)             # 21 rows: 3 per strip, the last strip empty
+        _run(emu, 256, 128, 2, [100.0], O.AM, 1)                       # config 3's grid, explicit (U, lambda_bar) pair
+        _run(emu, 256, 128, 3, [100.0, 91.0], O.AM, 1, scheme=3)       # ... and the P representation (4-slot ring, raw row re-read)
+        _run(emu, 180, 33, 3, [100.0], O.AM_DIV, 1, scheme=3, r_f=0.02)
+        emu.emu_set_tuning(b"strip_blocks", 2)                         # 16 strips per instance
+        _run(emu, 256, 128, 2, [100.0], O.EU, 1)
+        emu.emu_set_tuning(b"pair_strips", 0)                          # the plain 4-node strips are still there
+        emu.emu_set_tuning(b"strip_blocks", 0)
+        _run(emu, 200, 40, 2, [100.0], O.EU, 1)
+    finally:
+        emu.emu_set_tuning(b"reset", 0)

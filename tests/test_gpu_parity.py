@@ -588,6 +588,31 @@ def test_strip_row_pass_vs_oracle(solver, forced_strips, variant, name, m1, m2, 
         assert np.abs(lam - lo).max() <= 1e-8 * max(1.0, np.abs(lo).max())
 
 
+@pytest.mark.parametrize("variant,name,american_p", [(H.EU, "EU", 1), (H.DIV, "DIV", 1), (H.AM, "AM", 0), (H.AM, "AM", 1), (H.AM_DIV, "AM_DIV", 1)])
+@pytest.mark.parametrize("m1,m2,N,n", [(256, 128, 25, 3), (200, 100, 6, 2), (130, 20, 5, 2), (180, 33, 7, 1), (256, 70, 6, 5)])
+def test_pair_strips_vs_oracle(solver, forced_strips, variant, name, american_p, m1, m2, N, n):
+    """128 < m1 <= 256: hadi_pass_a_pairs -- two strips per wavefront on the 8-nodes-per-lane arithmetic (lanes 0..31 / 32..63),
+    chosen by itself for batches that fill the GPU (config 3: test_config3_batch_geometry_field_vs_oracle), forced here on
+    small ones: strips of equal and unequal length, an empty second strip (130x20: 21 rows), the b2 row in either half,
+    dividend steps in between (N = 25), the explicit (U, lambda_bar) pair and the P representation; U and lambda_bar
+    of every instance against the oracle."""
+    strikes = Cm.strikes_for(n)
+    solver.set_tuning("pair_strips", 1)
+    solver.set_tuning("american_p", american_p)
+    try:
+        grids, U0, U, lam = _hadi_solve(solver, m1, m2, N, strikes, variant, r_f=0.01, want_lambda=(variant in (H.AM, H.AM_DIV)))
+        d = solver.describe_last_sweep()
+    finally:
+        solver.set_tuning("pair_strips", -1)
+        solver.set_tuning("american_p", 1)
+    assert "hadi_pass_a_pairs<%s>" % ("EU" if variant in (H.EU, H.DIV) else "AM-P" if american_p else "AM") in d, d
+    p = Cm.oracle_params(m1, m2, N, name, r_f=0.01)
+    Uo, lo, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0, want_lambda=True)
+    _assert_field(U, Uo)
+    if lam is not None:
+        assert np.abs(lam - lo).max() <= 1e-8 * max(1.0, np.abs(lo).max())
+
+
 @pytest.mark.parametrize("variant,name", [(H.AM, "AM"), (H.AM_DIV, "AM_DIV")])
 @pytest.mark.parametrize("m1,m2,N,n", [(512, 256, 12, 2), (300, 140, 25, 2), (256, 128, 25, 3), (128, 64, 10, 2)])
 def test_strip_row_pass_with_the_p_representation(solver, forced_strips, variant, name, m1, m2, N, n):
@@ -896,6 +921,9 @@ STRICT_CASES = [
     (700, 300, 4, 2, H.AM, {"strip": 1, "american_p": 0}, False),   # paired strips, explicit (U, lambda_bar) pair
     (700, 300, 4, 2, H.AM_DIV, {"strip": 1}, False),                # paired strips, P representation (+ explicit steps)
     (1024, 512, 3, 1, H.AM, {"strip": 1}, False),
+    (256, 128, 6, 3, H.EU, {"strip": 1, "pair_strips": 1}, False),        # two strips per wavefront (hadi_pass_a_pairs)
+    (256, 128, 25, 3, H.AM_DIV, {"strip": 1, "pair_strips": 1}, False),   # ... P representation with explicit steps in between
+    (200, 100, 6, 2, H.AM, {"strip": 1, "pair_strips": 1, "american_p": 0}, False),
 ]
 
 
@@ -928,7 +956,7 @@ def test_counted_vmcnt_waits_equal_full_drains(solver, strict_solver, m1, m2, N,
                                state_precision=H.STATE_FP32 if fp32 else H.STATE_FP64)
         finally:
             for k in tuning:
-                sv.set_tuning(k, {"strip": -1, "small_grid": 1, "american_p": 1}[k])
+                sv.set_tuning(k, {"strip": -1, "small_grid": 1, "american_p": 1, "pair_strips": -1}[k])
         res.append((U, lam, sv.describe_last_sweep()))
     assert res[0][2] == res[1][2]
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])

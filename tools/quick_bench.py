@@ -54,6 +54,12 @@ CASES = {
     "c2_t2b1g3": ["--workload", "c2", "--tuning", "streams=2", "--tuning", "strip_blocks=1", "--tuning", "col_groups=3"],
     "c2_t2b1g2": ["--workload", "c2", "--tuning", "streams=2", "--tuning", "strip_blocks=1", "--tuning", "col_groups=2"],
     "c2_512_t2b1g3": ["--workload", "c2", "--instances", "512", "--tuning", "streams=2", "--tuning", "strip_blocks=1", "--tuning", "col_groups=3"],
+    **{"%s_p0" % nm: base + ["--tuning", "pair_strips=0"] for nm, base in {
+           "c3": ["--workload", "c3"], "c3_256": ["--workload", "c3", "--instances", "256"], "c3_1024": ["--workload", "c3", "--instances", "1024"],
+           "g256": ["--workload", "c2", "--m1", "256", "--m2", "128", "--timesteps", "500", "--instances", "1024"],
+           "g256_300": ["--workload", "c2", "--m1", "256", "--m2", "128", "--timesteps", "500", "--instances", "300"],
+           "g200": ["--workload", "c2", "--m1", "200", "--m2", "100", "--timesteps", "400", "--instances", "700"]}.items()},
+    "c3_256": ["--workload", "c3", "--instances", "256"], "c3_1024": ["--workload", "c3", "--instances", "1024"],
     "c2ring": ["--workload", "c2", "--tuning", "strip=0"], "c2am": ["--workload", "c3", "--m1", "512", "--m2", "256", "--timesteps", "1000", "--instances", "256"], "c5": ["--workload", "c5"], "c5f64": ["--workload", "c5", "--state", "fp64"], "c4": ["--workload", "c4"],
 }
 argv = sys.argv[1:]
