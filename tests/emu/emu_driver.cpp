@@ -163,7 +163,7 @@ extern "C" int emu_plan(int m1, int m2, int n_inst, int target_waves, int *out /
 }
 
 // every launch-geometry field of the plan, for the host-logic invariants test
-extern "C" int emu_plan_full(int m1, int m2, int n_inst, int target_waves, long long *o /*[24]*/) {
+extern "C" int emu_plan_full(int m1, int m2, int n_inst, int target_waves, long long *o /*[26]*/) {
     HadiPlan pl;
     if (hadi_make_plan(m1, m2, n_inst, target_waves, &pl, g_tune)) return 1;
     const HadiLayout &L = pl.L;
@@ -171,6 +171,7 @@ extern "C" int emu_plan_full(int m1, int m2, int n_inst, int target_waves, long 
     o[7] = pl.W; o[8] = pl.NG; o[9] = pl.PD; o[10] = pl.R; o[11] = pl.ntiles; o[12] = pl.grid_a; o[13] = (long long)pl.smem_a;
     o[14] = pl.use_strip; o[15] = pl.RS; o[16] = pl.sblocks; o[17] = pl.grid_as; o[18] = (long long)pl.smem_as;
     o[19] = pl.ctiles; o[20] = pl.btpw; o[21] = pl.bgroups; o[22] = pl.grid_b; o[23] = (long long)pl.smem_b;
+    o[24] = pl.use_pairs; o[25] = (long long)pl.smem_pairs_amp;
     return 0;
 }
 

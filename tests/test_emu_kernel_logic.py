@@ -209,7 +209,7 @@ def test_plan_invariants_over_shapes_and_batch_sizes(emu):
     columns and instances, and every kernel's dynamic LDS fits the 160 KB of a CU (incl. the payoff row the American P
     representation adds to the row kernels)."""
     LDS = 160 * 1024
-    o = (C.c_longlong * 24)()
+    o = (C.c_longlong * 26)()
     shapes = [(m1, m2) for m1 in (20, 50, 64, 65, 100, 128, 129, 200, 256, 257, 300, 400, 512, 513, 700, 1024)
               for m2 in (8, 25, 32, 33, 64, 66, 100, 128, 131, 132, 200, 256, 263, 264, 300, 512) if m2 <= m1]
     seen_strip = set()
@@ -218,13 +218,18 @@ def test_plan_invariants_over_shapes_and_batch_sizes(emu):
             for tw in (8, 2048):  # emulator-sized and MI355X-sized (8 wavefronts x 256 CUs)
                 assert emu.emu_plan_full(m1, m2, n, tw, o) == 0, (m1, m2, n)
                 (B, G, rowp, P, nrows, npad, stride, W, NG, PD, R, ntiles, grid_a, smem_a, use_strip, RS, sblocks, grid_as,
-                 smem_as, ctiles, btpw, bgroups, grid_b, smem_b) = list(o)
+                 smem_as, ctiles, btpw, bgroups, grid_b, smem_b, use_pairs, smem_pairs) = list(o)
                 assert nrows == m2 + 1 and npad == 33 * P and npad >= nrows and stride == rowp * npad
                 assert 64 * B * G >= m1 and rowp == 64 * B * G + (16 if B >= 4 else 8) and B in (1, 2, 4, 8) and G in (1, 2)
                 assert R % W == 0 and R * ntiles >= nrows and grid_a * NG >= n * ntiles
                 assert smem_a + rowp * 8 <= LDS
                 nwv = 8 if B == 8 else 4
-                if B >= 2 and G == 1:  # strips can be forced for any of these (hadi_set_tuning "strip"), so check them all
+                if use_pairs:  # two strips per wavefront (hadi_pass_a_pairs): 8 strips per 4-wavefront block, chosen only
+                    # where the launch keeps two blocks per CU and the strips 16 rows
+                    assert B == 4 and G == 1 and use_strip and RS >= 16 and RS * 8 * sblocks >= nrows and grid_as >= n * sblocks
+                    assert n * sblocks >= 2 * max(1, tw // 8) and smem_pairs <= LDS
+                    seen_strip.add("pairs")
+                elif B >= 2 and G == 1:  # strips can be forced for any of these (hadi_set_tuning "strip"), so check them all
                     assert RS * nwv * sblocks >= nrows and grid_as >= n * sblocks
                     assert smem_as + rowp * 8 <= LDS
                 elif G == 2:  # paired strips: 4 pairs per block, 3 ring slots of doubles
@@ -249,7 +254,7 @@ def test_plan_invariants_over_shapes_and_batch_sizes(emu):
                 if (m1, m2, n, tw) == (1024, 512, 64, 2048):  # config 5: 16 full tiles on 4 blocks, the short one appended
                     assert (btpw, bgroups) == (4, 4)
                 assert grid_b == (n * bgroups + 7) // 8 * 8 and smem_b <= LDS and P <= 16
-    assert seen_strip == {2, 4, 8, 16}
+    assert seen_strip == {2, 4, 8, 16, "pairs"}
     assert emu.emu_plan_full(100, 101, 1, 8, o) == 0  # m2 > m1 is covered (two b1 entries on the v-rows k*m1)
     assert emu.emu_plan_full(1025, 100, 1, 8, o) == 0 and o[0] == 1 and o[1] == 17  # beyond 1024: natural order, sequential row pass
     assert emu.emu_plan_full(600, 528, 1, 8, o) == 0 and o[3] == 1 and o[5] == 529  # beyond 16 chunks: one chunk, sequential column pass

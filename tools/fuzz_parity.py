@@ -2,7 +2,8 @@
 """Diagnostic (needs a GPU): random grid shapes / batch sizes / variants / parameters through libhadi against the oracle.
 
     python tools/fuzz_parity.py SEED COUNT          (FUZZ_SMALL=1: LDS-resident shapes; FUZZ_WIDE=1: two wavefronts per row;
-                                                     FUZZ_ONLY=i,j: only these case indices)
+                                                     FUZZ_ONLY=i,j: only these case indices; FUZZ_PAIRS=1: grids with
+                                                     128 < m1 <= 256 forced onto hadi_pass_a_pairs)
 
 The cases come from tests/fuzz_cases.py (case INDEX of seed SEED is always the same problem; flagged cases become
 regression tests in tests/test_gpu_regressions.py).  Judged per instance:
@@ -36,7 +37,9 @@ def run_case(s, c):
     U0 = grids.put_payoff(strikes) if put else grids.call_payoff(strikes)
     U, lam = U0.copy(), np.zeros_like(U0)
     div = H.Dividends(*Cm.DIVS) if variant in (H.DIV, H.AM_DIV) else None
-    defaults = {"american_p": 1, "strip": -1, "small_seq": -1}
+    defaults = {"american_p": 1, "strip": -1, "small_seq": -1, "pair_strips": -1}
+    if os.environ.get("FUZZ_PAIRS") and 128 < m1 <= 256:  # (not part of the generator's stream: the cases stay the same problems)
+        c["tuning"]["strip"], c["tuning"]["pair_strips"] = 1, 1
     for k, v in c["tuning"].items(): s.set_tuning(k, v)
     try:
         s.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, c["r_f"], *c["model"], grids, U, variant=variant, U_0=U0,
@@ -113,6 +116,7 @@ def main():
     only = [int(x) for x in os.environ.get("FUZZ_ONLY", "").split(",") if x]  # FUZZ_ONLY=i,j: just these case indices
     for c in F.cases(seed, count, small, wide):
         if only and c["index"] not in only: continue
+        if os.environ.get("FUZZ_PAIRS") and not (128 < c["m1"] <= 256): continue
         r = run_case(s, c)
         ok, j = judge(c, r)
         if not c["f32"]: worst = max(worst, j["err"])
