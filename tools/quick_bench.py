@@ -60,6 +60,8 @@ CASES = {
            "g256_300": ["--workload", "c2", "--m1", "256", "--m2", "128", "--timesteps", "500", "--instances", "300"],
            "g200": ["--workload", "c2", "--m1", "200", "--m2", "100", "--timesteps", "400", "--instances", "700"]}.items()},
     "c3_256": ["--workload", "c3", "--instances", "256"], "c3_1024": ["--workload", "c3", "--instances", "1024"],
+    "c3_t2p1": ["--workload", "c3", "--tuning", "streams=2", "--tuning", "pair_strips=1"],
+    "c3_1024_t2": ["--workload", "c3", "--instances", "1024", "--tuning", "streams=2"],
     "c2ring": ["--workload", "c2", "--tuning", "strip=0"], "c2am": ["--workload", "c3", "--m1", "512", "--m2", "256", "--timesteps", "1000", "--instances", "256"], "c5": ["--workload", "c5"], "c5f64": ["--workload", "c5", "--state", "fp64"], "c4": ["--workload", "c4"],
 }
 argv = sys.argv[1:]
