@@ -85,3 +85,22 @@ def test_ring_kernels_issue_at_least_the_stores_the_waits_count(kernels):
         assert n_st >= 2 * STORES(B, es), (name, n_st)   # two copies of hadi_row_step (last v-row or not)
         seen += 1
     assert seen >= 25
+
+
+def test_pair_strip_kernels_issue_the_dma_pieces_and_stores_the_waits_count(kernels):
+    """hadi_pass_a_pairs: HADI_PAIR_DMA = 6 LDS-DMA instructions per fetch (four 1 KiB pieces of both rows + the two 128-byte
+    tails), four fetch sites (three in the prologue, one in the loop; the P representation fetches row js instead of the row
+    4 ahead), HADI_PAIR_STORES = 4 counted row stores per step (one copy of the step)."""
+    csrc = os.path.join(ROOT, "pde_based_heston_solver_gpu_accelerated_amd", "csrc")
+    k = open(os.path.join(csrc, "hadi_kernels.h")).read()
+    assert "#define HADI_PAIR_DMA 6" in k and "#define HADI_PAIR_STORES 4" in k
+    seen = 0
+    for name, body in kernels.items():
+        if not name.startswith("hadi_pass_a_pairs<"):
+            continue
+        n_dma = len(re.findall(r"\bglobal_load_lds_dwordx4\b", body))
+        n_st = len(re.findall(r"\bglobal_store_dwordx4\b", body))
+        assert n_dma == 4 * 6, (name, n_dma)
+        assert n_st >= 4, (name, n_st)
+        seen += 1
+    assert seen == 3
