@@ -360,6 +360,22 @@ def main():
             if (m1, m2, N) == (512, 256, 1000):
                 single.update(reference_price=8.8942192888223310, price_abs_err=abs(price1 - 8.8942192888223310))
 
+        two_streams = None
+        if wl == "c3" and n_gpus == 1 and not args.skip_single and not args.tuning:
+            # the same batch as two halves side by side on two streams (hadi_set_tuning "streams" = 2, an opt-in: DESIGN.md
+            # section 5): one warm-up + the best of two timed passes
+            solver.set_tuning("streams", 2)
+            best2 = 1e30
+            for rep in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                step()
+                torch.cuda.synchronize()
+                if rep > 0:
+                    best2 = min(best2, time.perf_counter() - t1)
+            two_streams = {"value": units_step / best2, "kernels": solver.describe_last_sweep()}
+            solver.set_tuning("streams", 1)
+
         state_err = None
         if state == "fp32" and wl in ("c2", "c5") and n_gpus == 1 and not args.skip_single:
             # what the fp32 state costs at this step count: the K ~ 100 instance once more with the fp64 state
@@ -415,7 +431,7 @@ def main():
             "cpu_baseline": cpu,
             "batch_sweep": sweep_obj,
             "single_instance": single,
-            "fp32_state_error": state_err,
+            "fp32_state_error": state_err, "two_streams": two_streams,
             "price_check": price_check,
             "device": info,
         }
