@@ -3378,9 +3378,14 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
     const double *urow = Ul + (act ? j : 0) * PL;  // (idle lanes walk row 0 and store nothing)
     // The v-neighbours j-2 .. j+2, clamped to the grid instead of zero halo rows (1.7 KB that cost the sixth instance per CU):
     // a clamped row only ever meets a zero weight -- the first / last rows of A0 and A2 have no entries beyond the grid.
-    const int jr = act ? j : 0;
-    const double *pm2 = Ul + (jr >= 2 ? jr - 2 : 0) * PL, *pm1 = Ul + (jr >= 1 ? jr - 1 : 0) * PL;
-    const double *pp1 = Ul + (jr + 1 < nrows ? jr + 1 : nrows - 1) * PL, *pp2 = Ul + (jr + 2 < nrows ? jr + 2 : nrows - 1) * PL;
+    // The v-neighbours j-2 .. j+2 of a column are the SAME column in the neighbouring LANES' rows: one LDS read of the own row
+    // and four wave shifts (DPP) instead of five LDS reads per node -- at six wavefronts per CU the one LDS pipe, not the
+    // SIMDs, is what this kernel fills (round 3).  Beyond the grid the shifts deliver 0 or an idle lane's (finite) value of
+    // row 0; either only ever meets a zero weight -- the first / last rows of A0 and A2 have no entries beyond the grid.
+    auto col5 = [&](const double own, double &m2v, double &m1v, double &p1v, double &p2v) {
+        m1v = hadi_lane_prev(own); m2v = hadi_lane_prev(m1v);
+        p1v = hadi_lane_next(own); p2v = hadi_lane_next(p1v);
+    };
     double *yrow = act ? Yl + j * PL : smem + Ls.off_dummy;  // (idle lanes store into a dummy row)
     double *crow = act ? Ul + j * PL : smem + Ls.off_dummy;  // column i - 1 of this row receives c'_i
     const double *b2p = last ? b2l : smem + Ls.off_zero;      // b2 lives on the last v-row only
@@ -3426,9 +3431,12 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
         const double b1l = b1val * cb1;
         // ---- row pass: lane <-> v-row, i = 1 .. m1 (same formulas as hadi_row_step) --------------------------------
         // column i = 0 (A0 and A1 rows are zero there; only A2 and the boundary act)
-        const double c0m2 = pm2[0], c0m1 = pm1[0], c00 = urow[0], c0p1 = pp1[0], c0p2 = pp2[0];
+        const double c00 = urow[0];
+        double c0m2, c0m1, c0p1, c0p2;
+        col5(c00, c0m2, c0m1, c0p1, c0p2);
         // first interior column, raw: rows j-2 .. j+2
-        double r_m2 = pm2[1], r_m1 = pm1[1], r_0 = urow[1], r_p1 = pp1[1], r_p2 = pp2[1];
+        double r_0 = urow[1], r_m2, r_m1, r_p1, r_p2;
+        col5(r_0, r_m2, r_m1, r_p1, r_p2);
         double yout_c0, x0;
         {
             const double a2c0 = a2l2 * c0m2 + a2l1 * c0m1 + a2m * c00 + a2u1 * c0p1 + a2u2 * c0p2;
@@ -3449,20 +3457,17 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
         double b2c = b2p[1];
         double corr_cur = thdt * (b2c * e_n - (a2u_cur + b2c * e_nm1));
         // raw values of column 2 (column m1 + 1 is the zero spare)
-        r_m2 = pm2[2]; r_m1 = pm1[2]; r_0 = urow[2]; r_p1 = pp1[2]; r_p2 = pp2[2];
+        r_0 = urow[2];
+        col5(r_0, r_m2, r_m1, r_p1, r_p2);
         // x_0 is known and moves to the right-hand side of node 1: with ys_0 = x_0 and c'_0 = 0 the general step does exactly
         // that (pivot im - il 0, right-hand side y - il x_0)
         double cp_prev = 0.0, ys_prev = x0;
-#pragma unroll 2
-        for (int i = 1; i <= m1; i++) {
-            // column i + 1 (fetched one step ahead), then the fetch of column i + 2
+        // One node of the sweep.  On entry r_* hold the raw column i + 1; `cB`, `cD` are node i's coefficients, `b2n` the b2
+        // entry of node i + 1.  The caller refills r_* with column i + 2 afterwards.
+        auto node = [&](int i, const double2 cB, const double2 cD, const double b2n) {
             const double u_next = r_0;
             const double t_next = wm * r_m1 + wz * r_0 + wp * r_p1;
             const double a2u_next = fma(a2u2, r_p2, fma(a2l2, r_m2, a2l1 * r_m1 + a2m * r_0 + a2u1 * r_p1));
-            const int inx = i + 2;  // (<= m1 + 2: a zero column)
-            r_m2 = pm2[inx]; r_m1 = pm1[inx]; r_0 = urow[inx]; r_p1 = pp1[inx]; r_p2 = pp2[inx];
-            const double2 cB = *reinterpret_cast<const double2 *>(coefl + 4 * i);      // Bm, Bp
-            const double2 cD = *reinterpret_cast<const double2 *>(coefl + 4 * i + 2);  // Dm, Dp
             const double lo = fma(v, cD.x, qd * cB.x);
             const double up = fma(v, cD.y, qd * cB.y);
             const double mn = -((lo + up) + half_rd);
@@ -3480,7 +3485,6 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
             const double inv = hadi_rcp(fma(-il, cp_prev, im));
             const double cp = iu * inv;
             const double ys = fma(-il, ys_prev, y) * inv;
-            const double b2n = b2p[i + 1];  // (entry m1 + 1 is zero)
             const double corr_next = thdt * (b2n * e_n - (a2u_next + b2n * e_nm1));
             yrow[i] = ys + corr_cur + cp * corr_next;  // g_i  (c'_{m1} = 0: the row ends there)
             crow[i - 1] = cp;
@@ -3488,6 +3492,46 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
             t_prev = t_cur; t_cur = t_next;
             a2u_cur = a2u_next; corr_cur = corr_next; b2c = b2n;
             cp_prev = cp; ys_prev = ys;
+        };
+        // Rounds of FOUR nodes: the own-row values of the columns i + 2 .. i + 5, the four nodes' coefficients and b2 entries
+        // are all read first -- 16 independent LDS reads behind ONE wait -- then the four dependent steps run without touching
+        // the LDS return path.  (Round 2 read five rows' values per node and waited for each node's coefficient and b2 reads:
+        // ~900 LDS instructions per time step, and at the six wavefronts per CU that the 26 KB of an instance allow, the CU's
+        // one LDS pipe was the busiest unit.)  Column indices reach i + 5 <= m1 + 2: the two zero spare columns of the pitch.
+        int i = 1;
+        for (; i + 3 <= m1; i += 4) {
+            double Rm2[4], Rm1[4], R0[4], Rp1[4], Rp2[4], b2q[4];
+            double2 cBq[4], cDq[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                R0[q] = urow[i + 2 + q];
+                cBq[q] = *reinterpret_cast<const double2 *>(coefl + 4 * (i + q));
+                cDq[q] = *reinterpret_cast<const double2 *>(coefl + 4 * (i + q) + 2);
+                b2q[q] = b2p[i + 1 + q];  // (entry m1 + 1 is zero)
+            }
+#if !defined(HADI_EMU)
+            asm volatile("" ::: "memory");  // (the reads stay in front of the four steps' stores)
+#endif
+            hadi_wave_rendezvous();  // (emulator: every lane has read its columns before anybody's c' lands in them)
+#pragma unroll
+            for (int q = 0; q < 4; q++) col5(R0[q], Rm2[q], Rm1[q], Rp1[q], Rp2[q]);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                node(i + q, cBq[q], cDq[q], b2q[q]);
+                r_m2 = Rm2[q]; r_m1 = Rm1[q]; r_0 = R0[q]; r_p1 = Rp1[q]; r_p2 = Rp2[q];
+                hadi_wave_rendezvous();  // (emulator: the lanes walk in lock step on the GPU)
+            }
+        }
+        for (; i <= m1; i++) {  // the last m1 mod 4 nodes, one at a time
+            const double n_0 = urow[i + 2];  // (column <= m1 + 2: a zero column)
+            double n_m2, n_m1, n_p1, n_p2;
+            col5(n_0, n_m2, n_m1, n_p1, n_p2);
+            const double2 cB = *reinterpret_cast<const double2 *>(coefl + 4 * i);      // Bm, Bp
+            const double2 cD = *reinterpret_cast<const double2 *>(coefl + 4 * i + 2);  // Dm, Dp
+            const double b2n = b2p[i + 1];
+            hadi_wave_rendezvous();
+            node(i, cB, cD, b2n);
+            r_m2 = n_m2; r_m1 = n_m1; r_0 = n_0; r_p1 = n_p1; r_p2 = n_p2;
             hadi_wave_rendezvous();  // (emulator: the lanes walk in lock step on the GPU)
         }
         // back substitution on the output itself: Y_i = g_i - c'_i Y_{i+1}
@@ -3498,6 +3542,9 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
                 double g[8], cq[8];
 #pragma unroll
                 for (int q = 0; q < 8; q++) { g[q] = yrow[i - q]; cq[q] = crow[i - q - 1]; }
+#if !defined(HADI_EMU)
+                asm volatile("" ::: "memory");
+#endif
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     Yn = fma(-cq[q], Yn, g[q]);
@@ -3519,13 +3566,19 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
             double ym1 = 0.0, ym2 = 0.0;
             int k = 0;
             for (; k + 8 <= nrows; k += 8) {
-                double yv[8];
+                double yv[8], tL[8], tL2[8], tQ[8];
 #pragma unroll
-                for (int q = 0; q < 8; q++) yv[q] = Yl[(k + q) * PL + col];
+                for (int q = 0; q < 8; q++) {  // (the round's table entries with its column values: 32 reads, one wait)
+                    const double *t = ptab + (k + q) * 5;
+                    yv[q] = Yl[(k + q) * PL + col];
+                    tL[q] = t[PB_L]; tL2[q] = t[PB_L2]; tQ[q] = t[PB_Q];
+                }
+#if !defined(HADI_EMU)
+                asm volatile("" ::: "memory");
+#endif
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
-                    const double *t = ptab + (k + q) * 5;
-                    const double yk = (yv[q] - t[PB_L] * ym1 - t[PB_L2] * ym2) * t[PB_Q];
+                    const double yk = (yv[q] - tL[q] * ym1 - tL2[q] * ym2) * tQ[q];
                     Yl[(k + q) * PL + col] = yk;
                     ym2 = ym1;
                     ym1 = yk;
@@ -3541,13 +3594,19 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
             double xp1 = 0.0, xp2 = 0.0;
             k = nrows - 1;
             for (; k >= 7; k -= 8) {
-                double yv[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) yv[q] = Yl[(k - q) * PL + col];
+                double yv[8], tC[8], tC2[8];
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     const double *t = ptab + (k - q) * 5;
-                    const double xk = yv[q] - t[PB_C] * xp1 - t[PB_C2] * xp2;
+                    yv[q] = Yl[(k - q) * PL + col];
+                    tC[q] = t[PB_C]; tC2[q] = t[PB_C2];
+                }
+#if !defined(HADI_EMU)
+                asm volatile("" ::: "memory");
+#endif
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const double xk = yv[q] - tC[q] * xp1 - tC2[q] * xp2;
                     xp2 = xp1;
                     xp1 = xk;
                     Ul[(k - q) * PL + col] = xk;
