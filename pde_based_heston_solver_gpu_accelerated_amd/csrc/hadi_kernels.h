@@ -3430,6 +3430,16 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
         const double cb1 = dt * e_nm1 + thdt * (e_n - e_nm1);
         const double b1l = b1val * cb1;
         // ---- row pass: lane <-> v-row, i = 1 .. m1 (same formulas as hadi_row_step) --------------------------------
+        // Only the lanes that own a v-row run the sweeps: the LDS moves 16 or 8 bytes per ACTIVE lane, and with nrows of 64 lanes
+        // busy that is less than half of what the idle lanes' dummy walk used to drag through the CU's one LDS pipe.  (The wave
+        // shifts deliver 0 from a switched-off lane: the row beyond the last one only ever meets a zero weight.  The emulator's
+        // lane threads all have to take part in its collective shuffles, so there every lane still runs.)
+#if defined(HADI_EMU)
+        const bool rowrun = true;
+#else
+        const bool rowrun = act;
+#endif
+        if (rowrun) {
         // column i = 0 (A0 and A1 rows are zero there; only A2 and the boundary act)
         const double c00 = urow[0];
         double c0m2, c0m1, c0p1, c0p2;
@@ -3557,6 +3567,7 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
             }
             yrow[0] = yout_c0;
         }
+        }  // (rowrun)
         __syncthreads();
         // ---- column pass: lane <-> s-column, sequential pentadiagonal sweeps (hes_a2_shuffled_kernels.hpp:243-299) ----
         // (measured and left out, 50x25 x3000: fetching a node's coefficients one iteration ahead 2.64 -> 2.72 ms; the column

@@ -17,6 +17,6 @@ def run(n, N, variant=H.EU):
         best = min(best, time.perf_counter() - t)
     return best * 1e3, float(U[0, 500].item())
 cases = ((1, 100), (60, 20), (500, 20), (500, 100), (1024, 50), (3000, 50))
-if os.environ.get("SIZES"): cases = tuple((int(x), 40) for x in os.environ["SIZES"].split(","))
+if os.environ.get("SIZES"): cases = tuple((int(x), int(os.environ.get("STEPS", "40"))) for x in os.environ["SIZES"].split(","))
 for n, N in cases:
     print(n, N, "%.3f ms" % run(n, N)[0], run(n, N)[1])
