@@ -185,6 +185,9 @@ int hadi_get_timing(const hadi_ctx *ctx, hadi_timing *out);
  *                 strips keep 16 rows, e.g. 512 instances of 256x128), 0 never, 1 wherever the strips run
  *   "col_groups"  column pass: blocks per instance (0 = automatic)
  *   "small_waves" small-grid kernel: wavefronts per instance, 4 or 8 (0 = automatic)
+ *   "small_pairs" LDS-resident European / dividend sweeps: two instances per wavefront (hadi_small_seq2_kernel; grids of at most
+ *                 32 v-rows): -1 automatic (default: batches of more than 2 and at most 4.5 instances per CU, where it is 14 - 20 %
+ *                 faster), 0 never, 1 whenever possible
  *   "sub_batch"   batches of several rounds of one instance per CU on grids whose round exceeds the 256 MB memory-side
  *                 cache run sub-batch by sub-batch through the time loop (default 1; instances are independent)
  *   "streams"     1 (default) or 2: with 2 the sub-batches of a Douglas sweep run side by side on two streams (a batch that is

@@ -51,6 +51,7 @@ struct Ctx {
     int use_amp = 1;    // American sweeps without the lambda_bar array when the payoff depends on s only
     int device_vgrid = 1;  // compute_base_prices / compute_jacobian: v-grids rebuilt per instance on the device
     int sub_batch = 1;     // large batches run sub-batch by sub-batch (run_sweep)
+    int small_pairs = -1;  // small-grid sequential kernel with two instances per wavefront: -1 by batch size, 0 never, 1 always
     int streams = 1;       // sub-batches run on this many streams side by side (1 or 2; hadi_set_tuning "streams")
     hipStream_t stream2 = nullptr;                 // the second stream of a two-stream sweep
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
@@ -230,6 +231,8 @@ hipError_t raise_all_lds_limits() {
     if ((e = raise_lds_limit(hadi_pass_a_pairs<2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_team_kernel<8>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_team_kernel<4>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_small_seq2_kernel<1>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_small_seq2_kernel<2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_seq_kernel<1>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_seq_kernel<2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_small_kernel<1, 4, false>)) != hipSuccess) return e;
@@ -646,10 +649,19 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     // "small_seq" = 1 forces it, 0 forbids it, -1 (default) picks by batch size.
     const bool seq = takes_small_path && !american && (c->small_seq > 0 || (c->small_seq < 0 && d.n > c->cu_count));
     const size_t smem_seq = (size_t)hadi_small_seq_layout(L.m1, L.nrows).total * sizeof(double);
+    // ... and two instances per wavefront for batches of more than 2 and at most 4.5 instances per CU: a wavefront then retires
+    // two instances' steps in 1.15x the time of one, but the launch has half the wavefronts -- below 2 per CU the instances are
+    // better spread over the CUs, at the 6 per CU that the LDS holds either way the halved instruction count and the halved
+    // latency hiding cancel (50x25 x 200 steps, ms: 768 instances 3.20 -> 2.76, 1024: 3.49 -> 2.78, 1536: 3.53 -> 3.83, 3072:
+    // 6.68 -> 6.98).  "small_pairs" = 1 forces it, 0 forbids it, -1 (default) picks by batch size.  Needs nrows <= 32.
+    const bool seq2 = seq && L.nrows <= 32 && 2 * smem_seq <= (size_t)160 * 1024 &&
+                      (c->small_pairs > 0 || (c->small_pairs < 0 && d.n > 2 * c->cu_count && 2 * d.n <= 9 * c->cu_count));
     if (takes_small_path) {
         {
             char buf[192];
-            if (seq)
+            if (seq2)
+                std::snprintf(buf, sizeof buf, "hadi_small_seq2_kernel<%d>: whole time loop in one launch, two instances per wavefront, lines solved sequentially in LDS (2 x %zu B)", L.B, smem_seq);
+            else if (seq)
                 std::snprintf(buf, sizeof buf, "hadi_small_seq_kernel<%d>: whole time loop in one launch, one wavefront per instance, lines solved sequentially in LDS (%zu B)", L.B, smem_seq);
             else
                 std::snprintf(buf, sizeof buf, "hadi_small_kernel<%d,%d,%s>: whole time loop in one launch, instance resident in LDS (%zu B)", L.B,
@@ -679,7 +691,10 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         // dependent per-step phases; more waves share the rows of the row pass)
         // (measured, 50x25 grid: 1 instance x 100 steps 1.27 -> 1.04 ms with 8; 3000 instances x 50 steps 4.19 -> 4.58 ms)
         const int sw = c->tune.small_waves ? c->tune.small_waves : (d.n <= 2 * c->cu_count ? 8 : 4);
-        if (seq) {
+        if (seq2) {
+            if (L.B == 1) hipLaunchKernelGGL((hadi_small_seq2_kernel<1>), dim3((d.n + 1) / 2), dim3(64), 2 * smem_seq, s, a, sm);
+            else hipLaunchKernelGGL((hadi_small_seq2_kernel<2>), dim3((d.n + 1) / 2), dim3(64), 2 * smem_seq, s, a, sm);
+        } else if (seq) {
             if (L.B == 1) hipLaunchKernelGGL((hadi_small_seq_kernel<1>), dim3(d.n), dim3(64), smem_seq, s, a, sm);
             else hipLaunchKernelGGL((hadi_small_seq_kernel<2>), dim3(d.n), dim3(64), smem_seq, s, a, sm);
         } else if (sw == 8) {
@@ -1311,6 +1326,7 @@ int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value) {
     else if (!std::strcmp(key, "american_p")) c->use_amp = value ? 1 : 0;
     else if (!std::strcmp(key, "device_vgrid")) c->device_vgrid = value ? 1 : 0;
     else if (!std::strcmp(key, "sub_batch")) c->sub_batch = value ? 1 : 0;
+    else if (!std::strcmp(key, "small_pairs")) c->small_pairs = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "streams")) c->streams = value == 2 ? 2 : 1;
     else if (!std::strcmp(key, "strip")) c->tune.strip = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "debug_fault")) c->debug_fault = value;
@@ -1344,6 +1360,7 @@ int hadi_get_tuning(const hadi_ctx *ctx, const char *key, int *value) {
     else if (!std::strcmp(key, "american_p")) *value = c->use_amp;
     else if (!std::strcmp(key, "device_vgrid")) *value = c->device_vgrid;
     else if (!std::strcmp(key, "sub_batch")) *value = c->sub_batch;
+    else if (!std::strcmp(key, "small_pairs")) *value = c->small_pairs;
     else if (!std::strcmp(key, "streams")) *value = c->streams;
     else if (!std::strcmp(key, "strip")) *value = c->tune.strip;
     else if (!std::strcmp(key, "debug_fault")) *value = c->debug_fault;

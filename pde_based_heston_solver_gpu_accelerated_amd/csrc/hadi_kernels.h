@@ -3640,6 +3640,338 @@ __global__ void __launch_bounds__(64) hadi_small_seq_kernel(HadiSweepArgs a, Had
 }
 
 // ------------------------------------------------------------------------------------------------
+// hadi_small_seq_kernel with TWO instances per wavefront (round 3).  The row sweep above keeps nrows of the 64 lanes busy
+// -- 26 for the reference's 50x25 grid -- and is nine tenths of the kernel's instructions: here lanes 0..31 walk the v-rows
+// of one instance and lanes 32..63 those of a second one through the SAME instruction stream (per-lane LDS base pointers
+// and instance scalars; the wave shifts that fetch the v-neighbours meet zero weights across the boundary between the two
+// instances exactly as they do beyond a grid's own first and last row).  The column sweeps (lane <-> s-column) run once
+// per instance.  LDS: two instances' arrays per wavefront (52 KB for 50x25: three wavefronts = six instances per CU, as
+// before), but a wavefront now retires two instances' time steps in little more than the time of one.  Instances with
+// different numbers of time steps (multi-maturity batches, dispatched longest first) simply stop at their own N.
+// Needs nrows <= 32.  Same arithmetic, operation by operation, as hadi_small_seq_kernel: the results are bit-identical.
+template <int B>
+__global__ void __launch_bounds__(64) hadi_small_seq2_kernel(HadiSweepArgs a, HadiSmallArgs sm) {
+    HADI_DYN_SMEM(double, smem);
+    const int lane = threadIdx.x;
+    const int half = lane >> 5, jl = lane & 31;
+    const int nrows = a.L.nrows, rowp = a.L.rowp, m1 = a.L.m1;
+    const HadiSmallSeqLayout Ls = hadi_small_seq_layout(m1, nrows);
+    const int PL = Ls.pitch;
+    // the two instances of this wavefront (the second slot of the last block may be empty)
+    const int slot0 = 2 * (int)blockIdx.x, slot1 = slot0 + 1;
+    if (slot0 >= a.n_inst) return;
+    const bool has1 = slot1 < a.n_inst;
+    const int inst0 = sm.order ? sm.order[slot0] : slot0;
+    const int inst1 = has1 ? (sm.order ? sm.order[slot1] : slot1) : inst0;
+    const int inst = half ? inst1 : inst0;             // this lane's instance
+    const HadiInstPar ip = a.ipar[inst];               // (per lane: two different structs in the wavefront)
+    const HadiInstPar ip0 = a.ipar[inst0], ip1 = a.ipar[inst1];
+    const int N0 = ip0.N < sm.Nmax ? ip0.N : sm.Nmax;
+    const int N1 = has1 ? (ip1.N < sm.Nmax ? ip1.N : sm.Nmax) : 0;
+    const int Nw = N0 > N1 ? N0 : N1;                  // (wave-uniform)
+    const int Nl = half ? N1 : N0;                     // this lane's number of time steps
+    double *const base0 = smem, *const base1 = smem + Ls.total;
+    double *const bl = half ? base1 : base0;           // this lane's instance in LDS
+    double *Ul = bl;
+    double *Yl = bl + Ls.off_y;
+    double *coefl = bl + Ls.off_coef;                  // [i][4]: Bm, Bp, Dm, Dp of node i
+    double *b2l = bl + Ls.off_b2;
+
+    for (int e = lane; e < 2 * Ls.total; e += 64) smem[e] = 0.0;
+    __syncthreads();
+    for (int h = 0; h < (has1 ? 2 : 1); h++) {         // (uniform loops: all 64 lanes copy one instance, then the other)
+        const int ih = h ? inst1 : inst0;
+        double *bh = h ? base1 : base0;
+        const double *__restrict__ Ug = a.U + (size_t)ih * a.L.inst_stride;
+        for (int e = lane; e < nrows * (m1 + 1); e += 64) {
+            const int j = e / (m1 + 1), i = e - j * (m1 + 1);
+            bh[j * PL + i] = Ug[(size_t)j * rowp + hadi_pos(B, 1, i)];
+        }
+        const double *__restrict__ sc = a.scoef + (size_t)ih * 4 * 64 * B;
+        for (int e = lane; e < 4 * (m1 + 1); e += 64) {
+            const int i = e >> 2, k = e & 3;
+            bh[Ls.off_coef + e] = (i >= 1) ? sc[k * 64 * B + hadi_pos(B, 1, i)] : 0.0;
+        }
+        const double *__restrict__ b2g = a.b2row + (size_t)ih * rowp;
+        for (int i = lane; i <= m1; i += 64) bh[Ls.off_b2 + i] = b2g[hadi_pos(B, 1, i)];
+        const double *__restrict__ pg = a.pb + (size_t)ih * a.L.nrows_pad * HADI_PBW;
+        for (int e = lane; e < nrows * 5; e += 64) bh[Ls.off_ptab + e] = pg[(e / 5) * HADI_PBW + e % 5];
+    }
+    // this lane's v-row of its instance: the table entry stays in registers for the whole time loop
+    const int j = jl;
+    const bool act = j < nrows && (half == 0 || has1);
+    const bool last = (j == nrows - 1);
+    double v = 0.0, wm = 0.0, wz = 0.0, wp = 0.0, a2l2 = 0.0, a2l1 = 0.0, a2m = 0.0, a2u1 = 0.0, a2u2 = 0.0, b1val = 0.0;
+    int b1col = -1;
+    bool b1_at0 = false;
+    if (act) {
+        const double *__restrict__ rc = a.rowc + ((size_t)inst * nrows + j) * HADI_RC;
+        v = rc[RC_V]; wm = rc[RC_WM]; wz = rc[RC_WZ]; wp = rc[RC_WP];
+        a2l2 = rc[RC_L2]; a2l1 = rc[RC_L1]; a2m = rc[RC_M]; a2u1 = rc[RC_U1]; a2u2 = rc[RC_U2];
+        b1val = rc[RC_B1VAL];
+        const int b1raw = (int)rc[RC_B1COL];
+        b1_at0 = b1raw == 0 || b1raw >= HADI_B1_BOTH;
+        b1col = b1raw >= HADI_B1_BOTH ? b1raw - HADI_B1_BOTH : b1raw;
+    }
+    const double dt = ip.dt, thdt = ip.thdt, qd = ip.q, half_rd = ip.half_rd;
+    const double inv0 = 1.0 / (1.0 + ip.thdt * ip.hr0);
+    const double *urow = Ul + (act ? j : 0) * PL;  // (idle lanes walk row 0 and store nothing)
+    auto col5 = [&](const double own, double &m2v, double &m1v, double &p1v, double &p2v) {
+        m1v = hadi_lane_prev(own); m2v = hadi_lane_prev(m1v);
+        p1v = hadi_lane_next(own); p2v = hadi_lane_next(p1v);
+    };
+    double *const yrow_real = act ? Yl + j * PL : bl + Ls.off_dummy;
+    double *const crow_real = act ? Ul + j * PL : bl + Ls.off_dummy;
+    const double *b2p = last ? b2l : bl + Ls.off_zero;      // b2 lives on the last v-row only
+    __syncthreads();
+
+    for (int n = 1; n <= Nw; n++) {
+        // ---- discrete dividends at the start of the step, instance by instance (device_solver.hpp:448-504) ----
+        for (int h = 0; h < (has1 ? 2 : 1); h++) {
+            const int ih = h ? inst1 : inst0, Nh = h ? N1 : N0;
+            const int dv = (sm.div_flag && n <= Nh) ? sm.div_flag[(size_t)ih * sm.flag_stride + n - 1] : -1;
+            if (dv >= 0) {  // (wave-uniform)
+                double *Uh = h ? base1 : base0, *Yh = Uh + Ls.off_y;
+                const double *__restrict__ vs = sm.vec_s + (size_t)ih * (m1 + 1);
+                const int put_h = h ? ip1.put : ip0.put;
+                for (int e = lane; e < nrows * PL; e += 64) Yh[e] = Uh[e];  // U_temp
+                __syncthreads();
+                const double amount = sm.div_amounts[dv], pct = sm.div_pcts[dv];
+                for (int e = lane; e < nrows * (m1 + 1); e += 64) {
+                    const int jj = e / (m1 + 1), i = e - jj * (m1 + 1);
+                    const double *src = Yh + jj * PL;
+                    const double new_s = vs[i] * (1.0 - pct) - amount;
+                    double out = put_h ? src[0] : 0.0;
+                    if (new_s > 0) {
+                        int lo = 0, hi = m1 + 1;  // first k with s[k] > new_s (0 if none)
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if (vs[mid] > new_s) hi = mid;
+                            else lo = mid + 1;
+                        }
+                        const int idx = (lo <= m1) ? lo : 0;
+                        if (idx > 0) {
+                            const double s_low = vs[idx - 1], s_high = vs[idx];
+                            const double weight = (new_s - s_low) / (s_high - s_low);
+                            out = (1.0 - weight) * src[idx - 1] + weight * src[idx];
+                        } else {
+                            out = src[0];
+                        }
+                    }
+                    Uh[jj * PL + i] = out;
+                }
+                __syncthreads();
+            }
+        }
+        const double e_nm1 = exp(ip.bc_rate * ip.dt * (n - 1));  // device_solver.hpp:238
+        const double e_n = exp(ip.bc_rate * ip.dt * n);          // device_solver.hpp:246
+        const double cb1 = dt * e_nm1 + thdt * (e_n - e_nm1);
+        const double b1l = b1val * cb1;
+        // a lane whose instance has finished its own N steps keeps walking (the wave shifts are collective) but stores into the
+        // dummy row; on the GPU it is switched off altogether
+        const bool live = act && n <= Nl;
+        double *const yrow = live ? yrow_real : bl + Ls.off_dummy;
+        double *const crow = live ? crow_real : bl + Ls.off_dummy;
+#if defined(HADI_EMU)
+        const bool rowrun = true;
+#else
+        const bool rowrun = live;
+#endif
+        if (rowrun) {
+        // ---- row pass: lane <-> v-row of its instance (hadi_small_seq_kernel, operation by operation) ----
+        const double c00 = urow[0];
+        double c0m2, c0m1, c0p1, c0p2;
+        col5(c00, c0m2, c0m1, c0p1, c0p2);
+        double r_0 = urow[1], r_m2, r_m1, r_p1, r_p2;
+        col5(r_0, r_m2, r_m1, r_p1, r_p2);
+        double yout_c0, x0;
+        {
+            const double a2c0 = a2l2 * c0m2 + a2l1 * c0m1 + a2m * c00 + a2u1 * c0p1 + a2u2 * c0p2;
+            const double b1c0 = b1_at0 ? b1val : 0.0;
+            const double b2c0 = b2p[0];
+            const double a1c0 = -ip.hr0 * c00;
+            double y0c0 = c00 + dt * (a2c0 + a1c0 + (b1c0 + b2c0) * e_nm1);
+            y0c0 = y0c0 + thdt * (b1c0 * e_n - (a1c0 + b1c0 * e_nm1));
+            const double c2c0 = thdt * (b2c0 * e_n - (a2c0 + b2c0 * e_nm1));
+            x0 = y0c0 * inv0;
+            yout_c0 = x0 + c2c0;
+        }
+        hadi_wave_rendezvous();
+        double u_prev = c00, u_cur = r_0;
+        double t_prev = wm * c0m1 + wz * c00 + wp * c0p1;
+        double t_cur = wm * r_m1 + wz * r_0 + wp * r_p1;
+        double a2u_cur = fma(a2u2, r_p2, fma(a2l2, r_m2, a2l1 * r_m1 + a2m * r_0 + a2u1 * r_p1));
+        double b2c = b2p[1];
+        double corr_cur = thdt * (b2c * e_n - (a2u_cur + b2c * e_nm1));
+        r_0 = urow[2];
+        col5(r_0, r_m2, r_m1, r_p1, r_p2);
+        double cp_prev = 0.0, ys_prev = x0;
+        auto node = [&](int i, const double2 cB, const double2 cD, const double b2n) {
+            const double u_next = r_0;
+            const double t_next = wm * r_m1 + wz * r_0 + wp * r_p1;
+            const double a2u_next = fma(a2u2, r_p2, fma(a2l2, r_m2, a2l1 * r_m1 + a2m * r_0 + a2u1 * r_p1));
+            const double lo = fma(v, cD.x, qd * cB.x);
+            const double up = fma(v, cD.y, qd * cB.y);
+            const double mn = -((lo + up) + half_rd);
+            const double A1U = lo * u_prev + mn * u_cur + up * u_next;
+            const double A0U = cB.x * t_prev - (cB.x + cB.y) * t_cur + cB.y * t_next;
+            double S = A0U + A1U + a2u_cur;
+            S += b2c * e_nm1;
+            double y = fma(dt, S, u_cur);
+            y = fma(-thdt, A1U, y);
+            y += (i == b1col) ? b1l : 0.0;
+            const double il = -thdt * lo;
+            const double im = 1.0 - thdt * mn;
+            const double iu = -thdt * up;
+            const double inv = hadi_rcp(fma(-il, cp_prev, im));
+            const double cp = iu * inv;
+            const double ys = fma(-il, ys_prev, y) * inv;
+            const double corr_next = thdt * (b2n * e_n - (a2u_next + b2n * e_nm1));
+            yrow[i] = ys + corr_cur + cp * corr_next;
+            crow[i - 1] = cp;
+            u_prev = u_cur; u_cur = u_next;
+            t_prev = t_cur; t_cur = t_next;
+            a2u_cur = a2u_next; corr_cur = corr_next; b2c = b2n;
+            cp_prev = cp; ys_prev = ys;
+        };
+        int i = 1;
+        for (; i + 3 <= m1; i += 4) {
+            double Rm2[4], Rm1[4], R0[4], Rp1[4], Rp2[4], b2q[4];
+            double2 cBq[4], cDq[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                R0[q] = urow[i + 2 + q];
+                cBq[q] = *reinterpret_cast<const double2 *>(coefl + 4 * (i + q));
+                cDq[q] = *reinterpret_cast<const double2 *>(coefl + 4 * (i + q) + 2);
+                b2q[q] = b2p[i + 1 + q];
+            }
+#if !defined(HADI_EMU)
+            asm volatile("" ::: "memory");
+#endif
+            hadi_wave_rendezvous();
+#pragma unroll
+            for (int q = 0; q < 4; q++) col5(R0[q], Rm2[q], Rm1[q], Rp1[q], Rp2[q]);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                node(i + q, cBq[q], cDq[q], b2q[q]);
+                r_m2 = Rm2[q]; r_m1 = Rm1[q]; r_0 = R0[q]; r_p1 = Rp1[q]; r_p2 = Rp2[q];
+                hadi_wave_rendezvous();
+            }
+        }
+        for (; i <= m1; i++) {
+            const double n_0 = urow[i + 2];
+            double n_m2, n_m1, n_p1, n_p2;
+            col5(n_0, n_m2, n_m1, n_p1, n_p2);
+            const double2 cB = *reinterpret_cast<const double2 *>(coefl + 4 * i);
+            const double2 cD = *reinterpret_cast<const double2 *>(coefl + 4 * i + 2);
+            const double b2n = b2p[i + 1];
+            hadi_wave_rendezvous();
+            node(i, cB, cD, b2n);
+            r_m2 = n_m2; r_m1 = n_m1; r_0 = n_0; r_p1 = n_p1; r_p2 = n_p2;
+            hadi_wave_rendezvous();
+        }
+        {   // back substitution on the output itself: Y_i = g_i - c'_i Y_{i+1}
+            double Yn = yrow[m1];
+            int ib = m1 - 1;
+            for (; ib >= 8; ib -= 8) {
+                double g[8], cq[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) { g[q] = yrow[ib - q]; cq[q] = crow[ib - q - 1]; }
+#if !defined(HADI_EMU)
+                asm volatile("" ::: "memory");
+#endif
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    Yn = fma(-cq[q], Yn, g[q]);
+                    yrow[ib - q] = Yn;
+                }
+            }
+            for (; ib >= 1; ib--) {
+                Yn = fma(-crow[ib - 1], Yn, yrow[ib]);
+                yrow[ib] = Yn;
+            }
+            yrow[0] = yout_c0;
+        }
+        }  // (rowrun)
+        __syncthreads();
+        // ---- column pass, instance by instance: lane <-> s-column (hes_a2_shuffled_kernels.hpp:243-299) ----
+        for (int h = 0; h < (has1 ? 2 : 1); h++) {
+            if (n > (h ? N1 : N0)) continue;  // (wave-uniform)
+            double *Uh = h ? base1 : base0, *Yh = Uh + Ls.off_y;
+            const double *ptab = Uh + Ls.off_ptab;   // [k][5]: L, L2, Q, C, C2
+            for (int col = lane; col <= m1; col += 64) {
+                double ym1 = 0.0, ym2 = 0.0;
+                int k = 0;
+                for (; k + 8 <= nrows; k += 8) {
+                    double yv[8], tL[8], tL2[8], tQ[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const double *t = ptab + (k + q) * 5;
+                        yv[q] = Yh[(k + q) * PL + col];
+                        tL[q] = t[PB_L]; tL2[q] = t[PB_L2]; tQ[q] = t[PB_Q];
+                    }
+#if !defined(HADI_EMU)
+                    asm volatile("" ::: "memory");
+#endif
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const double yk = (yv[q] - tL[q] * ym1 - tL2[q] * ym2) * tQ[q];
+                        Yh[(k + q) * PL + col] = yk;
+                        ym2 = ym1;
+                        ym1 = yk;
+                    }
+                }
+                for (; k < nrows; k++) {
+                    const double *t = ptab + k * 5;
+                    const double yk = (Yh[k * PL + col] - t[PB_L] * ym1 - t[PB_L2] * ym2) * t[PB_Q];
+                    Yh[k * PL + col] = yk;
+                    ym2 = ym1;
+                    ym1 = yk;
+                }
+                double xp1 = 0.0, xp2 = 0.0;
+                k = nrows - 1;
+                for (; k >= 7; k -= 8) {
+                    double yv[8], tC[8], tC2[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const double *t = ptab + (k - q) * 5;
+                        yv[q] = Yh[(k - q) * PL + col];
+                        tC[q] = t[PB_C]; tC2[q] = t[PB_C2];
+                    }
+#if !defined(HADI_EMU)
+                    asm volatile("" ::: "memory");
+#endif
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const double xk = yv[q] - tC[q] * xp1 - tC2[q] * xp2;
+                        xp2 = xp1;
+                        xp1 = xk;
+                        Uh[(k - q) * PL + col] = xk;
+                    }
+                }
+                for (; k >= 0; k--) {
+                    const double *t = ptab + k * 5;
+                    const double xk = Yh[k * PL + col] - t[PB_C] * xp1 - t[PB_C2] * xp2;
+                    xp2 = xp1;
+                    xp1 = xk;
+                    Uh[k * PL + col] = xk;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int h = 0; h < (has1 ? 2 : 1); h++) {
+        const int ih = h ? inst1 : inst0;
+        const double *bh = h ? base1 : base0;
+        double *__restrict__ Ug = a.U + (size_t)ih * a.L.inst_stride;
+        for (int e = lane; e < nrows * (m1 + 1); e += 64) {
+            const int jj = e / (m1 + 1), i = e - jj * (m1 + 1);
+            Ug[(size_t)jj * rowp + hadi_pos(B, 1, i)] = bh[jj * PL + i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Grids beyond the streaming kernels' shapes -- the reference bounds a grid by its total size only
 // (src/perfomance_test.cpp:62).  Two sequential passes in the reference's own mapping (hes_a1_kernels.hpp:139-161: one
 // thread per v-row; hes_a2_shuffled_kernels.hpp:243-299: one thread per s-column), correct for ANY shape, far from the

@@ -249,7 +249,11 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
         HadiSmallArgs sm;
         sm.div_flag = dividend ? flags.data() : nullptr; sm.flag_stride = 0; sm.div_amounts = damounts; sm.div_pcts = dpcts;
         sm.vec_s = vec_s; sm.Nmax = N; sm.order = nullptr;
-        if (use_small == 3 && !american) {  // one wavefront per instance, sequential line solves (European / dividends)
+        if (use_small == 5 && !american && pl.L.nrows <= 32) {  // ... two instances per wavefront
+            const size_t smem_seq = (size_t)hadi_small_seq_layout(pl.L.m1, pl.L.nrows).total * sizeof(double);
+            if (pl.L.B == 1) emu::launch((n_inst + 1) / 2, 64, [&]() { hadi_small_seq2_kernel<1>(a, sm); }, 2 * smem_seq);
+            else emu::launch((n_inst + 1) / 2, 64, [&]() { hadi_small_seq2_kernel<2>(a, sm); }, 2 * smem_seq);
+        } else if (use_small == 3 && !american) {  // one wavefront per instance, sequential line solves (European / dividends)
             const size_t smem_seq = (size_t)hadi_small_seq_layout(pl.L.m1, pl.L.nrows).total * sizeof(double);
             if (pl.L.B == 1) emu::launch(n_inst, 64, [&]() { hadi_small_seq_kernel<1>(a, sm); }, smem_seq);
             else emu::launch(n_inst, 64, [&]() { hadi_small_seq_kernel<2>(a, sm); }, smem_seq);

@@ -202,6 +202,12 @@ def test_small_grid_sequential_kernel(emu):
     _run(emu, 20, 25, 4, [100.0], O.EU, 8, r_f=0.02, small=3)
     _run(emu, 50, 25, 5, [100.0], O.EU, 8, small=3, put=True)
     _run(emu, 40, 12, 24, [105.0], O.DIV, 8, small=3, put=True)
+    # two instances per wavefront (hadi_small_seq2_kernel): lanes 0..31 / 32..63 walk the v-rows of two instances through one
+    # instruction stream; an odd batch (the last wavefront carries one instance), dividends, put data, r_f != 0, 32 v-rows
+    _run(emu, 50, 25, 6, [100.0, 91.0, 104.0], O.EU, 8, small=5)
+    _run(emu, 50, 25, 24, [100.0, 97.0], O.DIV, 8, r_f=0.01, small=5)
+    _run(emu, 100, 31, 3, [96.0, 101.0, 99.0, 103.0], O.EU, 8, r_f=0.01, small=5)
+    _run(emu, 40, 12, 24, [105.0, 95.0], O.DIV, 8, small=5, put=True)
 
 
 def test_plan_invariants_over_shapes_and_batch_sizes(emu):

@@ -849,6 +849,40 @@ def test_small_grid_sequential_kernel_vs_oracle(solver, put, variant, name, m1, 
     _assert_field(U, Uo)
 
 
+@pytest.mark.parametrize("put", [False, True])
+@pytest.mark.parametrize("variant,name", [(H.EU, "EU"), (H.DIV, "DIV")])
+@pytest.mark.parametrize("m1,m2,N,n", [(50, 25, 24, 5), (25, 20, 20, 3), (100, 25, 6, 2), (128, 26, 5, 7), (64, 31, 7, 4), (20, 25, 9, 1), (65, 8, 24, 6)])
+def test_small_grid_two_instances_per_wavefront_vs_oracle(solver, put, variant, name, m1, m2, N, n):
+    """hadi_small_seq2_kernel: lanes 0..31 / 32..63 walk the v-rows of two instances through one instruction stream (chosen
+    by itself for batches of more than two instances per CU; forced here): even and odd batches (the last wavefront carries
+    one instance), a single instance, one and two nodes per packed lane, dividends, put data, r_f != 0 -- full field against
+    the oracle, and BIT-identical to the one-instance-per-wavefront kernel (same arithmetic, operation by operation)."""
+    strikes = Cm.strikes_for(n)
+    grids, U0 = _batch(m1, m2, strikes)
+    if put:
+        U0 = grids.put_payoff(strikes)
+    div = H.Dividends(*Cm.DIVS) if variant == H.DIV else None
+    out = {}
+    solver.set_tuning("small_seq", 1)
+    try:
+        for pairs in (1, 0):
+            solver.set_tuning("small_pairs", pairs)
+            U = U0.copy()
+            solver.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U,
+                                   variant=variant, dividends=div, option_type=H.PUT if put else H.CALL, strikes=strikes if put else None)
+            assert ("hadi_small_seq2_kernel" if pairs else "hadi_small_seq_kernel") in solver.describe_last_sweep()
+            out[pairs] = U
+    finally:
+        solver.set_tuning("small_seq", -1)
+        solver.set_tuning("small_pairs", -1)
+    assert np.array_equal(out[1], out[0])
+    p = O.make_params(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA,
+                      O.DIV if variant == H.DIV else O.EU, Cm.DIVS if variant == H.DIV else None,
+                      option_type=O.PUT if put else O.CALL, strikes=np.array(strikes) if put else None)
+    Uo, _, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0)
+    _assert_field(out[1], Uo)
+
+
 @pytest.mark.parametrize("seq", [1, 0])
 def test_small_grid_kernel_on_a_batch_larger_than_two_per_cu(solver, seq):
     """A batch of several instances per CU with per-instance maturities (dispatch order: longest time loops first) on both
@@ -866,7 +900,8 @@ def test_small_grid_kernel_on_a_batch_larger_than_two_per_cu(solver, seq):
                                per_instance=per)
     finally:
         solver.set_tuning("small_seq", -1)
-    assert ("hadi_small_seq_kernel<1>" if seq else "hadi_small_kernel<1,4,EU>") in solver.describe_last_sweep()
+    # (more than two instances per CU: the sequential kernel runs two instances per wavefront, each stopping at its own N)
+    assert ("hadi_small_seq2_kernel<1>" if seq else "hadi_small_kernel<1,4,EU>") in solver.describe_last_sweep()
     for N in sorted(set(Ns)):
         rows = np.array([k for k in range(n) if Ns[k] == N])
         p = O.make_params(m1, m2, N, 0.5 / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA)
@@ -877,7 +912,11 @@ def test_small_grid_kernel_on_a_batch_larger_than_two_per_cu(solver, seq):
 def test_describe_last_sweep_names_the_kernels(solver):
     _hadi_solve(solver, 50, 25, 4, [100.0], H.EU)
     assert "hadi_small_kernel<1,8,EU>" in solver.describe_last_sweep()
-    _hadi_solve(solver, 50, 25, 2, Cm.strikes_for(1100), H.EU)   # more instances than CUs: one wavefront per instance
+    _hadi_solve(solver, 50, 25, 2, Cm.strikes_for(400), H.EU)    # more instances than CUs: one wavefront per instance
+    assert "hadi_small_seq_kernel<1>" in solver.describe_last_sweep()
+    _hadi_solve(solver, 50, 25, 2, Cm.strikes_for(1100), H.EU)   # 2 .. 4.5 per CU: two instances per wavefront
+    assert "hadi_small_seq2_kernel<1>" in solver.describe_last_sweep()
+    _hadi_solve(solver, 50, 25, 2, Cm.strikes_for(1600), H.EU)   # the LDS is full either way: one wavefront per instance
     assert "hadi_small_seq_kernel<1>" in solver.describe_last_sweep()
     _hadi_solve(solver, 50, 25, 2, Cm.strikes_for(1100), H.AM)
     assert "hadi_small_kernel<1,4,AM>" in solver.describe_last_sweep()
