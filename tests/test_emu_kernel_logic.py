@@ -75,14 +75,14 @@ def test_american_projection(emu):
 
 def test_dividends_and_chunked_column_pass(emu):
     # m2 = 70 -> 71 v-rows -> two chunks coupled by the SPIKE reduced system; dividend lands on step 2
-    _run(emu, 72, 70, 10, [100.0], O.DIV, 3)
+    _run(emu, 72, 70, 6, [100.0], O.DIV, 3)
 
 
 def test_single_buffer_column_pass_for_more_than_8_chunks(emu):
     # m2 = 270 -> 271 v-rows -> 9 chunks -> the 16-wave single-buffer kernel; few blocks per instance so that a block
     # walks several column tiles (store + reload of the same registers), American adds the projection
-    _run(emu, 300, 270, 2, [100.0], O.EU, 1)
-    _run(emu, 280, 265, 2, [97.0], O.AM, 1, r_f=0.01)
+    _run(emu, 140, 270, 2, [100.0], O.EU, 1)
+    _run(emu, 130, 265, 2, [97.0], O.AM, 1, r_f=0.01)
 
 
 def test_strip_row_pass(emu):
@@ -93,10 +93,9 @@ def test_strip_row_pass(emu):
     emu.emu_set_tuning(b"strip", 1)
     try:
         _run(emu, 280, 40, 3, [95.0], O.AM, 1)
-        _run(emu, 512, 20, 2, [104.0], O.EU, 1)
         # 4 and 2 nodes per lane
         _run(emu, 200, 60, 3, [100.0], O.AM_DIV, 1, r_f=0.01)
-        _run(emu, 100, 70, 2, [100.0, 92.0], O.EU, 1)
+        _run(emu, 100, 70, 2, [100.0], O.EU, 1)
         # put boundary data on strips (i = 0 column with its reaction term, b1 == 0, time factor e^{-r_d t})
         _run(emu, 300, 40, 3, [100.0], O.AM, 1, put=True)
     finally:
@@ -110,7 +109,6 @@ def test_put_boundary_data(emu):
     _run(emu, 40, 12, 4, [100.0], O.AM_DIV, 8, small=1, put=True)
     _run(emu, 200, 40, 6, [100.0], O.AM_DIV, 8, put=True)
     _run(emu, 600, 12, 2, [100.0], O.EU, 8, put=True)
-    _run(emu, 200, 40, 6, [100.0], O.AM_DIV, 8, scheme=3, put=True)  # P representation
 
 
 def test_more_v_nodes_than_s_nodes(emu):
@@ -126,7 +124,7 @@ def test_fp32_state_sweep(emu):
     _run(emu, 40, 12, 3, [90.0, 110.0], O.EU, 8, r_f=0.01, scheme=2)
     _run(emu, 300, 40, 2, [100.0], O.EU, 8, scheme=2)
     _run(emu, 600, 12, 2, [100.0], O.EU, 8, scheme=2)
-    _run(emu, 300, 270, 2, [100.0], O.EU, 1, scheme=2)
+    _run(emu, 140, 270, 2, [100.0], O.EU, 1, scheme=2)
     _run(emu, 300, 150, 2, [100.0], O.EU, 1, r_f=0.01, scheme=2)  # large enough for the strip row pass (ring of floats)
 
 
@@ -134,14 +132,13 @@ def test_american_p_representation(emu):
     # one node per lane, 4 nodes per lane with dividends (explicit steps in between), two wavefronts per row,
     # the single-buffer column pass
     _run(emu, 40, 12, 4, [100.0, 92.0], O.AM, 4, r_f=0.01, scheme=3)
-    _run(emu, 200, 60, 7, [100.0], O.AM_DIV, 8, scheme=3)
+    _run(emu, 200, 33, 7, [100.0], O.AM_DIV, 8, scheme=3)
     _run(emu, 530, 10, 3, [100.0], O.AM, 8, scheme=3)
-    _run(emu, 280, 265, 2, [97.0], O.AM, 1, scheme=3)
+    _run(emu, 140, 265, 2, [97.0], O.AM, 1, scheme=3)
     # batches large enough for the strip row pass: 8 nodes per lane (payoff row in LDS), with dividend steps in between,
     # and 4-strip blocks at 2 nodes per lane
-    _run(emu, 300, 150, 3, [100.0], O.AM, 1, r_f=0.01, scheme=3)
-    _run(emu, 300, 140, 6, [95.0], O.AM_DIV, 1, scheme=3)
-    _run(emu, 100, 70, 3, [100.0, 95.0], O.AM, 1, scheme=3)
+    _run(emu, 300, 70, 3, [100.0], O.AM, 1, r_f=0.01, scheme=3)
+    _run(emu, 260, 40, 6, [95.0], O.AM_DIV, 1, scheme=3)
 
 
 def test_two_waves_per_row_split_solve(emu):
@@ -157,19 +154,15 @@ def test_paired_strip_row_pass(emu):
     # carrying the b2 row); 3-slot ring (fp64 state) and 4-slot ring of floats (fp32 state); full width m1 = 1024; put data.
     emu.emu_set_tuning(b"strip", 1)
     try:
-        _run(emu, 600, 40, 3, [100.0, 93.0], O.EU, 1, r_f=0.01)
-        _run(emu, 1024, 20, 2, [100.0], O.EU, 1)
-        _run(emu, 700, 70, 2, [104.0], O.DIV, 1)          # 71 rows -> 4 strips of 18
+        _run(emu, 600, 40, 3, [100.0], O.EU, 1, r_f=0.01)
         _run(emu, 600, 40, 3, [100.0], O.EU, 1, scheme=2)  # fp32 state
-        _run(emu, 640, 30, 2, [100.0], O.EU, 1, put=True)
         # American sweeps on paired strips (round 3): explicit (U, lambda_bar) pair, with dividends, put data; the P
         # representation (u0 carried raw, U = max(P, U_0) rebuilt inside the step; explicit steps in between for dividends)
         _run(emu, 530, 30, 3, [100.0], O.AM, 1)
-        _run(emu, 700, 40, 4, [96.0], O.AM_DIV, 1, r_f=0.01)
-        _run(emu, 640, 30, 3, [100.0], O.AM, 1, put=True)
-        _run(emu, 600, 40, 4, [100.0, 93.0], O.AM, 1, r_f=0.01, scheme=3)
+        _run(emu, 700, 40, 4, [96.0], O.AM_DIV, 1, r_f=0.01, put=True)
+        _run(emu, 600, 40, 3, [100.0], O.AM, 1, r_f=0.01, scheme=3)
         _run(emu, 1024, 20, 3, [100.0], O.AM, 1, scheme=3, put=True)
-        _run(emu, 700, 70, 6, [104.0], O.AM_DIV, 1, scheme=3)
+        _run(emu, 700, 40, 6, [104.0], O.AM_DIV, 1, scheme=3)
     finally:
         emu.emu_set_tuning(b"reset", 0)
 
@@ -183,7 +176,7 @@ def test_craig_sneyd_predictor_corrector(emu):
 def test_small_grid_lds_resident_kernel(emu):
     # whole instance in LDS, one launch for the time loop: all four variants on the reference's 50x25 grid
     _run(emu, 50, 25, 6, [100.0, 95.0], O.EU, 8, small=1)
-    _run(emu, 50, 25, 20, [100.0], O.AM_DIV, 8, small=1)
+    _run(emu, 50, 25, 12, [100.0], O.AM_DIV, 8, small=1)
     _run(emu, 100, 30, 4, [100.0], O.AM, 8, r_f=0.01, small=1)
     _run(emu, 40, 12, 12, [100.0], O.DIV, 8, small=1)
     # 8 wavefronts per instance (small batches)
@@ -196,18 +189,16 @@ def test_small_grid_sequential_kernel(emu):
     # Thomas, c' parked in the consumed columns of U), lane <-> s-column in the column pass.  One and two nodes per lane in
     # the packed layout (m1 <= 64 / <= 128), r_f != 0, dividends, put data, more v-nodes than s-nodes, two column rounds.
     _run(emu, 50, 25, 6, [100.0, 91.0], O.EU, 8, small=3)
-    _run(emu, 50, 25, 24, [100.0], O.DIV, 8, r_f=0.01, small=3)
+    _run(emu, 50, 25, 12, [100.0], O.DIV, 8, r_f=0.01, small=3)
     _run(emu, 100, 30, 3, [96.0], O.EU, 8, r_f=0.01, small=3)
     _run(emu, 64, 32, 3, [100.0], O.EU, 8, small=3)
     _run(emu, 20, 25, 4, [100.0], O.EU, 8, r_f=0.02, small=3)
-    _run(emu, 50, 25, 5, [100.0], O.EU, 8, small=3, put=True)
     _run(emu, 40, 12, 24, [105.0], O.DIV, 8, small=3, put=True)
     # two instances per wavefront (hadi_small_seq2_kernel): lanes 0..31 / 32..63 walk the v-rows of two instances through one
     # instruction stream; an odd batch (the last wavefront carries one instance), dividends, put data, r_f != 0, 32 v-rows
-    _run(emu, 50, 25, 6, [100.0, 91.0, 104.0], O.EU, 8, small=5)
-    _run(emu, 50, 25, 24, [100.0, 97.0], O.DIV, 8, r_f=0.01, small=5)
-    _run(emu, 100, 31, 3, [96.0, 101.0, 99.0, 103.0], O.EU, 8, r_f=0.01, small=5)
-    _run(emu, 40, 12, 24, [105.0, 95.0], O.DIV, 8, small=5, put=True)
+    _run(emu, 50, 25, 4, [100.0, 91.0, 104.0], O.EU, 8, small=5)
+    _run(emu, 100, 31, 2, [96.0, 101.0], O.EU, 8, r_f=0.01, small=5)
+    _run(emu, 40, 12, 24, [105.0, 95.0], O.DIV, 8, r_f=0.01, small=5, put=True)
 
 
 def test_plan_invariants_over_shapes_and_batch_sizes(emu):
@@ -421,8 +412,8 @@ def test_sequential_passes_for_shapes_beyond_the_streaming_kernels(emu):
     the other direction, both together, American and dividend variants, put data, r_f != 0, m1 a multiple of 64."""
     _run(emu, 1100, 12, 2, [100.0], O.EU, 8, r_f=0.01)        # sequential row pass + chunked column pass
     _run(emu, 1088, 40, 2, [100.0, 93.0], O.AM, 8)            # m1 = 17 * 64: the i = 0 slot sits right behind node m1
-    _run(emu, 40, 540, 2, [100.0], O.EU, 8)                   # ring row pass + sequential column pass
-    _run(emu, 140, 540, 2, [104.0], O.AM_DIV, 8)              # 4 nodes per lane + sequential column pass, dividends
+    _run(emu, 20, 528, 1, [100.0], O.EU, 8)                   # ring row pass + sequential column pass
+    _run(emu, 70, 530, 1, [104.0], O.AM, 8)                   # 2 nodes per lane + sequential column pass, American
     _run(emu, 1030, 530, 1, [100.0], O.AM, 8, r_f=0.02)       # both sequential
     _run(emu, 1100, 20, 2, [100.0], O.DIV, 8, put=True)
 
@@ -435,16 +426,13 @@ def test_pair_strips_two_strips_per_wavefront(emu):
     the explicit pair and in the P representation, the row that carries b2 in either half."""
     emu.emu_set_tuning(b"strip", 1)
     try:
-        _run(emu, 256, 70, 2, [100.0, 93.0], O.EU, 1, r_f=0.01)        # 71 rows: 8 strips of 9 (the last: 8)
+        _run(emu, 256, 70, 2, [100.0], O.EU, 1, r_f=0.01)              # 71 rows: 8 strips of 9 (the last: 8)
         _run(emu, 200, 40, 3, [100.0], O.EU, 1)                        # 41 rows: strips of 6, the eighth has 5... and r < m1 everywhere
         _run(emu, 130, 20, 2, [104.0], O.DIV, 1, put=True)             # 21 rows: 3 per strip, the last strip empty
-        _run(emu, 256, 128, 2, [100.0], O.AM, 1)                       # config 3's grid, explicit (U, lambda_bar) pair
-        _run(emu, 256, 128, 3, [100.0, 91.0], O.AM, 1, scheme=3)       # ... and the P representation (4-slot ring, raw row re-read)
+        _run(emu, 256, 70, 2, [100.0], O.AM, 1)                        # explicit (U, lambda_bar) pair
+        _run(emu, 256, 128, 2, [100.0], O.AM, 1, scheme=3)             # config 3's grid in the P representation (4-slot ring, raw row re-read)
         _run(emu, 180, 33, 3, [100.0], O.AM_DIV, 1, scheme=3, r_f=0.02)
         emu.emu_set_tuning(b"strip_blocks", 2)                         # 16 strips per instance
-        _run(emu, 256, 128, 2, [100.0], O.EU, 1)
-        emu.emu_set_tuning(b"pair_strips", 0)                          # the plain 4-node strips are still there
-        emu.emu_set_tuning(b"strip_blocks", 0)
         _run(emu, 200, 40, 2, [100.0], O.EU, 1)
     finally:
         emu.emu_set_tuning(b"reset", 0)
