@@ -465,12 +465,8 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         return x;
     };
     const HadiSweepArgs a_all = a, av_all = av;
-    auto enqueue_loop = [&](hipStream_t q0) -> int {
+    auto enqueue_body = [&](hipStream_t q0) -> int {
       const int n_first = d.debug ? d.debug_step : 1, n_last = d.debug ? d.debug_step : d.Nmax;
-      if (two_streams) {  // fork: the second stream starts behind everything enqueued so far
-          HIP_TRY(c, hipEventRecord(c->fork_ev, q0));
-          HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->fork_ev, 0));
-      }
       for (int sb = 0; sb < nsub; sb++) {  // one sub-batch after the other (per stream), each through its whole time loop
         hipStream_t q = (two_streams && (sb & 1)) ? c->stream2 : q0;
         const int o = subs[sb].off, nsb = subs[sb].cnt;
@@ -633,11 +629,22 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         if (amp)  // explicit U and lambda_bar for the outputs
             hipLaunchKernelGGL(hadi_am_materialise_kernel, dim3(grid1d(tot)), dim3(256), 0, q, L, nsb, a.ipar, U0b, Ub, LAMb, pl.pos_m1);
       }
-      if (two_streams) {  // join
-          HIP_TRY(c, hipEventRecord(c->join_ev, c->stream2));
-          HIP_TRY(c, hipStreamWaitEvent(q0, c->join_ev, 0));
-      }
       return HADI_OK;
+    };
+    // Fork / join around the body.  The join is enqueued even when the body failed half way: a second stream left un-joined
+    // would make hipStreamEndCapture fail ("unjoined work") and stay in capture mode for the handle's next call.
+    auto enqueue_loop = [&](hipStream_t q0) -> int {
+      if (two_streams) {  // fork: the second stream starts behind everything enqueued so far
+          HIP_TRY(c, hipEventRecord(c->fork_ev, q0));
+          HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->fork_ev, 0));
+      }
+      const int rcb = enqueue_body(q0);
+      if (two_streams) {  // join
+          const hipError_t e1 = hipEventRecord(c->join_ev, c->stream2);
+          const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(q0, c->join_ev, 0) : e1;
+          if (!rcb && e2 != hipSuccess) return fail(c, HADI_ERR_HIP, "joining the second stream failed: %s", hipGetErrorString(e2));
+      }
+      return rcb;
     };
 
     // ---- small grids: the whole instance fits in LDS -> one launch runs the entire time loop ----------
@@ -804,6 +811,13 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
             put(ptrs, sizeof(ptrs));
             put(ints, sizeof(ints));
         }
+        for (const auto &sbt : subs) {  // the launch geometry of EVERY sub-batch is baked into the nodes (unequal halves on two
+                                        // streams, a tuning change that flips only the second sub-batch's plan)
+            const HadiPlan &q = sbt.pl;
+            const int geo[] = {sbt.off, sbt.cnt, q.R, q.ntiles, q.grid_a, (int)q.smem_a, q.use_strip, q.use_pairs, q.RS, q.sblocks, q.grid_as,
+                               (int)q.smem_as, q.ctiles, q.btpw, q.bgroups, q.grid_b, q.block_b, (int)q.smem_b, q.row_seq, q.col_seq, q.W, q.NG, q.PD};
+            put(geo, sizeof(geo));
+        }
         put(&d.Nmax, sizeof(int)); put(&d.dt0, sizeof(double));
         put(&d.variant, sizeof(int)); put(&d.d_vec_s, sizeof(void *));
         void *ut = c->UT.p; put(&ut, sizeof(ut));
@@ -831,7 +845,10 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
             HIP_TRY(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             const int rcl = enqueue_loop(s);
             hipError_t ec = hipStreamEndCapture(s, &graph);
-            if (rcl) return rcl;
+            if (rcl || ec != hipSuccess) {  // nothing half-built survives: the captured graph is dropped
+                if (graph) (void)hipGraphDestroy(graph);
+                if (rcl) return rcl;
+            }
             HIP_TRY(c, ec);
             HIP_TRY(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
             c->graphs.push_back(Ctx::GraphEntry{key, graph, exec, 0});

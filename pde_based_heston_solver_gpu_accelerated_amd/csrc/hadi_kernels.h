@@ -2931,10 +2931,19 @@ HADI_DEV HADI_FORCEINLINE bool hadi_team_barrier(int *ctr, int target, int xcc_t
         int guard = 0;
         while (__atomic_load_n(ctr, __ATOMIC_SEQ_CST) < target && ++guard < HADI_TEAM_POLLS) sched_yield();
 #else
+        // Release side: every wavefront of the block drained its stores above (the vector L1 is write-through: an
+        // acknowledged store IS in this XCD's L2), so the counter update itself can be relaxed.  An agent-scope RELEASE
+        // would add `buffer_wbl2 sc1` -- a write-back of the L2's dirty lines, i.e. of the instance the team keeps there on
+        // purpose -- for readers that share this very L2 (checked below through HW_REG_XCC_ID).
         __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int guard = 0;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++guard < HADI_TEAM_POLLS)
             __builtin_amdgcn_s_sleep(2);
+        // Acquire side: invalidate this CU's vector L1 (the agent-scope acquire of the gfx942 / gfx950 memory model) before
+        // anybody in the block reads what the other CUs of the team wrote.  The cross-CU loads are `nt` on top of that, but
+        // `nt` is a streaming HINT, not a coherence guarantee: a line of the previous step left in L1 would be a silently
+        // wrong price.  One invalidate per block and barrier (~1 us each): not measurable.
+        asm volatile("buffer_inv sc1" ::: "memory");
 #endif
         if (guard >= HADI_TEAM_POLLS || hadi_xcc_id() != xcc_team) {
             hadi_report(err, HADI_DEVERR_TEAM);

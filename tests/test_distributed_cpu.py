@@ -167,4 +167,29 @@ def test_bench_gpus_flag_is_never_ignored():
         pytest.skip("GPU box: the spawning path is exercised for real in tests/test_distributed_gpu.py")
     out = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "c4",
                           "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
-    assert out.returncode != 0 and "rank exit codes [1, 1]" in out.stderr and not out.stdout.strip()
+    # (the first rank to fail ends its sibling: the codes are 1 and 1 or 1 and -15, never a 0)
+    assert out.returncode != 0 and "rank exit codes [" in out.stderr and not out.stdout.strip()
+    codes = out.stderr.split("rank exit codes [")[1].split("]")[0].split(",")
+    assert len(codes) == 2 and all(int(c) != 0 for c in codes)
+
+
+def test_launcher_never_imports_torch_or_maps_the_hip_library():
+    """`python bench.py --gpus N` without a launcher: the parent process compiles the artefacts and checks the exports with
+    `nm -D` -- at the moment it starts its ranks it has neither imported torch nor mapped libhadi.so / the HIP runtime
+    (a launcher that initialised the GPU could not safely start children on this pool)."""
+    code = (
+        "import sys, subprocess\n"
+        "sys.argv = ['bench.py', '--gpus', '2', '--workload', 'c4']\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "def fake(*a, **k):\n"
+        "    maps = open('/proc/self/maps').read()\n"
+        "    print('TORCH=%%d HIP=%%d' %% ('torch' in sys.modules, ('libhadi' in maps) or ('amdhip64' in maps)))\n"
+        "    sys.stdout.flush()\n"
+        "    raise SystemExit(0)\n"
+        "subprocess.Popen = fake\n"
+        "bench.main()\n" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr
+    assert "TORCH=0 HIP=0" in out.stdout, out.stdout

@@ -192,6 +192,34 @@ def test_instance_resident_launch_vs_oracle_and_streaming_path(solver, m1, m2, N
     assert np.abs(res[1][0] - res[0][0]).max() < 1e-11 * scale
 
 
+@pytest.mark.parametrize("m1,m2,N,n", [(512, 256, 1000, 1), (512, 256, 600, 8), (256, 128, 800, 3)])
+def test_instance_resident_launch_over_a_long_time_loop_matches_the_streaming_path(solver, m1, m2, N, n):
+    """The cross-CU visibility of the team kernel (stores acknowledged by the XCD's L2, `buffer_inv sc1` behind every team
+    barrier, L1-bypassing loads) over a LONG loop: 600 - 1000 steps = 1200 - 2000 team barriers per instance, every one a
+    chance for a stale L1 line to return the previous step's row.  The whole field against the two-launches-per-step path
+    (no oracle at this size: it would take minutes), plus the recorded price of the literal config 2."""
+    strikes = Cm.strikes_for(n)
+    grids = H.GridViewsBatch.for_strikes(m1, m2, Cm.S_0, Cm.V_0, strikes)
+    U0 = grids.call_payoff(strikes)
+    res = {}
+    for mode in (1, 0):
+        solver.set_tuning("team_launch", mode)
+        try:
+            U = U0.copy()
+            solver.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, Cm.R_F, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U)
+            res[mode] = (U, solver.describe_last_sweep(), solver.get_tuning("team_launch"))
+        finally:
+            solver.set_tuning("team_launch", -1)
+    assert "hadi_team_kernel" in res[1][1] and res[1][2] == 1, res[1][1:]
+    assert "hadi_team_kernel" not in res[0][1]
+    scale = np.abs(res[0][0]).max()
+    assert np.abs(res[1][0] - res[0][0]).max() < 2e-11 * scale
+    if (m1, m2, N, n) == (512, 256, 1000, 1):
+        g = H.Grid(m1, 800.0, Cm.S_0, 100.0, 20.0, m2, 5.0, Cm.V_0, 5.0 / 500)
+        price = res[1][0][0, g.find_s_index(Cm.S_0) + g.find_v0_index(Cm.V_0) * (m1 + 1)]
+        assert abs(price - 8.8942192888223310) < 1e-9
+
+
 def test_instance_resident_launch_is_the_default_for_small_batches_of_large_grids(solver):
     strikes = Cm.strikes_for(2)
     grids, U0, Uo, kw = _team_case(512, 256, 4, strikes)

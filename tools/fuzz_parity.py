@@ -10,14 +10,21 @@ regression tests in tests/test_gpu_regressions.py).  Judged per instance:
   well-conditioned instances     field 1e-10 of max|U|, lambda_bar 1e-8 of max(1, |lambda_bar|), against the oracle
   ill-conditioned instances      (neighbouring s-intervals differing by > 30x: S_0 inserted right beside a node; 1/ds^2
                                  coefficients of 1e6+ amplify the round-off of ANY fp64 solver -- at a ratio of 6e6 the ORACLE
-                                 is 6.6e-7 from the exact result) by the extended-precision adjudicator (oracle.solve_xp) on
-                                 the worst such instance: libhadi may be at most 30x further from the exact result than the
-                                 fp64 oracle is (plus a sanity cap of 1e-4 against the oracle)
+                                 is 6.6e-7 from the exact result) by the extended-precision adjudicator (oracle.solve_xp), EVERY
+                                 such instance whose difference from the oracle leaves the well-conditioned band: libhadi
+                                 may be at most 30x further from the exact result than the fp64 oracle is (plus a sanity
+                                 cap of 1e-4 against the oracle)
   fp32 state                     against the oracle with the same roundings, with that instance's own fp32 noise as the
                                  yardstick (last-bit fp64 differences flip float roundings, and the flips grow like the
                                  noise): |libhadi - oracle32| <= 1.5 |oracle32 - oracle64| + 2e-7 N per well-conditioned
                                  instance, 10x on ill-conditioned ones
-Every BAD line is followed by the adjudicator's verdict on its worst instance."""
+Every BAD line is followed by the adjudicator's verdict on its worst instance.
+
+THE RULES ABOVE ARE FROZEN (round 4).  They were fitted twice to cases that tripped them (the fp32 rule for ill-conditioned
+instances went 4x -> 10x in round 3); a bound that moves whenever it trips is not a bound.  From here on a BAD line is a
+FINDING -- it becomes a regression test with its adjudicated numbers and, if the adjudicator blames libhadi, a defect to fix --
+never a new constant.  Since round 4 every ill-conditioned instance outside the well-conditioned band is adjudicated, not only
+the worst one of its case."""
 import os, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -98,14 +105,24 @@ def judge(c, r):
     else:
         ok = ok and err < 1e-10 and lerr < 1e-8 and err_ill < 1e-4 and lerr_ill < 1e-3
     verdict = None
-    if ill.any() and not f32:  # the adjudicator decides on the worst ill-conditioned instance
-        k = int(np.where(ill)[0][np.argmax(per[ill] + (lper[ill] if r["lo"] is not None else 0.0))])
-        verdict = adjudicate(c, r, k)
-        # (both distances are realisations of cond * eps: scanning the position of a 2e-5-wide interval over the lanes their
-        # ratio ranges over 0.2 .. 10; the one-node-per-lane defect this check caught in round 3 was 380x)
-        ok = ok and verdict["hadi_U"] < max(30 * verdict["oracle_U"], 1e-11)
-        if verdict["hadi_lam"] is not None:
-            ok = ok and verdict["hadi_lam"] < max(30 * verdict["oracle_lam"], 1e-9)
+    if ill.any() and not f32:
+        # EVERY ill-conditioned instance outside the well-conditioned band (field 1e-10, lambda_bar 1e-8) goes through the
+        # adjudicator -- a defect must not hide behind a worse neighbour of its batch; the rest are inside the band anyway.
+        # The verdict printed is the worst one's.
+        lp = lper if r["lo"] is not None else np.zeros_like(per)
+        todo = [int(k) for k in np.where(ill)[0] if per[k] >= 1e-10 or lp[k] >= 1e-8]
+        if not todo:
+            todo = [int(np.where(ill)[0][np.argmax(per[ill] + lp[ill])])]
+        for k in todo:
+            v = adjudicate(c, r, k)
+            # (both distances are realisations of cond * eps: scanning the position of a 2e-5-wide interval over the lanes their
+            # ratio ranges over 0.2 .. 10; the one-node-per-lane defect this check caught in round 3 was 380x)
+            ok = ok and v["hadi_U"] < max(30 * v["oracle_U"], 1e-11)
+            if v["hadi_lam"] is not None:
+                ok = ok and v["hadi_lam"] < max(30 * v["oracle_lam"], 1e-9)
+            if verdict is None or v["hadi_U"] / max(v["oracle_U"], 1e-300) > verdict["hadi_U"] / max(verdict["oracle_U"], 1e-300):
+                verdict = v
+        verdict["adjudicated"] = len(todo)
     return ok, dict(err=err, err_ill=err_ill, lerr=lerr, lerr_ill=lerr_ill, per=per, verdict=verdict)
 
 
@@ -123,8 +140,8 @@ def main():
         ok, j = judge(c, r)
         if not c["f32"]: worst = max(worst, j["err"])
         v = j["verdict"]
-        vs = "" if v is None else " | xp inst %d: hadi %.1e oracle %.1e%s" % (
-            v["k"], v["hadi_U"], v["oracle_U"], "" if v["hadi_lam"] is None else " lam %.1e / %.1e" % (v["hadi_lam"], v["oracle_lam"]))
+        vs = "" if v is None else " | xp %d inst, worst %d: hadi %.1e oracle %.1e%s" % (
+            v.get("adjudicated", 1), v["k"], v["hadi_U"], v["oracle_U"], "" if v["hadi_lam"] is None else " lam %.1e / %.1e" % (v["hadi_lam"], v["oracle_lam"]))
         print("%s %3d %s err=%.2e ill=%.2e lam_err=%.2e lam_ill=%.2e%s | %s" % (
             "ok " if ok else "BAD", c["index"], F.summary(c), j["err"], j["err_ill"], j["lerr"], j["lerr_ill"], vs, r["path"][:70]), flush=True)
         if not ok:
