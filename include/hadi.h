@@ -190,11 +190,14 @@ int hadi_get_timing(const hadi_ctx *ctx, hadi_timing *out);
  *                 faster), 0 never, 1 whenever possible
  *   "sub_batch"   batches of several rounds of one instance per CU on grids whose round exceeds the 256 MB memory-side
  *                 cache run sub-batch by sub-batch through the time loop (default 1; instances are independent)
- *   "streams"     1 (default) or 2: with 2 the sub-batches of a Douglas sweep run side by side on two streams (a batch that is
- *                 one sub-batch is cut in two halves; per-launch profiling switches it off).  Same kernels, same results
- *                 to round-off.  It pays where the launches of the whole batch leave a partial round of CUs idle -- 512x256:
- *                 160 instances +7 %, 192: +16 %, 24..32: +14..22 %, config 3 (512 x 256x128 American): +5 % -- and costs
- *                 2..12 % where they fill whole rounds (64, 128, 256, 512 instances); DESIGN.md section 5
+ *   "streams"     0 (default) automatic, 1 one stream, 2 two streams.  On two streams the two halves of a Douglas batch run their
+ *                 time loops side by side (fork / join by events inside the call; per-launch profiling switches it off).
+ *                 Same kernels, same results.  It pays where the row pass of the whole batch leaves a partial round of CUs
+ *                 idle -- 512x256: 160 instances +7 %, 192: +16 %, 24..32: +14..22 % -- and costs 2..12 % where the launches
+ *                 fill whole rounds (64, 128, 256, 512 instances): the automatic choice cuts the batch (or the remainder
+ *                 behind its full rounds of one instance per CU) in two exactly when the plan's row pass leaves 4 % or more
+ *                 of its CU-rounds idle (hadi_plan_row_idle) -- a function of the grid shape and the batch size alone.
+ *                 With 2 the sub-batches of a large batch alternate between the streams; DESIGN.md section 7
  *   "device_vgrid" v-grids of compute_base_prices / compute_jacobian rebuilt per instance on the device (default 1;
  *                 0 = built once on the host with glibc sinh/asinh and broadcast -- bit-identical to the reference's
  *                 host-side Grid, needs one shared V_0)

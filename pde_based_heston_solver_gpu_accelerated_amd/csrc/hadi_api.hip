@@ -52,7 +52,7 @@ struct Ctx {
     int device_vgrid = 1;  // compute_base_prices / compute_jacobian: v-grids rebuilt per instance on the device
     int sub_batch = 1;     // large batches run sub-batch by sub-batch (run_sweep)
     int small_pairs = -1;  // small-grid sequential kernel with two instances per wavefront: -1 by batch size, 0 never, 1 always
-    int streams = 1;       // sub-batches run on this many streams side by side (1 or 2; hadi_set_tuning "streams")
+    int streams = 0;       // hadi_set_tuning "streams": 0 automatic (hadi_plan_row_idle), 1 one stream, 2 two streams side by side
     hipStream_t stream2 = nullptr;                 // the second stream of a two-stream sweep
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     int last_nsub = 1;
@@ -281,41 +281,63 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     // 384 at once: 0.188 + 0.205 ms per step against 0.173 + 0.177 as 256 + 128).  Instances are independent, so the time
     // loop runs sub-batch by sub-batch -- whole rounds of cu_count instances plus the remainder (a remainder below a
     // quarter round rides with the last full round) -- each with the launch geometry of its own size.
-    struct SubBatch { int off, cnt; HadiPlan pl; };
+    struct SubBatch { int off, cnt; HadiPlan pl; int lane; };  // lane: 0 = the handle's stream, 1 = its second stream
     std::vector<SubBatch> subs;
+    // (the strip kernels scale the A1 action by (1 - theta) / theta and keep the s-convection weights multiplied by
+    // theta dt (r_d - r_f): hadi_strip_step)
+    const bool no_strips = !(d.theta > 0.0) || d.r_d == d.r_f;
+    auto plan_for = [&](int cnt, HadiPlan *q) {
+        if (hadi_make_plan(d.m1, d.m2, cnt, 8 * c->cu_count, q, c->tune, state_bytes)) return 1;
+        if (no_strips) q->use_strip = 0;
+        return 0;
+    };
+    if (no_strips) pl.use_strip = 0;
     if (d.scheme == HADI_SCHEME_DOUGLAS && !d.debug && c->sub_batch && d.n > c->cu_count &&
         2ll * c->cu_count * pl.L.inst_stride * (long long)state_bytes >= (256ll << 20)) {  // (bytes the sweep streams: 4 per element with the fp32 state)
         const int cu = c->cu_count, full = d.n / cu, rem = d.n - full * cu;
-        for (int k = 0; k < full; k++) subs.push_back(SubBatch{k * cu, cu, pl});
-        if (rem >= cu / 4) subs.push_back(SubBatch{full * cu, rem, pl});
+        for (int k = 0; k < full; k++) subs.push_back(SubBatch{k * cu, cu, pl, 0});
+        if (rem >= cu / 4) subs.push_back(SubBatch{full * cu, rem, pl, 0});
         else subs.back().cnt += rem;
         for (auto &sbt : subs)
-            if (hadi_make_plan(d.m1, d.m2, sbt.cnt, 8 * c->cu_count, &sbt.pl, c->tune, state_bytes))
-                return fail(c, HADI_ERR_UNSUPPORTED, "plan failed");
+            if (plan_for(sbt.cnt, &sbt.pl)) return fail(c, HADI_ERR_UNSUPPORTED, "plan failed");
         pl = subs[0].pl;  // (what the caller sees: layout and table sizes are the same for every sub-batch)
     } else {
-        subs.push_back(SubBatch{0, d.n, pl});
+        subs.push_back(SubBatch{0, d.n, pl, 0});
     }
-    // Two streams: the sub-batches run side by side, so that the ramp-up and the tail of one sub-batch's launches are filled
-    // by the other's (instances are independent; the two passes of a step stay ordered within their own stream).  A batch that
-    // is one sub-batch is cut in two halves for it.
-    const bool two_streams = c->streams == 2 && d.scheme == HADI_SCHEME_DOUGLAS && !d.debug && !c->profiling && d.n >= 2;
-    if (two_streams && subs.size() == 1) {
-        const int h0 = (d.n + 1) / 2;
-        subs.clear();
-        subs.push_back(SubBatch{0, h0, pl});
-        subs.push_back(SubBatch{h0, d.n - h0, pl});
-        for (auto &sbt : subs)
-            if (hadi_make_plan(d.m1, d.m2, sbt.cnt, 8 * c->cu_count, &sbt.pl, c->tune, state_bytes))
-                return fail(c, HADI_ERR_UNSUPPORTED, "plan failed");
-        pl = subs[0].pl;
+    // Two streams.  Forced (hadi_set_tuning "streams" = 2): the sub-batches alternate between the two streams from the start; a
+    // batch that is one sub-batch is cut in two halves for it.  Automatic ("streams" = 0, the default): the LAST sub-batch --
+    // the whole batch, or the remainder behind the full rounds -- is cut in two halves that run side by side when its row
+    // pass would leave a partial round of CUs idle (hadi_plan_row_idle); the full rounds before it run on one stream.
+    // Instances are independent and the two passes of a step stay ordered within their own stream.
+    const bool streams_ok = d.scheme == HADI_SCHEME_DOUGLAS && !d.debug && !c->profiling && d.n >= 2 && !seq_shape;
+    bool two_streams = false;
+    int fork_before = 0;  // the second stream forks off right before this sub-batch is enqueued
+    auto split_last = [&]() -> int {
+        const SubBatch last = subs.back();
+        const int h0 = (last.cnt + 1) / 2;
+        subs.pop_back();
+        subs.push_back(SubBatch{last.off, h0, last.pl, 0});
+        subs.push_back(SubBatch{last.off + h0, last.cnt - h0, last.pl, 1});
+        for (size_t k = subs.size() - 2; k < subs.size(); k++)
+            if (plan_for(subs[k].cnt, &subs[k].pl)) return 1;
+        return 0;
+    };
+    if (streams_ok && c->streams == 2) {
+        if (subs.size() == 1) {
+            if (split_last()) return fail(c, HADI_ERR_UNSUPPORTED, "plan failed");
+        } else {
+            for (size_t k = 0; k < subs.size(); k++) subs[k].lane = (int)(k & 1);
+        }
+        two_streams = true;
+        fork_before = 0;
+    } else if (streams_ok && c->streams == 0 && subs.back().cnt >= 2 &&
+               hadi_plan_row_idle(subs.back().pl, subs.back().cnt, c->cu_count) >= HADI_TWO_STREAM_IDLE) {
+        if (split_last()) return fail(c, HADI_ERR_UNSUPPORTED, "plan failed");
+        two_streams = true;
+        fork_before = (int)subs.size() - 2;
     }
+    if (two_streams) pl = subs[0].pl;
     const int nsub = (int)subs.size();
-    if (!(d.theta > 0.0) ||  // the strip kernel scales the A1 action by (1 - theta) / theta
-        d.r_d == d.r_f) {    // ... and keeps the s-convection weights multiplied by theta dt (r_d - r_f) (hadi_strip_step)
-        pl.use_strip = 0;
-        for (auto &sbt : subs) sbt.pl.use_strip = 0;
-    }
     const HadiLayout &L = pl.L;
     const bool american = d.variant == HADI_AM || d.variant == HADI_AM_DIV;
     const bool dividend = d.variant == HADI_DIV || d.variant == HADI_AM_DIV;
@@ -465,10 +487,16 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         return x;
     };
     const HadiSweepArgs a_all = a, av_all = av;
+    bool forked = false;
     auto enqueue_body = [&](hipStream_t q0) -> int {
       const int n_first = d.debug ? d.debug_step : 1, n_last = d.debug ? d.debug_step : d.Nmax;
       for (int sb = 0; sb < nsub; sb++) {  // one sub-batch after the other (per stream), each through its whole time loop
-        hipStream_t q = (two_streams && (sb & 1)) ? c->stream2 : q0;
+        if (two_streams && sb == fork_before) {  // fork: the second stream starts behind everything enqueued so far
+            HIP_TRY(c, hipEventRecord(c->fork_ev, q0));
+            HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->fork_ev, 0));
+            forked = true;
+        }
+        hipStream_t q = (two_streams && subs[sb].lane) ? c->stream2 : q0;
         const int o = subs[sb].off, nsb = subs[sb].cnt;
         const HadiPlan &pl = subs[sb].pl;  // (shadows the whole-batch plan: launch geometry of THIS sub-batch)
         const size_t so = (size_t)o * L.inst_stride;
@@ -634,12 +662,9 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     // Fork / join around the body.  The join is enqueued even when the body failed half way: a second stream left un-joined
     // would make hipStreamEndCapture fail ("unjoined work") and stay in capture mode for the handle's next call.
     auto enqueue_loop = [&](hipStream_t q0) -> int {
-      if (two_streams) {  // fork: the second stream starts behind everything enqueued so far
-          HIP_TRY(c, hipEventRecord(c->fork_ev, q0));
-          HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->fork_ev, 0));
-      }
+      forked = false;
       const int rcb = enqueue_body(q0);
-      if (two_streams) {  // join
+      if (forked) {  // join
           const hipError_t e1 = hipEventRecord(c->join_ev, c->stream2);
           const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(q0, c->join_ev, 0) : e1;
           if (!rcb && e2 != hipSuccess) return fail(c, HADI_ERR_HIP, "joining the second stream failed: %s", hipGetErrorString(e2));
@@ -756,7 +781,8 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                 for (auto &sbt : subs) c->last_path += " " + std::to_string(sbt.cnt);
                 c->last_path += " instances (each with the geometry of its own size)";
             }
-            if (two_streams) c->last_path += ", side by side on two streams";
+            if (two_streams && fork_before > 0) c->last_path += ", the last two side by side on two streams";
+            else if (two_streams) c->last_path += ", side by side on two streams";
         }
     }
     c->last_nsub = nsub;
@@ -814,7 +840,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         for (const auto &sbt : subs) {  // the launch geometry of EVERY sub-batch is baked into the nodes (unequal halves on two
                                         // streams, a tuning change that flips only the second sub-batch's plan)
             const HadiPlan &q = sbt.pl;
-            const int geo[] = {sbt.off, sbt.cnt, q.R, q.ntiles, q.grid_a, (int)q.smem_a, q.use_strip, q.use_pairs, q.RS, q.sblocks, q.grid_as,
+            const int geo[] = {sbt.lane, fork_before, sbt.off, sbt.cnt, q.R, q.ntiles, q.grid_a, (int)q.smem_a, q.use_strip, q.use_pairs, q.RS, q.sblocks, q.grid_as,
                                (int)q.smem_as, q.ctiles, q.btpw, q.bgroups, q.grid_b, q.block_b, (int)q.smem_b, q.row_seq, q.col_seq, q.W, q.NG, q.PD};
             put(geo, sizeof(geo));
         }
@@ -1344,7 +1370,7 @@ int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value) {
     else if (!std::strcmp(key, "device_vgrid")) c->device_vgrid = value ? 1 : 0;
     else if (!std::strcmp(key, "sub_batch")) c->sub_batch = value ? 1 : 0;
     else if (!std::strcmp(key, "small_pairs")) c->small_pairs = value < 0 ? -1 : (value ? 1 : 0);
-    else if (!std::strcmp(key, "streams")) c->streams = value == 2 ? 2 : 1;
+    else if (!std::strcmp(key, "streams")) c->streams = value == 2 ? 2 : (value == 1 ? 1 : 0);
     else if (!std::strcmp(key, "strip")) c->tune.strip = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "debug_fault")) c->debug_fault = value;
     else if (!std::strcmp(key, "team_launch")) { c->team_launch = value < 0 ? -1 : (value ? 1 : 0); c->team_failed = 0; }

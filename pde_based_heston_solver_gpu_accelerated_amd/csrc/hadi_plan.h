@@ -303,6 +303,29 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
     return 0;
 }
 
+// Fraction of the row pass's CU-rounds that a launch of this plan leaves idle: blocks / (rounds x block slots of the chip).
+// The strip kernels of 8 nodes per lane hold a CU alone, every other row kernel shares it with a second block (their launch
+// bounds).  This is what decides between one and two streams (hadi_api.hip, run_sweep): a batch whose row pass fills whole
+// rounds (512x256: 64, 128, 256, 512 instances) gains nothing from a second stream and loses 2 - 12 % to two kernels that each
+// want every CU; one that leaves a partial round idle (24 - 32: 50 - 60 % idle, 96 and 192: 25 %, 160: 6 %) gains 3 - 22 %
+// when its two halves run side by side, the row pass of one on the CUs the other's partial round leaves free (measured,
+// DESIGN.md section 7).  Deterministic per (shape, batch size): the path of a call never depends on the calls before it.
+inline double hadi_plan_row_idle(const HadiPlan &p, int n_inst, int cus) {
+    if (p.row_seq) return 0.0;
+    long long blocks, slots;
+    if (p.use_strip) {
+        blocks = (long long)n_inst * p.sblocks;
+        slots = (long long)cus * ((p.L.B == 8) ? 1 : 2);
+    } else {
+        blocks = (long long)n_inst * ((p.ntiles + p.NG - 1) / p.NG);
+        slots = (long long)cus * 2;
+    }
+    if (blocks < 1 || slots < 1) return 0.0;
+    const long long rounds = (blocks + slots - 1) / slots;
+    return 1.0 - (double)blocks / (double)(rounds * slots);
+}
+#define HADI_TWO_STREAM_IDLE 0.04  // two streams from this idle fraction on (160 instances of 512x256: 0.0625, +7 % measured)
+
 // Which dividend an instance with (N, dt) pays at the START of step n = 1..N (device_solver.hpp:426-447,508-516):
 // flags[n-1] = index into the schedule or -1.  n*dt is evaluated in floating point exactly as the reference
 // does (12*0.05 = 0.6000000000000001 decides the step a dividend lands on).  flags has `len` >= N entries;

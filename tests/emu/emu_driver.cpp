@@ -175,6 +175,13 @@ extern "C" int emu_plan_full(int m1, int m2, int n_inst, int target_waves, long 
     return 0;
 }
 
+// the fraction of its CU-rounds the plan's row pass leaves idle (decides one or two streams: hadi_plan_row_idle), x 1e6
+extern "C" long long emu_plan_row_idle_ppm(int m1, int m2, int n_inst, int cus) {
+    HadiPlan pl;
+    if (hadi_make_plan(m1, m2, n_inst, 8 * cus, &pl, g_tune)) return -1;
+    return (long long)(hadi_plan_row_idle(pl, n_inst, cus) * 1e6 + 0.5);
+}
+
 // variant bit0 = american, bit1 = dividends.  Arrays natural layout [n][...].
 extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double theta, double r_d, double r_f,
                          const double *par /*[n][4] rho sigma kappa eta*/, int variant, const double *vec_s,

@@ -257,6 +257,23 @@ def test_plan_invariants_over_shapes_and_batch_sizes(emu):
     assert emu.emu_plan_full(600, 528, 1, 8, o) == 0 and o[3] == 1 and o[5] == 529  # beyond 16 chunks: one chunk, sequential column pass
 
 
+def test_automatic_two_stream_choice_follows_the_idle_rounds_of_the_row_pass(emu):
+    """hadi_plan_row_idle: batches of 512x256 whose row pass fills whole rounds of the 256 CUs (64, 128, 256 instances: two
+    streams measured 5 - 12 % SLOWER) stay on one stream, batches that leave a partial round idle (32, 96, 160, 192: two
+    streams measured 3 - 22 % faster) are cut in two; config 3 and config 5 fill their rounds.  A function of (shape, batch
+    size) alone -- no timing, no history."""
+    emu.emu_plan_row_idle_ppm.restype = C.c_longlong
+    idle = lambda m1, m2, n: emu.emu_plan_row_idle_ppm(m1, m2, n, 256) / 1e6
+    for n in (64, 128, 256):
+        assert idle(512, 256, n) < 0.04, (n, idle(512, 256, n))
+    for n, want in ((160, 0.0625), (192, 0.25), (96, 0.25)):
+        assert abs(idle(512, 256, n) - want) < 1e-6, (n, idle(512, 256, n))
+    assert idle(512, 256, 32) >= 0.04 and idle(512, 256, 24) >= 0.04  # (the shared ring's launches are quantised as well)
+    assert idle(256, 128, 512) < 0.04   # config 3: 512 pair-strip blocks, two per CU
+    assert idle(1024, 512, 64) < 0.04   # config 5: 256 paired-strip blocks
+    assert idle(1024, 512, 48) >= 0.04  # ... three quarters of a round
+
+
 def test_setup_tables_against_oracle_operators(emu):
     """The O(m1+m2) tables reproduce the reference's dense operators: apply them to a random field and
     compare with the oracle's A0U / A1U / A2U of step 1."""
