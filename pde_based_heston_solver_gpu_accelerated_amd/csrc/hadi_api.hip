@@ -52,6 +52,11 @@ struct Ctx {
     int device_vgrid = 1;  // compute_base_prices / compute_jacobian: v-grids rebuilt per instance on the device
     int sub_batch = 1;     // large batches run sub-batch by sub-batch (run_sweep)
     int small_pairs = -1;  // small-grid sequential kernel with two instances per wavefront: -1 by batch size, 0 never, 1 always
+    // Two measured alternatives of the column pass, both opt-in (round 4; neither moves the 16-chunk pass by more than +-2 %:
+    // profiles/r04_colpass_ab.txt): the blocks of an instance take their full column tiles interleaved (hadi_pb_tiles), and
+    // hadi_pass_b2 -- part of the next tile prefetched into LDS -- instead of hadi_pass_b1 for European sweeps of 9 .. 16 chunks
+    int tile_il = 0;
+    int col_prefetch = 0;
     int streams = 0;       // hadi_set_tuning "streams": 0 automatic (hadi_plan_row_idle), 1 one stream, 2 two streams side by side
     hipStream_t stream2 = nullptr;                 // the second stream of a two-stream sweep
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
@@ -246,6 +251,8 @@ hipError_t raise_all_lds_limits() {
     if ((e = raise_lds_limit(hadi_pass_b<8, false>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b<8, true>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b1<16, false>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_b2<16, double, HADI_B2_NPF(8)>)) != hipSuccess) return e;
+    if ((e = raise_lds_limit(hadi_pass_b2<16, float, HADI_B2_NPF(4)>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b<8, 2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_b1<16, 2>)) != hipSuccess) return e;
     if ((e = raise_lds_limit(hadi_pass_a<1, 1, 4, 1, 2, 2>)) != hipSuccess) return e;
@@ -332,9 +339,15 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         fork_before = 0;
     } else if (streams_ok && c->streams == 0 && subs.back().cnt >= 2 &&
                hadi_plan_row_idle(subs.back().pl, subs.back().cnt, c->cu_count) >= HADI_TWO_STREAM_IDLE) {
+        const SubBatch whole = subs.back();
         if (split_last()) return fail(c, HADI_ERR_UNSUPPORTED, "plan failed");
-        two_streams = true;
-        fork_before = (int)subs.size() - 2;
+        if (subs[subs.size() - 2].pl.use_strip && subs.back().pl.use_strip) {
+            two_streams = true;
+            fork_before = (int)subs.size() - 2;
+        } else {  // (a half that falls back to the shared ring: the rounds argument does not carry over -- one stream)
+            subs.pop_back();
+            subs.back() = whole;
+        }
     }
     if (two_streams) pl = subs[0].pl;
     const int nsub = (int)subs.size();
@@ -447,6 +460,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     a.pb = ptr<double>(c->pb); a.rinv = ptr<double>(c->rinv); a.ipar = ptr<HadiInstPar>(c->ipar);
     a.L = L; a.n_inst = d.n; a.R = pl.R; a.ntiles = pl.ntiles; a.ctiles = pl.ctiles; a.btpw = pl.btpw; a.bgroups = pl.bgroups;
     a.american = american ? 1 : 0; a.pos_m1 = pl.pos_m1;
+    a.tile_il = c->tile_il;
     a.RS = pl.RS; a.sblocks = pl.sblocks;
     a.err = c->err_dev; a.debug = c->debug_fault;
     a.R1 = (cs || pl.row_seq) ? ptr<double>(c->R1) : nullptr;
@@ -623,6 +637,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                 }
                 if (f32) {
                     if (L.P <= 8) hipLaunchKernelGGL((hadi_pass_b<8, false, float>), g, b, pl.smem_b, q, ar, nstep);
+                    else if (c->col_prefetch) hipLaunchKernelGGL((hadi_pass_b2<16, float, HADI_B2_NPF(4)>), g, b, pl.smem_b2, q, ar, nstep);
                     else hipLaunchKernelGGL((hadi_pass_b1<16, false, float>), g, b, pl.smem_b, q, ar, nstep);
                     return;
                 }
@@ -631,6 +646,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                     else hipLaunchKernelGGL((hadi_pass_b<8, false>), g, b, pl.smem_b, q, ar, nstep);
                 } else {
                     if (american) hipLaunchKernelGGL((hadi_pass_b1<16, true>), g, b, pl.smem_b, q, ar, nstep);
+                    else if (c->col_prefetch) hipLaunchKernelGGL((hadi_pass_b2<16, double, HADI_B2_NPF(8)>), g, b, pl.smem_b2, q, ar, nstep);
                     else hipLaunchKernelGGL((hadi_pass_b1<16, false>), g, b, pl.smem_b, q, ar, nstep);
                 }
             };
@@ -770,7 +786,8 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
             std::snprintf(buf, sizeof buf, "row pass %s; column pass hadi_pass_b_seq<%s> (one lane per column, sequential along v)", rowk, american ? "AM" : "EU");
         else
             std::snprintf(buf, sizeof buf, "row pass %s; column pass %s<%d,%s> (%d chunks of %d rows, %d column tiles per block)", rowk,
-                          L.P <= 8 ? "hadi_pass_b" : "hadi_pass_b1", L.P <= 8 ? 8 : 16, amp ? "AM-P" : american ? "AM" : "EU", L.P, HADI_LC, pl.btpw);
+                          L.P <= 8 ? "hadi_pass_b" : (!american && c->col_prefetch) ? "hadi_pass_b2" : "hadi_pass_b1", L.P <= 8 ? 8 : 16,
+                          amp ? "AM-P" : american ? "AM" : "EU", L.P, HADI_LC, pl.btpw);
         c->last_path = buf;
         if (nsub > 1) {
             bool same = true;
@@ -840,7 +857,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         for (const auto &sbt : subs) {  // the launch geometry of EVERY sub-batch is baked into the nodes (unequal halves on two
                                         // streams, a tuning change that flips only the second sub-batch's plan)
             const HadiPlan &q = sbt.pl;
-            const int geo[] = {sbt.lane, fork_before, sbt.off, sbt.cnt, q.R, q.ntiles, q.grid_a, (int)q.smem_a, q.use_strip, q.use_pairs, q.RS, q.sblocks, q.grid_as,
+            const int geo[] = {c->col_prefetch, c->tile_il, sbt.lane, fork_before, sbt.off, sbt.cnt, q.R, q.ntiles, q.grid_a, (int)q.smem_a, q.use_strip, q.use_pairs, q.RS, q.sblocks, q.grid_as,
                                (int)q.smem_as, q.ctiles, q.btpw, q.bgroups, q.grid_b, q.block_b, (int)q.smem_b, q.row_seq, q.col_seq, q.W, q.NG, q.PD};
             put(geo, sizeof(geo));
         }
@@ -1371,6 +1388,8 @@ int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value) {
     else if (!std::strcmp(key, "sub_batch")) c->sub_batch = value ? 1 : 0;
     else if (!std::strcmp(key, "small_pairs")) c->small_pairs = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "streams")) c->streams = value == 2 ? 2 : (value == 1 ? 1 : 0);
+    else if (!std::strcmp(key, "col_prefetch")) c->col_prefetch = value ? 1 : 0;
+    else if (!std::strcmp(key, "tile_interleave")) c->tile_il = value ? 1 : 0;
     else if (!std::strcmp(key, "strip")) c->tune.strip = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "debug_fault")) c->debug_fault = value;
     else if (!std::strcmp(key, "team_launch")) { c->team_launch = value < 0 ? -1 : (value ? 1 : 0); c->team_failed = 0; }
@@ -1405,6 +1424,8 @@ int hadi_get_tuning(const hadi_ctx *ctx, const char *key, int *value) {
     else if (!std::strcmp(key, "sub_batch")) *value = c->sub_batch;
     else if (!std::strcmp(key, "small_pairs")) *value = c->small_pairs;
     else if (!std::strcmp(key, "streams")) *value = c->streams;
+    else if (!std::strcmp(key, "col_prefetch")) *value = c->col_prefetch;
+    else if (!std::strcmp(key, "tile_interleave")) *value = c->tile_il;
     else if (!std::strcmp(key, "strip")) *value = c->tune.strip;
     else if (!std::strcmp(key, "debug_fault")) *value = c->debug_fault;
     else if (!std::strcmp(key, "team_launch")) *value = c->team_failed ? -2 : c->team_launch;

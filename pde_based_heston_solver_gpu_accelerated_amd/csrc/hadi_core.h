@@ -27,6 +27,14 @@
 #define HADI_ROW_PAD(B, ES) ((B) < 4 ? 8 : ((ES) == 4 ? 32 : 16))
 #define HADI_B1_BOTH (1 << 24)  // row-table flag added to RC_B1COL (a column index < 2^20): the row has a b1 entry at column 0 as well (m2 > m1 only)
 
+// Column pass with the reduced system on the matrix core (hadi_pb_solve<.., MF>): LDS doubles = exchange values Z [4 P][64] +
+// selected inverse rows, transposed, RT [4 P][MP] + the product T [MP][64], MP = 4 P rounded up to whole 16-row blocks
+HADI_HD inline int hadi_pb_mp(int P) { return 16 * ((P + 3) >> 2); }
+HADI_HD inline size_t hadi_pb_mf_doubles(int P) { return (size_t)4 * P * 64 + (size_t)4 * P * hadi_pb_mp(P) + (size_t)hadi_pb_mp(P) * 64; }
+#ifndef HADI_PB_MF
+#define HADI_PB_MF 1
+#endif
+
 struct HadiLayout {
     int m1, m2, nrows;  // nrows = m2 + 1
     int nrows_pad;      // P * HADI_LC >= nrows: v-rows past nrows are identity rows (always 0) so that

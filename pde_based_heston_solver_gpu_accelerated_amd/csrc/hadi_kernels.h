@@ -41,6 +41,8 @@ struct HadiSweepArgs {
     int RS, sblocks; // strip row pass: v-rows per wavefront strip, 8-strip blocks per instance
     int ctiles;      // pass B: 64-column tiles per instance
     int btpw, bgroups;  // pass B: column tiles per block, blocks per instance
+    int tile_il;        // pass B: 1 = the blocks of an instance take the full column tiles INTERLEAVED (block g: g, g + G, g + 2 G ...)
+                        // instead of btpw consecutive ones each (hadi_pb_tiles)
     int american;
     int pos_m1;      // storage position of i = m1 (lambda_bar is forced to 0 there)
     int *err;        // the handle's sticky error word (host-pinned, device-visible): kernels OR a HADI_DEVERR_* code into it,
@@ -55,6 +57,10 @@ struct HadiSweepArgs {
 #define HADI_DEBUG_TEAM_NO_ROWS 16   // hadi_team_kernel, timing diagnostics (results are wrong): skip the row phase's work
 #define HADI_DEBUG_TEAM_NO_COLS 32   // ... skip the column phase's work
 #define HADI_DEBUG_TEAM_NO_BARRIER 64  // ... skip the team barriers
+#define HADI_DEBUG_COL_NO_SOLVE 256     // hadi_pass_b1 / hadi_pass_b2, timing diagnostics (results are wrong): tiles are loaded and stored
+                                       // but not solved -- what the memory system gives the pass's access pattern alone
+#define HADI_DEBUG_COL_NO_REDUCED 512   // column pass, timing diagnostics (results are wrong): the interface exchange and its barrier run, the
+                                       // reduced system t = R^-1 z does not (its 4 x 4P broadcast-operand FMAs per lane)
 #define HADI_DEBUG_TEAM_DESERT 128     // hadi_team_kernel: block 1 of every team leaves before the first barrier (the others must
                                        // time out, report HADI_DEVERR_TEAM, and the host must solve the batch on the streaming path)
 
@@ -2385,10 +2391,15 @@ struct HadiPassBCtx {
     const double *tabl; // hadi_pb_solve<true>: the chunk's table rows in LDS, [HADI_LC][HADI_PBW] (instance-resident kernel)
     const double *Ri;   // this wavefront's four rows of the reduced inverse in LDS, [4P][4]: for column m the
                         // coefficients of (left-neighbour last two, right-neighbour first two)
-    double *zsh;        // LDS exchange, 2 buffers of P*4*64
+    double *zsh;        // LDS exchange, 2 buffers of P*4*64 (ONE buffer with the matrix-core reduced system, below)
+    const double *RT;   // hadi_pb_solve<.., MF>: the selected rows of the reduced inverse in LDS, TRANSPOSED: RT[k][r], r = 4 w + q the
+                        // q-th coefficient row of wavefront w (0, 1: its left neighbour's last two unknowns, 2, 3: its right
+                        // neighbour's first two), pitch MP = 16 ceil(P / 4), zero beyond r = 4 P
+    double *Tsh;        // ... and its result T = R Z in LDS, [MP][64]
     int lane, wave, P, ja, rowp, american, pos_m1;
     int nrows;          // real v-rows (m2 + 1); rows nrows .. P*HADI_LC-1 are identity padding
     double dt;
+    int debug;          // HadiSweepArgs.debug (timing diagnostics only)
     HADI_STAMP_ACC
 };
 
@@ -2436,12 +2447,89 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_load(const HadiPassBCtx &c, int ctile, do
     for (int k = 0; k < HADI_LC; k++) y[k] = hadi_buf_load_t<T>(c.Yb, voff, hadi_pb_row(c, k) * rstride);
 }
 
+// D(16 x 16) += A(16 x 4) B(4 x 16) on the matrix core, fp64 (v_mfma_f64_16x16x4_f64).  Operand mapping, verified on gfx950 by
+// tools/mfma_probe.hip: lane 16 k + i holds A[i][k], lane 16 k + j holds B[k][j]; register r of lane 16 q + j holds D[4 r + q][j].
+HADI_DEV HADI_FORCEINLINE void hadi_mfma_f64_16x16x4(double a, double b, double (&acc)[4]) {
+#if defined(HADI_EMU)
+    const int q = emu::t_lane >> 4, j = emu::t_lane & 15;
+    double av[4][4], bv[4];
+    for (int k = 0; k < 4; k++) {
+        bv[k] = __shfl(b, 16 * k + j);
+        for (int r = 0; r < 4; r++) av[r][k] = __shfl(a, 16 * k + 4 * r + q);
+    }
+    for (int r = 0; r < 4; r++)
+        for (int k = 0; k < 4; k++) acc[r] = fma(av[r][k], bv[k], acc[r]);
+#else
+    typedef double hadi_d4 __attribute__((ext_vector_type(4)));
+    hadi_d4 c = {acc[0], acc[1], acc[2], acc[3]};
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    acc[0] = c[0]; acc[1] = c[1]; acc[2] = c[2]; acc[3] = c[3];
+#endif
+}
+// Stages RT for instance `inst` (whole block; the caller's barrier follows).  R^-1 is the dense inverse of the 4 P x 4 P SPIKE
+// reduced system (hadi_setup_instance); wavefront w needs the rows of its left neighbour's last two and its right neighbour's
+// first two unknowns (spikes are zero where there is no neighbour, so any row will do there).
+HADI_DEV HADI_FORCEINLINE void hadi_pb_stage_rt(const double *__restrict__ Rg, int P, double *__restrict__ RT, int nthreads) {
+    const int n4 = 4 * P, MP = hadi_pb_mp(P);
+    for (int e = threadIdx.x; e < n4 * MP; e += nthreads) {
+        const int k = e / MP, r = e - k * MP, w = r >> 2, q = r & 3;
+        double v = 0.0;
+        if (w < P) {
+            const int rl0 = (w > 0) ? 4 * (w - 1) + 2 : 0, rr0 = (w < P - 1) ? 4 * (w + 1) : 0;
+            v = Rg[(size_t)((q < 2) ? rl0 + q : rr0 + (q - 2)) * n4 + k];
+        }
+        RT[e] = v;
+    }
+}
+
+// The column pass's LDS (whole block; the caller's barrier follows).  Returns the first free double behind it.
+//   MF:      [Z: 4 P x 64] [RT: 4 P x MP] [T: MP x 64]
+//   else:    [Z: 1 or 2 buffers of 4 P x 64] [each wavefront's four rows of the reduced inverse: P x 4 x 4 P]
+template <bool MF>
+HADI_DEV HADI_FORCEINLINE double *hadi_pb_setup_lds(HadiPassBCtx &c, double *smem, const double *__restrict__ Rg, int zbuffers) {
+    const int P = c.P, n4 = 4 * P;
+    c.zsh = smem;
+    c.RT = nullptr; c.Tsh = nullptr; c.Ri = nullptr;
+    if constexpr (MF) {
+        double *RT = smem + (size_t)n4 * 64;
+        hadi_pb_stage_rt(Rg, P, RT, 64 * P);
+        c.RT = RT;
+        c.Tsh = RT + (size_t)n4 * hadi_pb_mp(P);
+        return c.Tsh + (size_t)hadi_pb_mp(P) * 64;
+    } else {
+        double *tsh = smem + (size_t)P * zbuffers * 4 * 64;
+        double *__restrict__ rw = tsh + (size_t)c.wave * 4 * n4;
+        const int rl0 = (c.wave > 0) ? 4 * (c.wave - 1) + 2 : 0, rr0 = (c.wave < P - 1) ? 4 * (c.wave + 1) : 0;
+        for (int e = c.lane; e < 4 * n4; e += 64) {
+            const int m = e >> 2, q = e & 3;
+            rw[e] = Rg[(size_t)((q < 2) ? rl0 + q : rr0 + (q - 2)) * n4 + m];
+        }
+        c.Ri = rw;
+        return tsh + (size_t)16 * P * P;
+    }
+}
+
 // Chunk-local solve + interface exchange + spike correction of one 64-column tile held in y (no memory traffic).
 // LDSTAB: the table scalars come from an LDS copy (broadcast reads) instead of v_readlane on the register image.  The
 // streaming kernels stream tiles through eight wavefronts and are short of LDS bandwidth, not of VALU slots: readlanes there.
 // The instance-resident kernel solves ONE tile per step and waits for it: there the 594 readlanes per tile (two VALU slots
 // per scalar) are a third of the phase's instruction chain, and 165 broadcast reads replace them.
-template <bool LDSTAB = false>
+// ONEBUF: ONE exchange buffer instead of two alternating ones -- a second block-wide barrier in front of the exchange
+// write keeps a fast wavefront from overwriting values a slow one still reads (hadi_pass_b2: the LDS of the second buffer
+// holds prefetched rows there).
+#ifndef HADI_PB_MF
+#define HADI_PB_MF 1  // the streaming column kernels run the reduced system on the matrix core (0: the broadcast-operand FMA loop, for A/B builds)
+#endif
+// MF: the reduced system t = R^-1 z on the MATRIX CORE.  Every wavefront needs four rows of T = R Z (its own four coefficient
+// rows times the 4 P x 64 exchange values of the tile's 64 columns): together the block computes a dense (4 P) x (4 P) x 64
+// product per tile.  As 4 x 4 P broadcast-operand FMAs per lane that product was two thirds of the whole solve -- every FMA
+// pulled a wave-uniform coefficient through the LDS return path (two broadcast ds_read_b128 per exchange row and wavefront:
+// 2.5 MB per 16-chunk tile, ~8 us of LDS pipe per tile against ~1.7 us of arithmetic; gpurun_out/r04g/colpass_ab.txt: the
+// 1024x512 column pass 0.136 -> 0.112 ms per launch with the loop removed).  Here wavefront w computes the 16 x 16 block
+// (w / 4, w % 4) of T with P v_mfma_f64_16x16x4_f64 (operands: one double per lane each, conflict-free ds_read_b64), writes it
+// to LDS, and after a second barrier every wavefront picks its four rows.  ONE exchange buffer: the two barriers of a tile
+// order every reuse.  The stencil sweep itself stays on the vector units; this is the one dense contraction of the scheme.
+template <bool LDSTAB = false, bool ONEBUF = false, bool MF = false>
 HADI_DEV HADI_FORCEINLINE void hadi_pb_solve(const HadiPassBCtx &c, int parity, double (&y)[HADI_LC], int younger = 0) {
 #undef HADI_PB_T
 #if defined(HADI_EMU)
@@ -2481,7 +2569,8 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve(const HadiPassBCtx &c, int parity, 
         // interface exchange.  Two LDS buffers alternate by tile parity, so one barrier per tile is
         // enough: a wave can only overwrite buffer b two tiles later, after every wave has passed the
         // barrier of the tile in between, i.e. has finished reading b.
-        double *__restrict__ z = c.zsh + (size_t)parity * P * 4 * 64;
+        double *__restrict__ z = c.zsh + (size_t)((ONEBUF || MF) ? 0 : parity) * P * 4 * 64;
+        if constexpr (ONEBUF && !MF) __syncthreads();  // every wavefront has read the previous tile's exchange values
         z[(c.wave * 4 + 0) * 64 + c.lane] = y[0];
         z[(c.wave * 4 + 1) * 64 + c.lane] = y[1];
         z[(c.wave * 4 + 2) * 64 + c.lane] = y[HADI_LC - 2];
@@ -2490,15 +2579,34 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve(const HadiPassBCtx &c, int parity, 
         HADI_STAMPB(19);  // exchange + barrier
         // t = Rinv z : this chunk needs the previous chunk's last two and the next chunk's first two
         const int n4 = 4 * P;
-        const double *__restrict__ Ri = c.Ri;
         double tl0 = 0.0, tl1 = 0.0, tr0 = 0.0, tr1 = 0.0;
+        if constexpr (MF) {
+            const int MP = hadi_pb_mp(P), nblk = MP >> 2;  // (MP / 16 row blocks x 4 column blocks)
+            const int kq = c.lane >> 4, ij = c.lane & 15;
+            for (int blk = c.wave; blk < ((c.debug & HADI_DEBUG_COL_NO_REDUCED) ? 0 : nblk); blk += P) {
+                const int bi = blk >> 2, bj = blk & 3;
+                const double *__restrict__ ap = c.RT + kq * MP + 16 * bi + ij;
+                const double *__restrict__ bp = z + kq * 64 + 16 * bj + ij;
+                double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int sK = 0; sK < P; sK++) hadi_mfma_f64_16x16x4(ap[(size_t)sK * 4 * MP], bp[(size_t)sK * 4 * 64], acc);
+#pragma unroll
+                for (int r = 0; r < 4; r++) c.Tsh[(16 * bi + 4 * r + kq) * 64 + 16 * bj + ij] = acc[r];
+            }
+            __syncthreads();
+            tl0 = c.Tsh[(4 * c.wave + 0) * 64 + c.lane];
+            tl1 = c.Tsh[(4 * c.wave + 1) * 64 + c.lane];
+            tr0 = c.Tsh[(4 * c.wave + 2) * 64 + c.lane];
+            tr1 = c.Tsh[(4 * c.wave + 3) * 64 + c.lane];
+        } else {
+            const double *__restrict__ Ri = c.Ri;
 #pragma unroll 8
-        for (int m = 0; m < n4; m++) {
-            const double zz = z[m * 64 + c.lane];
-            tl0 = fma(Ri[4 * m + 0], zz, tl0);
-            tl1 = fma(Ri[4 * m + 1], zz, tl1);
-            tr0 = fma(Ri[4 * m + 2], zz, tr0);
-            tr1 = fma(Ri[4 * m + 3], zz, tr1);
+            for (int m = 0; m < ((c.debug & HADI_DEBUG_COL_NO_REDUCED) ? 0 : n4); m++) {
+                const double zz = z[m * 64 + c.lane];
+                tl0 = fma(Ri[4 * m + 0], zz, tl0);
+                tl1 = fma(Ri[4 * m + 1], zz, tl1);
+                tr0 = fma(Ri[4 * m + 2], zz, tr0);
+                tr1 = fma(Ri[4 * m + 3], zz, tr1);
+            }
         }
         HADI_STAMPB(20);  // reduced system
         // spikes are zero where there is no neighbour (first chunk: V = 0, last chunk: W = 0)
@@ -2515,11 +2623,11 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve(const HadiPassBCtx &c, int parity, 
 // is refilled with the same row of tile `ctile + 1` right behind its store, so one register buffer serves both
 // tiles and the loads of the next tile are in flight as soon as the stores have been issued.
 template <int AMER, bool RELOAD, class T = double>
-HADI_DEV HADI_FORCEINLINE void hadi_pb_store(const HadiPassBCtx &c, int ctile, double (&y)[HADI_LC]) {
+HADI_DEV HADI_FORCEINLINE void hadi_pb_store(const HadiPassBCtx &c, int ctile, double (&y)[HADI_LC], int next_tile = -1) {
     static_assert(sizeof(T) == 8 || AMER == 0, "the fp32-state sweep is European only");
     constexpr unsigned ES = (unsigned)sizeof(T);
     HADI_STAMP_DECL(c.stamp_acc_)
-    const int coln = (ctile + 1) * 64 + c.lane;
+    const int coln = (next_tile < 0 ? ctile + 1 : next_tile) * 64 + c.lane;
     const unsigned voffn = (unsigned)(coln < c.rowp ? coln : c.rowp - 1) * ES;
     const int col = ctile * 64 + c.lane;
     const bool valid = col < c.rowp;
@@ -2635,21 +2743,43 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_store_am(const HadiPassBCtx &c, int ctile
 template <int AMER, class T = double>
 HADI_DEV HADI_FORCEINLINE void hadi_pb_solve_store(const HadiPassBCtx &c, int ctile, int parity, double (&y)[HADI_LC],
                                                    int younger = 0) {
-    hadi_pb_solve(c, parity, y, younger);
+    if (!(c.debug & HADI_DEBUG_COL_NO_SOLVE)) hadi_pb_solve<false, false, HADI_PB_MF != 0>(c, parity, y, younger);
     hadi_pb_store<AMER, false, T>(c, ctile, y);
 }
 
-// Column tiles [t0, t1) of block `grp` of an instance.  The pitch is 64*B*G + pad, so the last tile is always a SHORT one
-// (8..32 columns: little traffic, but a full solve).  The full tiles are dealt out btpw per block and the short tile rides
-// with the last block, which is the one that may hold fewer full tiles (1024x512: 16 full tiles on 4 blocks = 4,4,4,4+short
-// instead of 5,5,5,2 -- the launch takes 4.3 tile times instead of 5).  With btpw = 1 and one block more than full tiles the
-// short tile gets a block of its own (the one-tile-per-block geometry of the small-chunk grids).
-HADI_DEV HADI_FORCEINLINE void hadi_pb_tile_range(const HadiSweepArgs &a, int grp, int &t0, int &t1) {
+// Column tiles of block `grp` of an instance.  The pitch is 64*B*G + pad, so the last tile is always a SHORT one (8..32
+// columns: little traffic, but a full solve).  The full tiles are dealt out btpw per block and the short tile rides with the
+// last block, which is the one that may hold fewer full tiles (1024x512: 16 full tiles on 4 blocks = 4,4,4,4+short instead of
+// 5,5,5,2 -- the launch takes 4.3 tile times instead of 5).  With btpw = 1 and one block more than full tiles the short tile
+// gets a block of its own (the one-tile-per-block geometry of the small-chunk grids).
+// Which full tiles: consecutive ones (block g: g btpw .. g btpw + btpw - 1), or INTERLEAVED (tile_il: block g: g, g + G, g + 2 G,
+// ... with G blocks holding full tiles).  The blocks of an instance sit on one XCD in consecutive dispatch slots and walk their
+// tiles at the same pace, so interleaved they read -- and write -- G ADJACENT 512-byte segments of every v-row at about the
+// same time (one 2 KB piece of a DRAM page per row instead of four pieces 2 KB apart).
+struct HadiTileSet {
+    int first, stride, nfull_mine, cnt, short_tile;  // tile(i) = i < nfull_mine ? first + i stride : short_tile
+};
+HADI_DEV HADI_FORCEINLINE HadiTileSet hadi_pb_tiles(const HadiSweepArgs &a, int grp) {
     const int nfull = a.L.rowp >> 6;
-    t0 = grp * a.btpw;
+    HadiTileSet ts;
+    ts.short_tile = nfull;
+    int t0 = grp * a.btpw;
     if (t0 > nfull) t0 = nfull;
-    t1 = (grp == a.bgroups - 1) ? a.ctiles : (t0 + a.btpw < nfull ? t0 + a.btpw : nfull);
+    const int t1 = (grp == a.bgroups - 1) ? a.ctiles : (t0 + a.btpw < nfull ? t0 + a.btpw : nfull);
+    const int has_short = (t1 > nfull) ? 1 : 0;
+    if (a.tile_il && nfull > 0) {
+        const int gf = (nfull + a.btpw - 1) / a.btpw;  // blocks that hold full tiles
+        ts.first = grp; ts.stride = gf;
+        ts.nfull_mine = grp < gf ? (nfull - grp + gf - 1) / gf : 0;
+    } else {
+        ts.first = t0; ts.stride = 1;
+        ts.nfull_mine = (t1 < nfull ? t1 : nfull) - t0;
+        if (ts.nfull_mine < 0) ts.nfull_mine = 0;
+    }
+    ts.cnt = ts.nfull_mine + has_short;
+    return ts;
 }
+HADI_DEV HADI_FORCEINLINE int hadi_pb_tile(const HadiTileSet &ts, int i) { return i < ts.nfull_mine ? ts.first + i * ts.stride : ts.short_tile; }
 
 // Dynamic LDS: P * (2*4*64 + 16*P) doubles (two interface-exchange buffers, each wavefront's four rows of the reduced
 // inverse); the chunk tables live in registers (HADI_PB_T).
@@ -2661,8 +2791,6 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
     c.lane = threadIdx.x & 63;
     c.wave = HADI_UNIFORM((int)(threadIdx.x >> 6));
     c.P = a.L.P;
-    c.zsh = smem;
-    double *__restrict__ tsh = smem + (size_t)c.P * 2 * 4 * 64;
     // blocks walk the instances in DESCENDING order: the row pass writes Y ascending, so the column pass starts on the
     // part of Y that is still in the memory-side cache (and leaves the low instances of U there for the next row pass).
     // XCD-aware: the blocks of one instance (they read the same chunk tables and reduced-inverse rows) get consecutive
@@ -2686,50 +2814,38 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
     c.P0i = AMER ? a.U0 + (size_t)inst * a.L.inst_stride : nullptr;
     c.pay1d = AMER ? (a.pay_mis[inst] == 0) : 0;
     c.inv_dt = 1.0 / ip.dt;
-    c.american = a.american;
+    c.american = a.american; c.debug = a.debug;
     c.pos_m1 = a.pos_m1;
     c.dt = ip.dt;
     c.tabl = nullptr;
-    int t0, t1;
-    hadi_pb_tile_range(a, grp, t0, t1);
+    const HadiTileSet ts = hadi_pb_tiles(a, grp);
+    const int cnt = ts.cnt;
+    auto tile = [&](int i) { return hadi_pb_tile(ts, i); };
 
 #if defined(HADI_STAMPS) && !defined(HADI_EMU)
     unsigned long long stamp_store_[32] = {0};
     c.stamp_acc_ = stamp_store_;
 #endif
     double ya[HADI_LC], yb[HADI_LC];
-    hadi_pb_load<T>(c, t0, ya);
+    hadi_pb_load<T>(c, tile(0), ya);
     const bool am_fast = (AMER == 2) || (AMER == 1 && c.pay1d != 0);  // block-uniform
     // the chunk's table (identical for every column) is spread over the lanes' registers once per block
-    {
-        hadi_pb_load_table(c, a.pb + ((size_t)inst * nrows + c.ja) * HADI_PBW);
-        // t = Rinv z needs, for this chunk, the rows of the previous chunk's last two and the next chunk's first two
-        // unknowns (spikes are zero where there is no neighbour, so any row will do there)
-        const int n4 = 4 * c.P;
-        const double *__restrict__ Rg = a.rinv + (size_t)inst * 16 * c.P * c.P;
-        double *__restrict__ rw = tsh + (size_t)c.wave * 4 * n4;
-        const int rl0 = (c.wave > 0) ? 4 * (c.wave - 1) + 2 : 0, rr0 = (c.wave < c.P - 1) ? 4 * (c.wave + 1) : 0;
-        for (int e = c.lane; e < 4 * n4; e += 64) {
-            const int m = e >> 2, q = e & 3;
-            const int row = (q < 2) ? rl0 + q : rr0 + (q - 2);
-            rw[e] = Rg[(size_t)row * n4 + m];
-        }
-        c.Ri = rw;
-    }
+    hadi_pb_load_table(c, a.pb + ((size_t)inst * nrows + c.ja) * HADI_PBW);
+    hadi_pb_setup_lds<HADI_PB_MF != 0>(c, smem, a.rinv + (size_t)inst * 16 * c.P * c.P, 2);
     __syncthreads();
     if constexpr (AMER != 0) {
         if (am_fast) {
             double po[HADI_LC];
-            for (int t = t0; t < t1; t += 2) {
-                hadi_pb_load_old<AMER>(c, t, po);  // first: it is needed before the next tile's values
-                if (t + 1 < t1) hadi_pb_load<T>(c, t + 1, yb);
-                hadi_pb_solve(c, 0, ya, 0);
-                hadi_pb_store_am<AMER>(c, t, ya, po);
-                if (t + 1 < t1) {
-                    hadi_pb_load_old<AMER>(c, t + 1, po);
-                    if (t + 2 < t1) hadi_pb_load<T>(c, t + 2, ya);
-                    hadi_pb_solve(c, 1, yb, 0);
-                    hadi_pb_store_am<AMER>(c, t + 1, yb, po);
+            for (int i = 0; i < cnt; i += 2) {
+                hadi_pb_load_old<AMER>(c, tile(i), po);  // first: it is needed before the next tile's values
+                if (i + 1 < cnt) hadi_pb_load<T>(c, tile(i + 1), yb);
+                hadi_pb_solve<false, false, HADI_PB_MF != 0>(c, 0, ya, 0);
+                hadi_pb_store_am<AMER>(c, tile(i), ya, po);
+                if (i + 1 < cnt) {
+                    hadi_pb_load_old<AMER>(c, tile(i + 1), po);
+                    if (i + 2 < cnt) hadi_pb_load<T>(c, tile(i + 2), ya);
+                    hadi_pb_solve<false, false, HADI_PB_MF != 0>(c, 1, yb, 0);
+                    hadi_pb_store_am<AMER>(c, tile(i + 1), yb, po);
                 }
             }
             return;
@@ -2741,27 +2857,27 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
     // same 3 tiles per block (a block then has all its loads in flight from the start).
     if constexpr (AMER == 0) {
         double yc[HADI_LC];
-        if (t0 + 1 < t1) hadi_pb_load<T>(c, t0 + 1, yb);
-        for (int t = t0; t < t1; t += 3) {
-            if (t + 2 < t1) hadi_pb_load<T>(c, t + 2, yc);
-            hadi_pb_solve_store<AMER, T>(c, t, (t - t0) & 1, ya, 0);
-            if (t + 1 < t1) {
-                if (t + 3 < t1) hadi_pb_load<T>(c, t + 3, ya);
-                hadi_pb_solve_store<AMER, T>(c, t + 1, (t + 1 - t0) & 1, yb, 0);
+        if (1 < cnt) hadi_pb_load<T>(c, tile(1), yb);
+        for (int i = 0; i < cnt; i += 3) {
+            if (i + 2 < cnt) hadi_pb_load<T>(c, tile(i + 2), yc);
+            hadi_pb_solve_store<AMER, T>(c, tile(i), i & 1, ya, 0);
+            if (i + 1 < cnt) {
+                if (i + 3 < cnt) hadi_pb_load<T>(c, tile(i + 3), ya);
+                hadi_pb_solve_store<AMER, T>(c, tile(i + 1), (i + 1) & 1, yb, 0);
             }
-            if (t + 2 < t1) {
-                if (t + 4 < t1) hadi_pb_load<T>(c, t + 4, yb);
-                hadi_pb_solve_store<AMER, T>(c, t + 2, (t + 2 - t0) & 1, yc, 0);
+            if (i + 2 < cnt) {
+                if (i + 4 < cnt) hadi_pb_load<T>(c, tile(i + 4), yb);
+                hadi_pb_solve_store<AMER, T>(c, tile(i + 2), (i + 2) & 1, yc, 0);
             }
         }
         return;
     }
-    for (int t = t0; t < t1; t += 2) {  // American with a payoff that depends on v: two buffers, loads inside the store loop
+    for (int i = 0; i < cnt; i += 2) {  // American with a payoff that depends on v: two buffers, loads inside the store loop
         // `younger` = vector-memory operations issued after the loads of the tile being solved (diagnostic build only)
-        if (t + 1 < t1) hadi_pb_load<T>(c, t + 1, yb);
-        hadi_pb_solve_store<AMER, T>(c, t, 0, ya, (t + 1 < t1 ? HADI_LC : 0) + (t > t0 ? HADI_LC : 0));
-        if (t + 2 < t1) hadi_pb_load<T>(c, t + 2, ya);
-        if (t + 1 < t1) hadi_pb_solve_store<AMER, T>(c, t + 1, 1, yb, (t + 2 < t1 ? HADI_LC : 0) + HADI_LC);
+        if (i + 1 < cnt) hadi_pb_load<T>(c, tile(i + 1), yb);
+        hadi_pb_solve_store<AMER, T>(c, tile(i), 0, ya, (i + 1 < cnt ? HADI_LC : 0) + (i > 0 ? HADI_LC : 0));
+        if (i + 2 < cnt) hadi_pb_load<T>(c, tile(i + 2), ya);
+        if (i + 1 < cnt) hadi_pb_solve_store<AMER, T>(c, tile(i + 1), 1, yb, (i + 2 < cnt ? HADI_LC : 0) + HADI_LC);
     }
 #if defined(HADI_STAMPS) && !defined(HADI_EMU)
     if (HADI_STAMPS == 3 && c.lane == 0)
@@ -2780,8 +2896,6 @@ __global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, in
     c.lane = threadIdx.x & 63;
     c.wave = HADI_UNIFORM((int)(threadIdx.x >> 6));
     c.P = a.L.P;
-    c.zsh = smem;
-    double *__restrict__ tsh = smem + (size_t)c.P * 2 * 4 * 64;
     // blocks walk the instances in DESCENDING order: the row pass writes Y ascending, so the column pass starts on the
     // part of Y that is still in the memory-side cache (and leaves the low instances of U there for the next row pass).
     // XCD-aware: the blocks of one instance (they read the same chunk tables and reduced-inverse rows) get consecutive
@@ -2805,43 +2919,151 @@ __global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, in
     c.P0i = AMER ? a.U0 + (size_t)inst * a.L.inst_stride : nullptr;
     c.pay1d = AMER ? (a.pay_mis[inst] == 0) : 0;
     c.inv_dt = 1.0 / ip.dt;
-    c.american = a.american;
+    c.american = a.american; c.debug = a.debug;
     c.pos_m1 = a.pos_m1;
     c.dt = ip.dt;
     c.tabl = nullptr;
-    int t0, t1;
-    hadi_pb_tile_range(a, grp, t0, t1);
+    const HadiTileSet ts = hadi_pb_tiles(a, grp);
+    const int cnt = ts.cnt;
+    auto tile = [&](int i) { return hadi_pb_tile(ts, i); };
 
 #if defined(HADI_STAMPS) && !defined(HADI_EMU)
     unsigned long long stamp_store_[32] = {0};
     c.stamp_acc_ = stamp_store_;
 #endif
     double y[HADI_LC];
-    hadi_pb_load<T>(c, t0, y);
+    hadi_pb_load<T>(c, tile(0), y);
     // the chunk's table (identical for every column) is spread over the lanes' registers once per block
-    {
-        hadi_pb_load_table(c, a.pb + ((size_t)inst * nrows + c.ja) * HADI_PBW);
-        // t = Rinv z needs, for this chunk, the rows of the previous chunk's last two and the next chunk's first two
-        // unknowns (spikes are zero where there is no neighbour, so any row will do there)
-        const int n4 = 4 * c.P;
-        const double *__restrict__ Rg = a.rinv + (size_t)inst * 16 * c.P * c.P;
-        double *__restrict__ rw = tsh + (size_t)c.wave * 4 * n4;
-        const int rl0 = (c.wave > 0) ? 4 * (c.wave - 1) + 2 : 0, rr0 = (c.wave < c.P - 1) ? 4 * (c.wave + 1) : 0;
-        for (int e = c.lane; e < 4 * n4; e += 64) {
-            const int m = e >> 2, q = e & 3;
-            const int row = (q < 2) ? rl0 + q : rr0 + (q - 2);
-            rw[e] = Rg[(size_t)row * n4 + m];
-        }
-        c.Ri = rw;
-    }
+    hadi_pb_load_table(c, a.pb + ((size_t)inst * nrows + c.ja) * HADI_PBW);
+    hadi_pb_setup_lds<HADI_PB_MF != 0>(c, smem, a.rinv + (size_t)inst * 16 * c.P * c.P, 2);
     __syncthreads();
     // (fp32 state: holding the NEXT tile in 33 float registers so that its loads fly during the solve was tried -- 66 + 33 +
     // 10 table registers leave too few of the 128 for the reduced-system loop, the kernel spills 18 registers and the
     // scratch reloads drain the prefetch: 0.088 -> 0.099 ms per launch at 1024x512 x64.)
-    for (int t = t0; t < t1; t++) {
-        hadi_pb_solve(c, (t - t0) & 1, y, 0);
-        if (t + 1 < t1) hadi_pb_store<AMER, true, T>(c, t, y);
-        else hadi_pb_store<AMER, false, T>(c, t, y);
+    for (int i = 0; i < cnt; i++) {
+        if (!(a.debug & HADI_DEBUG_COL_NO_SOLVE)) hadi_pb_solve<false, false, HADI_PB_MF != 0>(c, i & 1, y, 0);
+        if (i + 1 < cnt) hadi_pb_store<AMER, true, T>(c, tile(i), y, tile(i + 1));
+        else hadi_pb_store<AMER, false, T>(c, tile(i), y);
+    }
+#if defined(HADI_STAMPS) && !defined(HADI_EMU)
+    if (HADI_STAMPS == 3 && c.lane == 0)
+        for (int k = 16; k < 24; k++) atomicAdd(&g_hadi_stamps[k], stamp_store_[k]);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// hadi_pass_b2: the single-buffer column pass with part of the NEXT tile prefetched into LDS (9 .. 16 chunks, European).
+// hadi_pass_b1 cannot hold a second tile -- 16 wavefronts per CU leave 128 VGPRs per lane, and a 16-chunk tile is 263 KB
+// against the 512 KB of a CU's whole register file -- so it stores a tile, loads the next one behind the stores and waits:
+// every tile pays the turn-round of the memory pipe and a full load latency with nothing in flight during the solve
+// (PMC: VALU busy 0.08, waiting 0.37 of the wave cycles).  LDS-DMA needs no registers: here every wavefront fetches the first
+// NPF rows of its chunk of tile t+1 into a private LDS area BEFORE it solves tile t, so they fly during the solve and the
+// stores; only the other 33 - NPF rows are loaded into the registers behind the stores.  The LDS comes from the second
+// exchange buffer (one buffer + a second barrier per tile: hadi_pb_solve<.., ONEBUF>): 16 chunks: 32 KB exchange + 32 KB
+// reduced-inverse rows + 16 x NPF x 64 elements.  One dwordx4 DMA instruction moves 64 x 16 B = RPI rows of this tile (a row
+// is 64 columns = 512 B as doubles, 256 B as floats): RPI = 2 resp. 4 rows, lanes grouped by row.
+// Completion: the wavefront's explicit s_waitcnt vmcnt(0) behind the register loads (they are younger than the DMA and the
+// stores; everything has to be there before the solve anyway) -- no counted waits, nothing depends on the retirement order
+// of different kinds of vector-memory operations.
+template <class T, int NPF>
+HADI_DEV HADI_FORCEINLINE void hadi_pb_dma(const HadiPassBCtx &c, const T *__restrict__ Yt, int ctile, T *pf) {
+    constexpr int ES = (int)sizeof(T), EPV = 16 / ES, LPR = 64 / EPV, RPI = 64 / LPR;
+    static_assert(NPF % RPI == 0 && NPF <= HADI_LC, "whole DMA instructions");
+    const int sub = c.lane / LPR, l = c.lane - sub * LPR;
+    int col = ctile * 64 + EPV * l;
+    if (col + EPV > c.rowp) col = c.rowp - EPV;  // lanes past the pitch (short tile) fetch a valid address; their columns are never stored
+#if !defined(HADI_EMU)
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)pf);
+#endif
+#pragma unroll
+    for (int q = 0; q < NPF / RPI; q++) {
+        const unsigned row = hadi_pb_row(c, q * RPI + sub);  // (per lane: the lanes of one instruction cover RPI rows)
+#if defined(HADI_EMU)
+        for (int e = 0; e < EPV; e++) pf[(q * RPI + sub) * 64 + EPV * l + e] = Yt[(size_t)row * c.rowp + col + e];
+#else
+        const unsigned voff = (row * (unsigned)c.rowp + (unsigned)col) * (unsigned)ES;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" HADI_DMA_POLICY "\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(Yt), "s"(lds0 + 1024u * q)
+                     : "memory");
+#endif
+    }
+}
+// rows [K0, HADI_LC) of tile `ctile` into the registers (hadi_pb_load for a part of the chunk)
+template <class T, int K0>
+HADI_DEV HADI_FORCEINLINE void hadi_pb_load_from(const HadiPassBCtx &c, int ctile, double (&y)[HADI_LC]) {
+    constexpr unsigned ES = (unsigned)sizeof(T);
+    const int col = ctile * 64 + c.lane;
+    const int colc = col < c.rowp ? col : c.rowp - 1;
+    const unsigned voff = (unsigned)colc * ES;
+    const unsigned rstride = (unsigned)c.rowp * ES;
+#pragma unroll
+    for (int k = K0; k < HADI_LC; k++) y[k] = hadi_buf_load_t<T>(c.Yb, voff, hadi_pb_row(c, k) * rstride);
+}
+
+template <int MAXP, class T, int NPF>
+__global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b2(HadiSweepArgs a, int n) {
+    HADI_DYN_SMEM(double, smem);
+    HadiPassBCtx c;
+    c.lane = threadIdx.x & 63;
+    c.wave = HADI_UNIFORM((int)(threadIdx.x >> 6));
+    c.P = a.L.P;
+    const int logical = hadi_xcd_remap(blockIdx.x, gridDim.x);  // (block order and XCD placement as in hadi_pass_b)
+    if (logical >= a.n_inst * a.bgroups) return;
+    const int binst = logical / a.bgroups, grp = logical - binst * a.bgroups;
+    const int inst = a.n_inst - 1 - binst;
+    const HadiInstPar ip = a.ipar[inst];
+    if (n > ip.N) return;
+    const int nrows = a.L.nrows_pad;
+    c.nrows = a.L.nrows;
+    c.rowp = a.L.rowp;
+    c.ja = c.wave * HADI_LC;
+    c.Yi = a.Y + (size_t)inst * a.L.inst_stride;
+    c.Ui = a.U + (size_t)inst * a.L.inst_stride;
+    const T *__restrict__ Yt = reinterpret_cast<const T *>(a.Y) + (size_t)inst * a.L.inst_stride;
+    c.Yb = hadi_make_buf(Yt, (size_t)a.L.inst_stride * sizeof(T));
+    c.Ub = hadi_make_buf(reinterpret_cast<const T *>(a.U) + (size_t)inst * a.L.inst_stride, (size_t)a.L.inst_stride * sizeof(T));
+    c.Li = nullptr; c.Lb = hadi_make_buf(nullptr, 0); c.P0i = nullptr; c.pay1d = 0;
+    c.inv_dt = 1.0 / ip.dt;
+    c.american = 0; c.debug = a.debug;
+    c.pos_m1 = a.pos_m1;
+    c.dt = ip.dt;
+    c.tabl = nullptr;
+    const HadiTileSet ts = hadi_pb_tiles(a, grp);
+    const int cnt = ts.cnt;
+    auto tile = [&](int i) { return hadi_pb_tile(ts, i); };
+#if defined(HADI_STAMPS) && !defined(HADI_EMU)
+    unsigned long long stamp_store_[32] = {0};
+    c.stamp_acc_ = stamp_store_;
+#endif
+    double y[HADI_LC];
+    hadi_pb_load<T>(c, tile(0), y);
+    hadi_pb_load_table(c, a.pb + ((size_t)inst * nrows + c.ja) * HADI_PBW);
+    // ONE exchange buffer either way; this wavefront's prefetch area behind the reduced system's LDS
+    T *const pf = reinterpret_cast<T *>(hadi_pb_setup_lds<HADI_PB_MF != 0>(c, smem, a.rinv + (size_t)inst * 16 * c.P * c.P, 1)) + (size_t)c.wave * NPF * 64;
+    __syncthreads();
+    for (int i = 0; i < cnt; i++) {
+        const bool more = i + 1 < cnt;  // (block-uniform)
+        const int t = tile(i), tn = tile(more ? i + 1 : i);
+        if (more) hadi_pb_dma<T, NPF>(c, Yt, tn, pf);  // flies during the solve and the stores of tile t
+        if (!(a.debug & HADI_DEBUG_COL_NO_SOLVE)) hadi_pb_solve<false, true, HADI_PB_MF != 0>(c, 0, y, 0);
+        if (more) {
+            hadi_pb_store<0, false, T>(c, t, y);
+            hadi_pb_load_from<T, NPF>(c, tn, y);
+#if !defined(HADI_EMU)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA (older than everything above) has landed
+#endif
+            hadi_wave_rendezvous();
+#pragma unroll
+            for (int k = 0; k < NPF; k++) y[k] = (double)pf[k * 64 + c.lane];
+#if !defined(HADI_EMU)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and has been read: the next DMA may overwrite the area
+#endif
+            hadi_wave_rendezvous();
+        } else {
+            hadi_pb_store<0, false, T>(c, t, y);
+        }
     }
 #if defined(HADI_STAMPS) && !defined(HADI_EMU)
     if (HADI_STAMPS == 3 && c.lane == 0)
@@ -3023,7 +3245,7 @@ __global__ void __launch_bounds__(512, 2) hadi_team_kernel(HadiSweepArgs a, Hadi
     cb.Yb = hadi_make_buf(c.Yi, (size_t)a.L.inst_stride * sizeof(double));
     cb.Ub = hadi_make_buf(Ui, (size_t)a.L.inst_stride * sizeof(double));
     cb.Li = nullptr; cb.Lb = hadi_make_buf(nullptr, 0); cb.P0i = nullptr; cb.pay1d = 0; cb.inv_dt = 0.0;
-    cb.american = 0; cb.pos_m1 = a.pos_m1; cb.dt = ip.dt;
+    cb.american = 0; cb.debug = 0; cb.pos_m1 = a.pos_m1; cb.dt = ip.dt;
     cb.tabl = tabl + (size_t)wave * HADI_LC * HADI_PBW;
     if (wave < P) hadi_pb_load_table(cb, a.pb + ((size_t)inst * a.L.nrows_pad + cb.ja) * HADI_PBW);
 

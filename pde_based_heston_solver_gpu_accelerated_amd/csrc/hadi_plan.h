@@ -4,6 +4,10 @@
 
 #include "hadi_core.h"
 
+// hadi_pass_b2: rows of the next tile each wavefront prefetches into LDS (16 chunks: 96 KB for the reduced system -- exchange
+// values, selected inverse rows, their product -- + 16 x NPF x 64 elements = the CU's whole 160 KB)
+#define HADI_B2_NPF(ES) (HADI_PB_MF ? ((ES) == 4 ? 16 : 8) : ((ES) == 4 ? 24 : 12))
+
 struct HadiPlan {
     HadiLayout L;
     int W;               // pass A: v-rows solved concurrently by one tile group (W*G wavefronts)
@@ -19,6 +23,8 @@ struct HadiPlan {
     int btpw, bgroups;   // pass B: column tiles per block (register double-buffered), blocks per instance
     int grid_b, block_b; // pass B grid / block (P*64 threads)
     size_t smem_b;       // pass B dynamic LDS bytes
+    // 9 .. 16 chunks, European: hadi_pass_b2 -- one exchange buffer + each wavefront's prefetch area of HADI_B2_NPF(ES) rows
+    size_t smem_b2;
     int pos_m1;
     // table sizes per instance (doubles)
     size_t n_scoef, n_b2row, n_rowc, n_a2i, n_pb, n_rinv, n_rwork;
@@ -281,8 +287,11 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
     }
     p.grid_b = (n_inst * p.bgroups + 7) / 8 * 8;  // padded to a multiple of 8 for the XCD remap
     p.block_b = 64 * L.P;
-    // two interface-exchange buffers + each wavefront's four rows of the reduced inverse
-    p.smem_b = (size_t)L.P * (2 * 4 * 64 + 16 * L.P) * sizeof(double);
+    // the reduced system on the matrix core: exchange values, the selected inverse rows (transposed) and their product; the
+    // A/B build without it: two interface-exchange buffers + each wavefront's four rows of the reduced inverse
+    p.smem_b = HADI_PB_MF ? hadi_pb_mf_doubles(L.P) * sizeof(double) : (size_t)L.P * (2 * 4 * 64 + 16 * L.P) * sizeof(double);
+    p.smem_b2 = (HADI_PB_MF ? hadi_pb_mf_doubles(L.P) : (size_t)L.P * (4 * 64 + 16 * L.P)) * sizeof(double) +
+                (size_t)L.P * HADI_B2_NPF(state_bytes) * 64 * state_bytes;
     p.pos_m1 = hadi_pos(L, m1);
     p.n_scoef = (size_t)4 * 64 * L.B * L.G;
     p.n_b2row = (size_t)L.rowp;
@@ -303,23 +312,21 @@ inline int hadi_make_plan(int m1, int m2, int n_inst, int target_waves, HadiPlan
     return 0;
 }
 
-// Fraction of the row pass's CU-rounds that a launch of this plan leaves idle: blocks / (rounds x block slots of the chip).
-// The strip kernels of 8 nodes per lane hold a CU alone, every other row kernel shares it with a second block (their launch
-// bounds).  This is what decides between one and two streams (hadi_api.hip, run_sweep): a batch whose row pass fills whole
-// rounds (512x256: 64, 128, 256, 512 instances) gains nothing from a second stream and loses 2 - 12 % to two kernels that each
-// want every CU; one that leaves a partial round idle (24 - 32: 50 - 60 % idle, 96 and 192: 25 %, 160: 6 %) gains 3 - 22 %
-// when its two halves run side by side, the row pass of one on the CUs the other's partial round leaves free (measured,
-// DESIGN.md section 7).  Deterministic per (shape, batch size): the path of a call never depends on the calls before it.
+// Fraction of the row pass's CU-rounds that a STRIP launch of this plan leaves idle: blocks / (rounds x block slots of the chip).
+// A strip block of 8 nodes per lane holds a CU alone, the 4-node strips and the pair strips share it with a second block, the
+// 2-node strips with three more (their launch bounds): there a launch really runs in rounds of equal blocks, and this number
+// is what decides between one and two streams (hadi_api.hip, run_sweep).  A batch whose row pass fills whole rounds (512x256:
+// 64, 128, 256, 512 instances) gains nothing from a second stream and loses 2 - 13 % to two kernels that each want every CU;
+// one that leaves a partial round idle (512x256: 96 and 192 instances 25 %, 160: 6 %; 1024x512 x96: 25 %; 256x128 x700
+// American: 18 %) gains 2 - 23 % when its two halves run side by side, the row pass of one on the CUs the other's partial
+// round leaves free (gpurun_out/r04b/stream_sweep.log).  The shared-ring row pass (small blocks, three
+// or four per CU, the chip refilled block by block) shows no such pattern -- of 18 measured cases 13 gain up to 24 % and 5
+// lose up to 10 %, with nothing in the launch geometry that tells them apart -- and stays on one stream (0 here).
+// Deterministic per (shape, batch size): the path of a call never depends on the calls before it.
 inline double hadi_plan_row_idle(const HadiPlan &p, int n_inst, int cus) {
-    if (p.row_seq) return 0.0;
-    long long blocks, slots;
-    if (p.use_strip) {
-        blocks = (long long)n_inst * p.sblocks;
-        slots = (long long)cus * ((p.L.B == 8) ? 1 : 2);
-    } else {
-        blocks = (long long)n_inst * ((p.ntiles + p.NG - 1) / p.NG);
-        slots = (long long)cus * 2;
-    }
+    if (p.row_seq || !p.use_strip) return 0.0;
+    const int per_cu = (p.L.B == 8) ? 1 : (p.use_pairs || p.L.B == 4) ? 2 : 4;
+    const long long blocks = (long long)n_inst * p.sblocks, slots = (long long)cus * per_cu;
     if (blocks < 1 || slots < 1) return 0.0;
     const long long rounds = (blocks + slots - 1) / slots;
     return 1.0 - (double)blocks / (double)(rounds * slots);

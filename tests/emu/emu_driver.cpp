@@ -18,6 +18,8 @@ thread_local int t_lane;
 // kernel-selection overrides, the emulator's stand-in for hadi_set_tuning
 static HadiTuning g_tune;
 static int g_err = 0, g_debug = 0;  // the handle's device error word and the "debug_fault" test hook
+static int g_tile_il = 0;           // "tile_interleave": the column pass's blocks take their full tiles interleaved (opt-in, as in the library)
+static int g_col_prefetch = 0;      // "col_prefetch": hadi_pass_b2 for European sweeps of 9 .. 16 chunks (opt-in, as in the library)
 extern "C" int emu_take_error() { const int e = g_err; g_err = 0; return e; }
 extern "C" int emu_set_tuning(const char *key, int value) {
     const std::string k(key);
@@ -27,7 +29,9 @@ extern "C" int emu_set_tuning(const char *key, int value) {
     else if (k == "strip_blocks") g_tune.strip_blocks = value > 0 ? value : 0;
     else if (k == "pair_strips") g_tune.pair_strips = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "col_groups") g_tune.col_groups = value > 0 ? value : 0;
-    else if (k == "reset") { g_tune = HadiTuning(); g_debug = 0; }
+    else if (k == "col_prefetch") g_col_prefetch = value ? 1 : 0;
+    else if (k == "tile_interleave") g_tile_il = value ? 1 : 0;
+    else if (k == "reset") { g_tune = HadiTuning(); g_debug = 0; g_col_prefetch = 0; g_tile_il = 0; }
     else return 1;
     return 0;
 }
@@ -103,6 +107,7 @@ static int run_sweep_f32(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
         default: return 2;
     }
     if (pl.L.P <= 8) emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b<8, false, float>(a, n); }, pl.smem_b);
+    else if (g_col_prefetch) emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b2<16, float, HADI_B2_NPF(4)>(a, n); }, pl.smem_b2);
     else emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b1<16, false, float>(a, n); }, pl.smem_b);
     return 0;
 }
@@ -151,6 +156,7 @@ static void run_col_pass(const HadiPlan &pl, const HadiSweepArgs &a, int n) {
         else emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b<8, false>(a, n); }, pl.smem_b);
     } else {
         if (a.american) emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b1<16, true>(a, n); }, pl.smem_b);
+        else if (g_col_prefetch) emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b2<16, double, HADI_B2_NPF(8)>(a, n); }, pl.smem_b2);
         else emu::launch(pl.grid_b, pl.block_b, [&]() { hadi_pass_b1<16, false>(a, n); }, pl.smem_b);
     }
 }
@@ -173,6 +179,18 @@ extern "C" int emu_plan_full(int m1, int m2, int n_inst, int target_waves, long 
     o[19] = pl.ctiles; o[20] = pl.btpw; o[21] = pl.bgroups; o[22] = pl.grid_b; o[23] = (long long)pl.smem_b;
     o[24] = pl.use_pairs; o[25] = (long long)pl.smem_pairs_amp;
     return 0;
+}
+
+// the column tiles block `grp` of an instance walks, in order (hadi_pb_tiles); returns their number
+extern "C" int emu_col_tiles(int m1, int m2, int n_inst, int target_waves, int interleave, int grp, int *out /*[ctiles]*/) {
+    HadiPlan pl;
+    if (hadi_make_plan(m1, m2, n_inst, target_waves, &pl, g_tune)) return -1;
+    HadiSweepArgs a{};
+    a.L = pl.L; a.ctiles = pl.ctiles; a.btpw = pl.btpw; a.bgroups = pl.bgroups; a.tile_il = interleave;
+    if (grp >= pl.bgroups) return -2;
+    const HadiTileSet ts = hadi_pb_tiles(a, grp);
+    for (int i = 0; i < ts.cnt; i++) out[i] = hadi_pb_tile(ts, i);
+    return ts.cnt;
 }
 
 // the fraction of its CU-rounds the plan's row pass leaves idle (decides one or two streams: hadi_plan_row_idle), x 1e6
@@ -226,7 +244,7 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
     HadiSweepArgs a;
     a.U = dU.data(); a.Y = dY.data(); a.LAM = american ? dLAM.data() : nullptr; a.U0 = american ? dU0.data() : nullptr;
     a.scoef = scoef.data(); a.b2row = b2row.data(); a.rowc = rowc.data(); a.pb = pb.data(); a.rinv = rinv.data();
-    a.ipar = ipar.data(); a.L = L; a.n_inst = n_inst; a.R = pl.R; a.ntiles = pl.ntiles; a.ctiles = pl.ctiles; a.btpw = pl.btpw; a.bgroups = pl.bgroups;
+    a.ipar = ipar.data(); a.L = L; a.n_inst = n_inst; a.R = pl.R; a.ntiles = pl.ntiles; a.ctiles = pl.ctiles; a.btpw = pl.btpw; a.bgroups = pl.bgroups; a.tile_il = g_tile_il;
     a.american = american; a.pos_m1 = pl.pos_m1; a.RS = pl.RS; a.sblocks = pl.sblocks;
     a.err = &g_err; a.debug = g_debug;
     std::vector<int> pay_mis(n_inst, 0);

@@ -81,8 +81,21 @@ def test_dividends_and_chunked_column_pass(emu):
 def test_single_buffer_column_pass_for_more_than_8_chunks(emu):
     # m2 = 270 -> 271 v-rows -> 9 chunks -> the 16-wave single-buffer kernel; few blocks per instance so that a block
     # walks several column tiles (store + reload of the same registers), American adds the projection
-    _run(emu, 140, 270, 2, [100.0], O.EU, 1)
     _run(emu, 130, 265, 2, [97.0], O.AM, 1, r_f=0.01)
+    # European sweeps: hadi_pass_b2 (12 rows of the next tile prefetched into LDS, 24 with the fp32 state; one exchange buffer)
+    # and, with the prefetch switched off, hadi_pass_b1; 9 and 16 chunks, a short last tile, a block of one tile
+    for pf in (1, 0):
+        emu.emu_set_tuning(b"col_prefetch", pf)
+        emu.emu_set_tuning(b"tile_interleave", pf)  # (with it: the blocks take their full tiles interleaved)
+        try:
+            _run(emu, 140, 270, 2, [100.0], O.EU, 1)
+            if pf:
+                _run(emu, 130, 500, 2, [100.0, 96.0], O.EU, 1, r_f=0.01)
+                _run(emu, 200, 270, 2, [100.0], O.EU, 1, scheme=2)
+                _run(emu, 64, 300, 2, [103.0], O.EU, 8)
+                _run(emu, 300, 150, 2, [100.0], O.AM, 1)  # interleaved tiles on the double-buffered kernel (5 chunks, American)
+        finally:
+            emu.emu_set_tuning(b"reset", 0)
 
 
 def test_strip_row_pass(emu):
@@ -248,6 +261,22 @@ def test_plan_invariants_over_shapes_and_batch_sizes(emu):
                     assert t0 == nxt and t1 > t0, (m1, m2, n, btpw, bgroups, grp)
                     nxt = t1
                 assert nxt == ctiles
+                # ... and so do the tile lists the kernels walk (hadi_pb_tiles), consecutive and interleaved: every tile once,
+                # the short tile last in its block, the blocks' loads differing by at most one full tile
+                tl = (C.c_int * 64)()
+                for il in (0, 1):
+                    seen, sizes = [], []
+                    for grp in range(bgroups):
+                        k = emu.emu_col_tiles(m1, m2, n, tw, il, grp, tl)
+                        assert k >= 1, (m1, m2, n, il, grp, k)
+                        mine = list(tl[:k])
+                        assert all(t < nfull for t in mine[:-1]) and mine == sorted(mine)
+                        seen += mine
+                        sizes.append(sum(1 for t in mine if t < nfull))
+                    assert sorted(seen) == list(range(ctiles)), (m1, m2, n, il, seen)
+                    if il:
+                        full_sizes = [z for z in sizes if z]
+                        assert max(full_sizes) - min(full_sizes) <= 1 if full_sizes else True
                 if (m1, m2, n, tw) == (1024, 512, 64, 2048):  # config 5: 16 full tiles on 4 blocks, the short one appended
                     assert (btpw, bgroups) == (4, 4)
                 assert grid_b == (n * bgroups + 7) // 8 * 8 and smem_b <= LDS and P <= 16
@@ -268,7 +297,7 @@ def test_automatic_two_stream_choice_follows_the_idle_rounds_of_the_row_pass(emu
         assert idle(512, 256, n) < 0.04, (n, idle(512, 256, n))
     for n, want in ((160, 0.0625), (192, 0.25), (96, 0.25)):
         assert abs(idle(512, 256, n) - want) < 1e-6, (n, idle(512, 256, n))
-    assert idle(512, 256, 32) >= 0.04 and idle(512, 256, 24) >= 0.04  # (the shared ring's launches are quantised as well)
+    assert idle(512, 256, 32) == 0.0 and idle(512, 256, 24) == 0.0  # shared-ring row pass: no rounds of equal blocks, one stream
     assert idle(256, 128, 512) < 0.04   # config 3: 512 pair-strip blocks, two per CU
     assert idle(1024, 512, 64) < 0.04   # config 5: 256 paired-strip blocks
     assert idle(1024, 512, 48) >= 0.04  # ... three quarters of a round

@@ -909,6 +909,43 @@ def test_small_grid_kernel_on_a_batch_larger_than_two_per_cu(solver, seq):
         _assert_field(U[rows], Uo)
 
 
+@pytest.mark.parametrize("m1,m2,N,n,variant,fp32", [(1024, 512, 3, 6, "EU", False), (1024, 512, 3, 5, "EU", True), (300, 270, 4, 3, "DIV", False),
+                                                     (600, 400, 3, 40, "EU", False), (512, 256, 4, 20, "EU", False), (512, 256, 4, 9, "AM", False),
+                                                     (256, 128, 24, 11, "AM_DIV", False)])
+def test_column_pass_alternatives_prefetch_and_interleaved_tiles(solver, m1, m2, N, n, variant, fp32):
+    """The two opt-in alternatives of the column pass (round 4, both measured neutral: profiles/r04_colpass_ab.txt): "col_prefetch"
+    -- hadi_pass_b2, European sweeps of 9 .. 16 chunks with the first 12 (fp32 state: 24) rows of the next tile prefetched into
+    LDS by LDS-DMA and ONE exchange buffer -- and "tile_interleave" -- the blocks of an instance take their full column tiles
+    interleaved, on every column kernel.  Same arithmetic on the same data: bit-identical to the default path, which is
+    checked against the oracle."""
+    strikes = Cm.strikes_for(n)
+    grids, U0 = _batch(m1, m2, strikes)
+    v = getattr(H, variant)
+    american = v in (H.AM, H.AM_DIV)
+    res = {}
+    for alt in (0, 1):
+        solver.set_tuning("col_prefetch", alt)
+        solver.set_tuning("tile_interleave", alt)
+        try:
+            U, lam = U0.copy(), np.zeros_like(U0)
+            solver.DO_timestepping(m1, m2, N, Cm.T / 500, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U, variant=v,
+                                   U_0=U0, lambda_bar=lam if american else None,
+                                   dividends=H.Dividends(*Cm.DIVS) if v in (H.DIV, H.AM_DIV) else None,
+                                   state_precision=H.STATE_FP32 if fp32 else H.STATE_FP64)
+            res[alt] = (U, lam, solver.describe_last_sweep())
+        finally:
+            solver.set_tuning("col_prefetch", 0)
+            solver.set_tuning("tile_interleave", 0)
+    assert ("hadi_pass_b2" in res[1][2]) == (m2 > 263 and not american), res[1][2]
+    assert "hadi_pass_b2" not in res[0][2]
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    p = O.make_params(m1, m2, N, Cm.T / 500, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, getattr(O, variant),
+                      Cm.DIVS if v in (H.DIV, H.AM_DIV) else None, state_fp32=1 if fp32 else 0)
+    rows = np.array(sorted({0, n // 2, n - 1}))
+    Uo, _, _ = O.solve_batch(p, grids.Vec_s[rows], grids.Vec_v[rows], grids.Delta_s[rows], grids.Delta_v[rows], U0[rows], U0[rows])
+    assert np.abs(res[1][0][rows] - Uo).max() <= (2e-7 * N if fp32 else FIELD_RTOL) * np.abs(Uo).max()
+
+
 def test_describe_last_sweep_names_the_kernels(solver):
     _hadi_solve(solver, 50, 25, 4, [100.0], H.EU)
     assert "hadi_small_kernel<1,8,EU>" in solver.describe_last_sweep()

@@ -62,6 +62,17 @@ CASES = {
     "c3_256": ["--workload", "c3", "--instances", "256"], "c3_1024": ["--workload", "c3", "--instances", "1024"],
     "c3_t2p1": ["--workload", "c3", "--tuning", "streams=2", "--tuning", "pair_strips=1"],
     "c3_1024_t2": ["--workload", "c3", "--instances", "1024", "--tuning", "streams=2"],
+    "c5f64_pf0": ["--workload", "c5", "--state", "fp64", "--tuning", "col_prefetch=0"], "c5_pf0": ["--workload", "c5", "--tuning", "col_prefetch=0"],
+    "c5f64_128": ["--workload", "c5", "--state", "fp64", "--instances", "128", "--timesteps", "500"],
+    "c5f64_128_pf0": ["--workload", "c5", "--state", "fp64", "--instances", "128", "--timesteps", "500", "--tuning", "col_prefetch=0"],
+    "g700x300": ["--workload", "c2", "--m1", "700", "--m2", "300", "--timesteps", "500", "--instances", "128"],
+    "g700x300_pf0": ["--workload", "c2", "--m1", "700", "--m2", "300", "--timesteps", "500", "--instances", "128", "--tuning", "col_prefetch=0"],
+    **{"%s_il0" % nm: base + ["--tuning", "tile_interleave=0"] for nm, base in {
+        "c2": ["--workload", "c2"], "c3": ["--workload", "c3"], "c5": ["--workload", "c5"], "c5f64": ["--workload", "c5", "--state", "fp64"],
+        "c2_64": ["--workload", "c2", "--instances", "64"], "c2_128": ["--workload", "c2", "--instances", "128"],
+        "c2am": ["--workload", "c3", "--m1", "512", "--m2", "256", "--timesteps", "1000", "--instances", "256"],
+        "g700x300": ["--workload", "c2", "--m1", "700", "--m2", "300", "--timesteps", "500", "--instances", "128"],
+        "c5f64_pf0": ["--workload", "c5", "--state", "fp64", "--tuning", "col_prefetch=0"]}.items()},
     "c2ring": ["--workload", "c2", "--tuning", "strip=0"], "c2am": ["--workload", "c3", "--m1", "512", "--m2", "256", "--timesteps", "1000", "--instances", "256"], "c5": ["--workload", "c5"], "c5f64": ["--workload", "c5", "--state", "fp64"], "c4": ["--workload", "c4"],
 }
 argv = sys.argv[1:]
@@ -81,7 +92,7 @@ for name, lib in [(n, l) for n in (argv or ["c2"]) for _ in range(reps) for l in
     if not line:
         print(name, "FAILED", out.stderr[-800:]); continue
     d = json.loads(line[-1]); r = d["roofline"]
-    pb = r.get("pass_b") or {}; sw = r.get("sweep") or {}
+    pa = r.get("pass_a") or {}; pb = r.get("pass_b") or {}; sw = r.get("sweep") or {}
     print("%-16s value %.4e  row %.5f ms (%.3f)  col %.5f ms (%.3f)  sweep %.3f | %s" % (
-        name, d["value"], r.get("avg_launch_ms") or 0, r["frac"], pb.get("avg_launch_ms") or 0, pb.get("frac") or 0, sw.get("frac") or 0,
-        r["kernel"][:60]), flush=True)
+        name, d["value"], pa.get("avg_launch_ms") or 0, pa.get("frac") or 0, pb.get("avg_launch_ms") or 0, pb.get("frac") or 0, sw.get("frac") or 0,
+        (r.get("kernels") or r["kernel"])[:100]), flush=True)
