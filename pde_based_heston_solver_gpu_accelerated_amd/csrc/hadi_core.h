@@ -211,7 +211,10 @@ enum { RC_V = 0, RC_WM = 1, RC_WZ = 2, RC_WP = 3, RC_L2 = 4, RC_L1 = 5, RC_M = 6
 // pb columns: forward  y_k = (rhs_k - PB_L y_{k-1} - PB_L2 y_{k-2}) * PB_Q
 //             backward x_k = y_k - PB_C x_{k+1} - PB_C2 x_{k+2}
 //             spikes   x_k -= PB_V0 tl0 + PB_V1 tl1 + PB_W0 tr0 + PB_W1 tr1
-enum { PB_L = 0, PB_L2 = 1, PB_Q = 2, PB_C = 3, PB_C2 = 4, PB_V0 = 5, PB_V1 = 6, PB_W0 = 7, PB_W1 = 8 };
+// The column kernels run the forward sweep as y_k = fma(-PB_LQ, y_{k-1}, fma(-PB_L2Q, y_{k-2}, rhs_k PB_Q)) with the scaled
+// multipliers PB_LQ = PB_L PB_Q, PB_L2Q = PB_L2 PB_Q: ONE operation of the step depends on the step before instead of three
+// (and the backward sweep as fma(-PB_C, x_{k+1}, fma(-PB_C2, x_{k+2}, y_k)): one instead of two).
+enum { PB_L = 0, PB_L2 = 1, PB_Q = 2, PB_C = 3, PB_C2 = 4, PB_V0 = 5, PB_V1 = 6, PB_W0 = 7, PB_W1 = 8, PB_LQ = 9, PB_L2Q = 10 };
 
 struct HadiNoSync { HADI_HD void operator()() const {} };
 
@@ -320,6 +323,7 @@ HADI_HD inline void hadi_setup_instance(const HadiLayout &L, const HadiSetupIn &
             const double c2 = uu2 * q;
             pb[PB_L] = Lk; pb[PB_L2] = e2; pb[PB_Q] = q; pb[PB_C] = c; pb[PB_C2] = c2;
             for (int z = PB_V0; z < HADI_PBW; z++) pb[z] = 0.0;
+            pb[PB_LQ] = Lk * q; pb[PB_L2Q] = e2 * q;
             c0 = c1; c20 = c21; c1 = c; c21 = c2;
         }
     }

@@ -2420,7 +2420,8 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_load_table(HadiPassBCtx &c, const double 
     for (int q = 0; q < 5; q++) {
         const int e = c.lane + 64 * q;
         const int k = e / 9, m = e - k * 9;
-        c.tab[q] = (k < HADI_LC) ? pbg[(size_t)k * HADI_PBW + m] : 0.0;
+        // (image positions 0, 1 hold the SCALED forward multipliers PB_LQ, PB_L2Q: the kernels never use the raw ones)
+        c.tab[q] = (k < HADI_LC) ? pbg[(size_t)k * HADI_PBW + (m == PB_L ? PB_LQ : m == PB_L2 ? PB_L2Q : m)] : 0.0;
 #if defined(HADI_EMU)
         emu::t_wave->pub[q][c.lane] = c.tab[q];
 #endif
@@ -2545,7 +2546,11 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve(const HadiPassBCtx &c, int parity, 
         double ym1 = 0.0, ym2 = 0.0;
 #pragma unroll
         for (int k = 0; k < HADI_LC; k++) {
-            const double yk = (y[k] - HADI_PB_T(c, k, PB_L) * ym1 - HADI_PB_T(c, k, PB_L2) * ym2) * HADI_PB_T(c, k, PB_Q);
+            // (scaled multipliers: one operation on the dependent chain; LDSTAB reads table slots, the register image keeps the
+            // scaled pair in positions PB_L, PB_L2)
+            const double lq = LDSTAB ? c.tabl[k * HADI_PBW + PB_LQ] : HADI_PB_T(c, k, PB_L);
+            const double l2q = LDSTAB ? c.tabl[k * HADI_PBW + PB_L2Q] : HADI_PB_T(c, k, PB_L2);
+            const double yk = fma(-lq, ym1, fma(-l2q, ym2, y[k] * HADI_PB_T(c, k, PB_Q)));
             y[k] = yk;
             ym2 = ym1;
             ym1 = yk;
@@ -2557,7 +2562,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_solve(const HadiPassBCtx &c, int parity, 
         double xp1 = 0.0, xp2 = 0.0;
 #pragma unroll
         for (int k = HADI_LC - 1; k >= 0; k--) {
-            const double xk = y[k] - HADI_PB_T(c, k, PB_C) * xp1 - HADI_PB_T(c, k, PB_C2) * xp2;
+            const double xk = fma(-HADI_PB_T(c, k, PB_C), xp1, fma(-HADI_PB_T(c, k, PB_C2), xp2, y[k]));
             y[k] = xk;
             xp2 = xp1;
             xp1 = xk;
