@@ -86,6 +86,25 @@ def init_distributed(args, torch, dev_index):
     return dist, None, "gloo (rccl unavailable%s)" % (": " + why if why else "")
 
 
+VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 4.0   # MI355X: 256 CUs x 4 SIMDs, one fp64 wave-instruction per 4 cycles at 2.4 GHz
+
+
+def valu_issue_bound(seconds_per_iteration, n_gpus=1):
+    """The bound of the LDS-resident small-grid kernels (config 4): fp64 VALU issue.  Wave-instructions of one LM iteration
+    (rocprofv3 --pmc SQ_INSTS_VALU over all hadi_small_* dispatches, committed in profiles/pmc_traffic.json by
+    tools/profile_c4_pmc.sh -- a lookup, not a measurement of this run) over the iteration's WALL time, against the chip's
+    issue rate of one wave-instruction per SIMD every 4 cycles."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["c4:50x25x500"]
+    except Exception:  # noqa: BLE001
+        return None
+    n = rec["valu_wave_instructions_per_iteration"]
+    ach = n / seconds_per_iteration / n_gpus
+    return {"bound": "fp64 VALU issue", "valu_wave_instructions_per_iteration": n, "achieved": ach, "peak": VALU_PEAK_WAVE_INSTS,
+            "unit": "wave-instructions/s per GPU", "frac": round(ach / VALU_PEAK_WAVE_INSTS, 4), "source": rec.get("source"),
+            "note": "wall time of the whole iteration (both launches, setup, host glue); the kernels' own share is higher"}
+
+
 def surface_points(H):
     """50 strikes x 10 maturities, N_m = max(20, 20 T_m) (heston_calibration.cpp:2485-2531)."""
     mats = [1.0 + i * 0.25 if i < 8 else 3.0 + (i - 8) * 0.5 for i in range(10)]
@@ -389,7 +408,9 @@ def main():
             roofline = {"bound": "hbm", "kernel": path, "achieved": round(value * 32.0 / 1e9 / n_gpus, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(value * 32.0 / 1e9 / n_gpus / HBM_PEAK_GBS, 4), "traffic": None,
                         "note": "LDS-resident kernel: the whole time loop of an instance runs out of LDS, HBM sees the state twice "
-                                "per SOLVE; `achieved` is the EFFECTIVE rate at 32 B per point-step, not HBM traffic"}
+                                "per SOLVE; `achieved` is the EFFECTIVE rate at 32 B per point-step, not HBM traffic -- the bound that "
+                                "applies is `valu_issue`"}
+            roofline["valu_issue"] = valu_issue_bound(elapsed / args.steps, n_gpus)
             price_check = {"strike": strikes[0], "price": state_holder["price"], "trial_error": state_holder.get("err")}
 
         if wl == "c2" and extras:
@@ -443,7 +464,7 @@ def main():
             others["c4"] = {"workload": "one LM iteration on the 500-option surface (50 strikes x 10 maturities, 50x25 grids): 3000-solve "
                                         "Jacobian + device-side normal equations + 500 trial solves",
                             "ms_per_iteration": round(best4 * 1e3, 3), "value": units4 / best4, "unit": "point-steps/s",
-                            "kernels": solver.describe_last_sweep(), "trial_error": hold4.get("err"),
+                            "kernels": solver.describe_last_sweep(), "trial_error": hold4.get("err"), "valu_issue": valu_issue_bound(best4),
                             "note": "LDS-resident kernels: no HBM roofline applies (the state crosses HBM twice per SOLVE)"}
 
             # ---- the reference's own perf harness (src/perfomance_test.cpp:20-230): 50x25 grid, N = 20, every strike 85,

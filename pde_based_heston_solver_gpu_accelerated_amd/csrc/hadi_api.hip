@@ -819,7 +819,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         HadiTeamArgs ta;
         ta.form = ptr<int>(c->team); ta.bar = ptr<int>(c->team) + 64; ta.nb = c->cu_count / 8; ta.N = d.Nmax;
         ta.stamps = reinterpret_cast<unsigned long long *>(ptr<int>(c->team) + 384);
-        const size_t smem = ((size_t)4 * 64 * L.B + (size_t)L.P * 2 * 4 * 64 + (size_t)L.P * 16 * L.P + (size_t)L.P * HADI_LC * HADI_PBW) * sizeof(double) + 64;
+        const size_t smem = ((size_t)4 * 64 * L.B + hadi_pb_mf_doubles(L.P) + (size_t)L.P * HADI_LC * HADI_PBW) * sizeof(double) + 64;
         if (L.B == 8) hipLaunchKernelGGL((hadi_team_kernel<8>), dim3(c->cu_count), dim3(512), smem, s, a, ta);
         else hipLaunchKernelGGL((hadi_team_kernel<4>), dim3(c->cu_count), dim3(512), smem, s, a, ta);
         HIP_TRY(c, hipGetLastError());

@@ -203,6 +203,10 @@ template <class T>
 HADI_DEV HADI_FORCEINLINE double hadi_buf_load_t(HadiBuf b, unsigned voff_bytes, unsigned soff_bytes) {
     return (double)*reinterpret_cast<const T *>(static_cast<const char *>(b.p) + voff_bytes + soff_bytes);
 }
+HADI_DEV HADI_FORCEINLINE double hadi_buf_load_sc1(HadiBuf b, unsigned voff_bytes, unsigned soff_bytes) { return hadi_buf_load(b, voff_bytes, soff_bytes); }
+HADI_DEV HADI_FORCEINLINE void hadi_buf_load2_sc1(HadiBuf b, unsigned voff_bytes, unsigned soff_bytes, double &x, double &y) {
+    x = hadi_buf_load(b, voff_bytes, soff_bytes); y = hadi_buf_load(b, voff_bytes + 8, soff_bytes);
+}
 template <class T>
 HADI_DEV HADI_FORCEINLINE void hadi_buf_store_t(HadiBuf b, unsigned voff_bytes, unsigned soff_bytes, double v) {
     if (voff_bytes >= 0x80000000u) return;
@@ -225,6 +229,19 @@ HADI_DEV HADI_FORCEINLINE HadiBuf hadi_make_buf(const void *base, size_t bytes) 
 HADI_DEV HADI_FORCEINLINE double hadi_buf_load(HadiBuf b, unsigned voff_bytes, unsigned soff_bytes) {
     const hadi_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(b.r, voff_bytes, soff_bytes, HADI_AUX_NT);
     return __hiloint2double((int)v.y, (int)v.x);
+}
+// Agent-coherent loads (cache policy sc1 on top of nt: gfx940+ cpol bit 4): served by the L2, never by this CU's vector L1 --
+// what the instance-resident kernel reads the rows other CUs of its team wrote with.
+#define HADI_AUX_NT_SC1 (HADI_AUX_NT | 16)
+HADI_DEV HADI_FORCEINLINE double hadi_buf_load_sc1(HadiBuf b, unsigned voff_bytes, unsigned soff_bytes) {
+    const hadi_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(b.r, voff_bytes, soff_bytes, HADI_AUX_NT_SC1);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+typedef unsigned hadi_u32x4 __attribute__((ext_vector_type(4)));
+HADI_DEV HADI_FORCEINLINE void hadi_buf_load2_sc1(HadiBuf b, unsigned voff_bytes, unsigned soff_bytes, double &x, double &y) {
+    const hadi_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b.r, voff_bytes, soff_bytes, HADI_AUX_NT_SC1);
+    x = __hiloint2double((int)v.y, (int)v.x);
+    y = __hiloint2double((int)v.w, (int)v.z);
 }
 HADI_DEV HADI_FORCEINLINE void hadi_buf_store(HadiBuf b, unsigned voff_bytes, unsigned soff_bytes, double v) {
     hadi_u32x2 d;
@@ -2437,7 +2454,7 @@ HADI_DEV HADI_FORCEINLINE unsigned hadi_pb_row(const HadiPassBCtx &c, int k) {
     return (unsigned)(r < c.nrows ? r : c.nrows);
 }
 
-template <class T = double>
+template <class T = double, bool SC1 = false>
 HADI_DEV HADI_FORCEINLINE void hadi_pb_load(const HadiPassBCtx &c, int ctile, double (&y)[HADI_LC]) {
     constexpr unsigned ES = (unsigned)sizeof(T);
     const int col = ctile * 64 + c.lane;
@@ -2445,7 +2462,10 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_load(const HadiPassBCtx &c, int ctile, do
     const unsigned voff = (unsigned)colc * ES;
     const unsigned rstride = (unsigned)c.rowp * ES;
 #pragma unroll
-    for (int k = 0; k < HADI_LC; k++) y[k] = hadi_buf_load_t<T>(c.Yb, voff, hadi_pb_row(c, k) * rstride);
+    for (int k = 0; k < HADI_LC; k++) {
+        if constexpr (SC1) y[k] = hadi_buf_load_sc1(c.Yb, voff, hadi_pb_row(c, k) * rstride);  // (agent-coherent: the team kernel)
+        else y[k] = hadi_buf_load_t<T>(c.Yb, voff, hadi_pb_row(c, k) * rstride);
+    }
 }
 
 // D(16 x 16) += A(16 x 4) B(4 x 16) on the matrix core, fp64 (v_mfma_f64_16x16x4_f64).  Operand mapping, verified on gfx950 by
@@ -3123,26 +3143,49 @@ HADI_DEV HADI_FORCEINLINE int hadi_xcc_id() {
     return (int)(__builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((4 - 1) << 11)) & 7);
 #endif
 }
-// this lane's B values of a row-layout global row, bypassing the vector L1 (another CU of the team wrote them)
+// Cross-CU visibility inside a team (HADI_TEAM_COHERENCE): how a wavefront is guaranteed to see what ANOTHER CU of its XCD wrote
+// before the team barrier.  The writer side is the same either way -- every wavefront drains its stores (the vector L1 is
+// write-through: an acknowledged store is in the XCD's L2) before its block arrives at the barrier.
+//   1  reader: agent-coherent loads (cache policy sc1, on top of nt): served by the L2, never by this CU's vector L1 -- the
+//      gfx942 / gfx950 memory model's "load atomic monotonic, agent scope", applied to the only loads that cross CUs (the five
+//      stencil rows of the row phase, the tile of the column phase).  No invalidate.
+//   2  reader: `buffer_inv sc1` behind the barrier's poll (the model's agent-scope acquire), plain nt loads.  Measured 1.7 us
+//      per time step slower than (1) on 512x256 (16.2 -> 17.9 ms per 1000 steps, profiles/r04_team_ab.txt): the invalidate also
+//      throws out the row tables and the lines the next phase's first loads would have hit.
+//   0  nt loads only (round 3): nt is a streaming HINT, not a coherence guarantee.  Kept for A/B timing only.
+#ifndef HADI_TEAM_COHERENCE
+#define HADI_TEAM_COHERENCE 1
+#endif
+// this lane's B values of a row-layout global row of the instance behind `ub` (byte offset `row_bytes`, wave-uniform)
 template <int B>
-HADI_DEV HADI_FORCEINLINE void hadi_get_block_l2(const double *row, int lane, double (&u)[B]) {
+HADI_DEV HADI_FORCEINLINE void hadi_get_block_l2(HadiBuf ub, const double *row, unsigned row_bytes, int lane, double (&u)[B]) {
 #if !defined(HADI_EMU)
     typedef double hadi_d2 __attribute__((ext_vector_type(2)));
 #endif
 #pragma unroll
     for (int q = 0; q < B / 2; q++) {
 #if defined(HADI_EMU)
+        (void)ub; (void)row_bytes;
         u[2 * q] = row[q * 128 + 2 * lane]; u[2 * q + 1] = row[q * 128 + 2 * lane + 1];
+#elif HADI_TEAM_COHERENCE == 1
+        (void)row;
+        hadi_buf_load2_sc1(ub, (unsigned)(q * 128 + 2 * lane) * 8u, row_bytes, u[2 * q], u[2 * q + 1]);
 #else
+        (void)ub; (void)row_bytes;
         const hadi_d2 t = __builtin_nontemporal_load(reinterpret_cast<const hadi_d2 *>(row + q * 128 + 2 * lane));
         u[2 * q] = t.x; u[2 * q + 1] = t.y;
 #endif
     }
 }
-HADI_DEV HADI_FORCEINLINE double hadi_get_l2(const double *p) {
+HADI_DEV HADI_FORCEINLINE double hadi_get_l2(HadiBuf ub, const double *p, unsigned off_bytes) {
 #if defined(HADI_EMU)
+    (void)ub; (void)off_bytes;
     return *p;
+#elif HADI_TEAM_COHERENCE == 1
+    (void)p;
+    return hadi_buf_load_sc1(ub, 0u, off_bytes);
 #else
+    (void)ub; (void)off_bytes;
     return __builtin_nontemporal_load(p);
 #endif
 }
@@ -3166,11 +3209,11 @@ HADI_DEV HADI_FORCEINLINE bool hadi_team_barrier(int *ctr, int target, int xcc_t
         int guard = 0;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++guard < HADI_TEAM_POLLS)
             __builtin_amdgcn_s_sleep(2);
-        // Acquire side: invalidate this CU's vector L1 (the agent-scope acquire of the gfx942 / gfx950 memory model) before
-        // anybody in the block reads what the other CUs of the team wrote.  The cross-CU loads are `nt` on top of that, but
-        // `nt` is a streaming HINT, not a coherence guarantee: a line of the previous step left in L1 would be a silently
-        // wrong price.  One invalidate per block and barrier (~1 us each): not measurable.
+        // Acquire side: see HADI_TEAM_COHERENCE above -- agent-coherent (sc1) loads of everything that crosses CUs, or, in the
+        // alternative build, an invalidate of this CU's vector L1 right here.
+#if HADI_TEAM_COHERENCE == 2
         asm volatile("buffer_inv sc1" ::: "memory");
+#endif
 #endif
         if (guard >= HADI_TEAM_POLLS || hadi_xcc_id() != xcc_team) {
             hadi_report(err, HADI_DEVERR_TEAM);
@@ -3189,13 +3232,14 @@ __global__ void __launch_bounds__(512, 2) hadi_team_kernel(HadiSweepArgs a, Hadi
     const int wave = HADI_UNIFORM((int)(threadIdx.x >> 6));
     const int xcc = hadi_xcc_id();
     if (xcc >= a.n_inst) return;  // (block-uniform: a workgroup lives on one XCD)
-    // LDS: [4 coefficient arrays of 64 B] [2 exchange buffers of P 4 64] [P wavefronts x 4 rows of the reduced inverse]
-    //      [P chunk tables of the column pass] [flags]
+    // LDS: [4 coefficient arrays of 64 B] [the column pass's reduced system: exchange values Z, selected inverse rows RT, their
+    //      product T (hadi_pb_mf_doubles)] [P chunk tables of the column pass] [flags]
     const int P = a.L.P, n4 = 4 * P;
     double *coef = smem;
     double *zsh = coef + 4 * 64 * B;
-    double *tsh = zsh + (size_t)P * 2 * 4 * 64;
-    double *tabl = tsh + (size_t)P * 4 * n4;  // the column-pass chunk tables, [P][HADI_LC][HADI_PBW]
+    double *rtsh = zsh + (size_t)n4 * 64;
+    double *tprod = rtsh + (size_t)n4 * hadi_pb_mp(P);
+    double *tabl = tprod + (size_t)hadi_pb_mp(P) * 64;  // the column-pass chunk tables, [P][HADI_LC][HADI_PBW]
     int *flags = reinterpret_cast<int *>(tabl + (size_t)P * HADI_LC * HADI_PBW);  // [0] rank of this block in its team, [1] dead
     if (threadIdx.x == 0) {
 #if defined(HADI_EMU)
@@ -3217,15 +3261,7 @@ __global__ void __launch_bounds__(512, 2) hadi_team_kernel(HadiSweepArgs a, Hadi
         const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B;
         const double mq = -(ip.thdt * ip.q);
         for (int e = threadIdx.x; e < 4 * 64 * B; e += 512) coef[e] = (e < 2 * 64 * B) ? mq * sc[e] : sc[e];
-        if (wave < P) {
-            const double *__restrict__ Rg = a.rinv + (size_t)inst * 16 * P * P;
-            double *__restrict__ rw = tsh + (size_t)wave * 4 * n4;
-            const int rl0 = (wave > 0) ? 4 * (wave - 1) + 2 : 0, rr0 = (wave < P - 1) ? 4 * (wave + 1) : 0;
-            for (int e = lane; e < 4 * n4; e += 64) {
-                const int m = e >> 2, q = e & 3;
-                rw[e] = Rg[(size_t)((q < 2) ? rl0 + q : rr0 + (q - 2)) * n4 + m];
-            }
-        }
+        hadi_pb_stage_rt(a.rinv + (size_t)inst * 16 * P * P, P, rtsh, 512);
         const double *__restrict__ pg = a.pb + (size_t)inst * a.L.nrows_pad * HADI_PBW;
         for (int e = threadIdx.x; e < P * HADI_LC * HADI_PBW; e += 512) tabl[e] = pg[e];
     }
@@ -3244,7 +3280,7 @@ __global__ void __launch_bounds__(512, 2) hadi_team_kernel(HadiSweepArgs a, Hadi
     c.inv_dt = 0.0; c.m1_lane = -1; c.m1_r = -1;
 
     HadiPassBCtx cb;
-    cb.lane = lane; cb.wave = wave; cb.P = P; cb.zsh = zsh; cb.Ri = tsh + (size_t)wave * 4 * n4;
+    cb.lane = lane; cb.wave = wave; cb.P = P; cb.zsh = zsh; cb.Ri = nullptr; cb.RT = rtsh; cb.Tsh = tprod;
     cb.nrows = nrows; cb.rowp = rowp; cb.ja = wave * HADI_LC;
     cb.Yi = c.Yi; cb.Ui = Ui;
     cb.Yb = hadi_make_buf(c.Yi, (size_t)a.L.inst_stride * sizeof(double));
@@ -3276,12 +3312,13 @@ __global__ void __launch_bounds__(512, 2) hadi_team_kernel(HadiSweepArgs a, Hadi
             for (int r = 0; r < B; r++) um2[r] = um1[r] = up1[r] = up2[r] = praw[r] = 0.0;
             double c0m2 = 0.0, c0m1 = 0.0, c0p1 = 0.0, c0p2 = 0.0;
             const double *r0 = Ui + (size_t)j * rowp;
-            if (j >= 2) { hadi_get_block_l2<B>(r0 - 2 * rowp, lane, um2); c0m2 = hadi_get_l2(r0 - 2 * rowp + c0slot); }
-            if (j >= 1) { hadi_get_block_l2<B>(r0 - rowp, lane, um1); c0m1 = hadi_get_l2(r0 - rowp + c0slot); }
-            hadi_get_block_l2<B>(r0, lane, u0);
-            const double c00 = hadi_get_l2(r0 + c0slot);
-            if (j + 1 < nrows) { hadi_get_block_l2<B>(r0 + rowp, lane, up1); c0p1 = hadi_get_l2(r0 + rowp + c0slot); }
-            if (j + 2 < nrows) { hadi_get_block_l2<B>(r0 + 2 * rowp, lane, up2); c0p2 = hadi_get_l2(r0 + 2 * rowp + c0slot); }
+            const unsigned rb = (unsigned)rowp * 8u, o0 = (unsigned)j * rb, oc = (unsigned)c0slot * 8u;  // (byte offsets inside the instance)
+            if (j >= 2) { hadi_get_block_l2<B>(cb.Ub, r0 - 2 * rowp, o0 - 2 * rb, lane, um2); c0m2 = hadi_get_l2(cb.Ub, r0 - 2 * rowp + c0slot, o0 - 2 * rb + oc); }
+            if (j >= 1) { hadi_get_block_l2<B>(cb.Ub, r0 - rowp, o0 - rb, lane, um1); c0m1 = hadi_get_l2(cb.Ub, r0 - rowp + c0slot, o0 - rb + oc); }
+            hadi_get_block_l2<B>(cb.Ub, r0, o0, lane, u0);
+            const double c00 = hadi_get_l2(cb.Ub, r0 + c0slot, o0 + oc);
+            if (j + 1 < nrows) { hadi_get_block_l2<B>(cb.Ub, r0 + rowp, o0 + rb, lane, up1); c0p1 = hadi_get_l2(cb.Ub, r0 + rowp + c0slot, o0 + rb + oc); }
+            if (j + 2 < nrows) { hadi_get_block_l2<B>(cb.Ub, r0 + 2 * rowp, o0 + 2 * rb, lane, up2); c0p2 = hadi_get_l2(cb.Ub, r0 + 2 * rowp + c0slot, o0 + 2 * rb + oc); }
             double rt[HADI_RCL];
             hadi_sload_wait(srow, rt);
             hadi_wave_rendezvous();
@@ -3300,16 +3337,16 @@ __global__ void __launch_bounds__(512, 2) hadi_team_kernel(HadiSweepArgs a, Hadi
         for (int t = (a.debug & HADI_DEBUG_TEAM_NO_COLS) ? a.ctiles : rank; t < a.ctiles; t += nb) {
             if (wave < P) {
                 double y[HADI_LC];
-                hadi_pb_load<double>(cb, t, y);
+                hadi_pb_load<double, HADI_TEAM_COHERENCE == 1>(cb, t, y);
                 HADI_TSTAMP(3, true);   // (diagnostic build: waits for the loads)
-                hadi_pb_solve<false>(cb, 0, y, 0);
+                hadi_pb_solve<false, false, true>(cb, 0, y, 0);  // (reduced system on the matrix core: two block barriers inside)
                 HADI_TSTAMP(4, false);
                 hadi_pb_store<0, false, double>(cb, t, y);
                 HADI_TSTAMP(5, false);
             } else if (P > 1) {
-                __syncthreads();  // (the exchange barrier inside hadi_pb_solve)
+                __syncthreads();  // (the two barriers inside hadi_pb_solve: exchange values written, product written)
+                __syncthreads();
             }
-            __syncthreads();  // the exchange buffer is free again (one buffer is used: parity 0)
         }
         arrivals += nb;
         if (!(a.debug & HADI_DEBUG_TEAM_NO_BARRIER) && !hadi_team_barrier(bar, arrivals, xcc, flags + 1, a.err)) return;

@@ -263,7 +263,7 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
         std::vector<int> team(512, 0);
         HadiTeamArgs ta;
         ta.form = team.data(); ta.bar = team.data() + 64; ta.nb = 1; ta.N = N; ta.stamps = nullptr;
-        const size_t smem = ((size_t)4 * 64 * L.B + (size_t)L.P * 2 * 4 * 64 + (size_t)L.P * 16 * L.P + (size_t)L.P * HADI_LC * HADI_PBW) * sizeof(double) + 64;
+        const size_t smem = ((size_t)4 * 64 * L.B + hadi_pb_mf_doubles(L.P) + (size_t)L.P * HADI_LC * HADI_PBW) * sizeof(double) + 64;
         if (L.B == 8) emu::launch(8, 512, [&]() { hadi_team_kernel<8>(a, ta); }, smem);
         else emu::launch(8, 512, [&]() { hadi_team_kernel<4>(a, ta); }, smem);
         emu::launch(8, 64, [&]() { hadi_unpack_kernel(L, n_inst, dU.data(), U); });

@@ -81,19 +81,18 @@ def test_dividends_and_chunked_column_pass(emu):
 def test_single_buffer_column_pass_for_more_than_8_chunks(emu):
     # m2 = 270 -> 271 v-rows -> 9 chunks -> the 16-wave single-buffer kernel; few blocks per instance so that a block
     # walks several column tiles (store + reload of the same registers), American adds the projection
-    _run(emu, 130, 265, 2, [97.0], O.AM, 1, r_f=0.01)
+    _run(emu, 130, 265, 1, [97.0], O.AM, 1, r_f=0.01)
     # European sweeps: hadi_pass_b2 (12 rows of the next tile prefetched into LDS, 24 with the fp32 state; one exchange buffer)
     # and, with the prefetch switched off, hadi_pass_b1; 9 and 16 chunks, a short last tile, a block of one tile
     for pf in (1, 0):
         emu.emu_set_tuning(b"col_prefetch", pf)
         emu.emu_set_tuning(b"tile_interleave", pf)  # (with it: the blocks take their full tiles interleaved)
         try:
-            _run(emu, 140, 270, 2, [100.0], O.EU, 1)
+            _run(emu, 140, 270, 1, [100.0], O.EU, 1)
             if pf:
-                _run(emu, 130, 500, 2, [100.0, 96.0], O.EU, 1, r_f=0.01)
-                _run(emu, 200, 270, 2, [100.0], O.EU, 1, scheme=2)
-                _run(emu, 64, 300, 2, [103.0], O.EU, 8)
-                _run(emu, 300, 150, 2, [100.0], O.AM, 1)  # interleaved tiles on the double-buffered kernel (5 chunks, American)
+                _run(emu, 64, 500, 1, [100.0], O.EU, 8, r_f=0.01)      # 16 chunks (1024-thread block), two tiles
+                _run(emu, 140, 270, 1, [100.0], O.EU, 1, scheme=2)     # fp32 state: 16 rows prefetched, 4 rows per DMA instruction
+                _run(emu, 72, 70, 2, [100.0], O.AM, 3)                 # interleaved tiles on the double-buffered kernel (American)
         finally:
             emu.emu_set_tuning(b"reset", 0)
 
@@ -101,16 +100,16 @@ def test_single_buffer_column_pass_for_more_than_8_chunks(emu):
 def test_strip_row_pass(emu):
     # 8 nodes per lane: every wavefront walks a strip of v-rows alone (register window + private LDS ring, no barrier).
     # 151 rows -> 8 strips of 19; r_f != 0 exercises the boundary terms, the last strip carries the b2 row
-    _run(emu, 300, 150, 2, [100.0], O.EU, 1, r_f=0.01)
+    _run(emu, 300, 150, 1, [100.0], O.EU, 1, r_f=0.01)
     # forced short strips (6 rows: prologue / halo / ring wrap-around on every strip), American adds lambda_bar
     emu.emu_set_tuning(b"strip", 1)
     try:
-        _run(emu, 280, 40, 3, [95.0], O.AM, 1)
+        _run(emu, 280, 40, 2, [95.0], O.AM, 1)
         # 4 and 2 nodes per lane
         _run(emu, 200, 60, 3, [100.0], O.AM_DIV, 1, r_f=0.01)
         _run(emu, 100, 70, 2, [100.0], O.EU, 1)
         # put boundary data on strips (i = 0 column with its reaction term, b1 == 0, time factor e^{-r_d t})
-        _run(emu, 300, 40, 3, [100.0], O.AM, 1, put=True)
+        _run(emu, 300, 40, 2, [100.0], O.AM, 1, put=True)
     finally:
         emu.emu_set_tuning(b"reset", 0)
 
@@ -137,8 +136,8 @@ def test_fp32_state_sweep(emu):
     _run(emu, 40, 12, 3, [90.0, 110.0], O.EU, 8, r_f=0.01, scheme=2)
     _run(emu, 300, 40, 2, [100.0], O.EU, 8, scheme=2)
     _run(emu, 600, 12, 2, [100.0], O.EU, 8, scheme=2)
-    _run(emu, 140, 270, 2, [100.0], O.EU, 1, scheme=2)
-    _run(emu, 300, 150, 2, [100.0], O.EU, 1, r_f=0.01, scheme=2)  # large enough for the strip row pass (ring of floats)
+    _run(emu, 300, 150, 1, [100.0], O.EU, 1, r_f=0.01, scheme=2)  # large enough for the strip row pass (ring of floats)
+    # (the single-buffer column pass with the fp32 state: test_single_buffer_column_pass_for_more_than_8_chunks)
 
 
 def test_american_p_representation(emu):
@@ -146,12 +145,12 @@ def test_american_p_representation(emu):
     # the single-buffer column pass
     _run(emu, 40, 12, 4, [100.0, 92.0], O.AM, 4, r_f=0.01, scheme=3)
     _run(emu, 200, 33, 7, [100.0], O.AM_DIV, 8, scheme=3)
-    _run(emu, 530, 10, 3, [100.0], O.AM, 8, scheme=3)
-    _run(emu, 140, 265, 2, [97.0], O.AM, 1, scheme=3)
+    _run(emu, 530, 10, 2, [100.0], O.AM, 8, scheme=3)
+    _run(emu, 140, 265, 1, [97.0], O.AM, 1, scheme=3)
     # batches large enough for the strip row pass: 8 nodes per lane (payoff row in LDS), with dividend steps in between,
     # and 4-strip blocks at 2 nodes per lane
-    _run(emu, 300, 70, 3, [100.0], O.AM, 1, r_f=0.01, scheme=3)
-    _run(emu, 260, 40, 6, [95.0], O.AM_DIV, 1, scheme=3)
+    _run(emu, 300, 70, 2, [100.0], O.AM, 1, r_f=0.01, scheme=3)
+    _run(emu, 120, 40, 6, [95.0], O.AM_DIV, 1, scheme=3)
 
 
 def test_two_waves_per_row_split_solve(emu):
@@ -167,15 +166,14 @@ def test_paired_strip_row_pass(emu):
     # carrying the b2 row); 3-slot ring (fp64 state) and 4-slot ring of floats (fp32 state); full width m1 = 1024; put data.
     emu.emu_set_tuning(b"strip", 1)
     try:
-        _run(emu, 600, 40, 3, [100.0], O.EU, 1, r_f=0.01)
-        _run(emu, 600, 40, 3, [100.0], O.EU, 1, scheme=2)  # fp32 state
+        _run(emu, 600, 26, 2, [100.0], O.EU, 1, r_f=0.01)
+        _run(emu, 600, 26, 2, [100.0], O.EU, 1, scheme=2)  # fp32 state
         # American sweeps on paired strips (round 3): explicit (U, lambda_bar) pair, with dividends, put data; the P
         # representation (u0 carried raw, U = max(P, U_0) rebuilt inside the step; explicit steps in between for dividends)
-        _run(emu, 530, 30, 3, [100.0], O.AM, 1)
-        _run(emu, 700, 40, 4, [96.0], O.AM_DIV, 1, r_f=0.01, put=True)
-        _run(emu, 600, 40, 3, [100.0], O.AM, 1, r_f=0.01, scheme=3)
-        _run(emu, 1024, 20, 3, [100.0], O.AM, 1, scheme=3, put=True)
-        _run(emu, 700, 40, 6, [104.0], O.AM_DIV, 1, scheme=3)
+        _run(emu, 530, 20, 2, [100.0], O.AM, 1)
+        _run(emu, 700, 26, 4, [96.0], O.AM_DIV, 1, r_f=0.01, put=True)
+        _run(emu, 1024, 20, 2, [100.0], O.AM, 1, scheme=3, put=True)
+        _run(emu, 700, 26, 6, [104.0], O.AM_DIV, 1, scheme=3, r_f=0.01)
     finally:
         emu.emu_set_tuning(b"reset", 0)
 
@@ -457,7 +455,7 @@ def test_sequential_passes_for_shapes_beyond_the_streaming_kernels(emu):
     unchunked factorisation) -- the reference bounds a grid by its total size only.  Each alone with the streaming kernel of
     the other direction, both together, American and dividend variants, put data, r_f != 0, m1 a multiple of 64."""
     _run(emu, 1100, 12, 2, [100.0], O.EU, 8, r_f=0.01)        # sequential row pass + chunked column pass
-    _run(emu, 1088, 40, 2, [100.0, 93.0], O.AM, 8)            # m1 = 17 * 64: the i = 0 slot sits right behind node m1
+    _run(emu, 1088, 40, 2, [100.0], O.AM, 8)                  # m1 = 17 * 64: the i = 0 slot sits right behind node m1
     _run(emu, 20, 528, 1, [100.0], O.EU, 8)                   # ring row pass + sequential column pass
     _run(emu, 70, 530, 1, [104.0], O.AM, 8)                   # 2 nodes per lane + sequential column pass, American
     _run(emu, 1030, 530, 1, [100.0], O.AM, 8, r_f=0.02)       # both sequential
@@ -472,11 +470,11 @@ def test_pair_strips_two_strips_per_wavefront(emu):
     the explicit pair and in the P representation, the row that carries b2 in either half."""
     emu.emu_set_tuning(b"strip", 1)
     try:
-        _run(emu, 256, 70, 2, [100.0], O.EU, 1, r_f=0.01)              # 71 rows: 8 strips of 9 (the last: 8)
+        _run(emu, 256, 54, 2, [100.0], O.EU, 1, r_f=0.01)              # 55 rows: 8 strips of 7 (the last: 6)
         _run(emu, 200, 40, 3, [100.0], O.EU, 1)                        # 41 rows: strips of 6, the eighth has 5... and r < m1 everywhere
         _run(emu, 130, 20, 2, [104.0], O.DIV, 1, put=True)             # 21 rows: 3 per strip, the last strip empty
-        _run(emu, 256, 70, 2, [100.0], O.AM, 1)                        # explicit (U, lambda_bar) pair
-        _run(emu, 256, 128, 2, [100.0], O.AM, 1, scheme=3)             # config 3's grid in the P representation (4-slot ring, raw row re-read)
+        _run(emu, 256, 54, 2, [100.0], O.AM, 1)                        # explicit (U, lambda_bar) pair
+        _run(emu, 256, 64, 2, [100.0], O.AM, 1, scheme=3)              # the P representation (4-slot ring, raw row re-read)
         _run(emu, 180, 33, 3, [100.0], O.AM_DIV, 1, scheme=3, r_f=0.02)
         emu.emu_set_tuning(b"strip_blocks", 2)                         # 16 strips per instance
         _run(emu, 200, 40, 2, [100.0], O.EU, 1)

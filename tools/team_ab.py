@@ -5,6 +5,8 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
+import pde_based_heston_solver_gpu_accelerated_amd._native as nat
+if os.environ.get("HADI_LIB"): nat.LIB_PATH = os.path.abspath(os.environ["HADI_LIB"])  # (an alternative build, tools/build_variant.py)
 import pde_based_heston_solver_gpu_accelerated_amd as H
 dev = torch.device("cuda:0"); s = H.HestonADI(0)
 for (m1, m2, N) in ((512, 256, 1000), (256, 128, 500)):
