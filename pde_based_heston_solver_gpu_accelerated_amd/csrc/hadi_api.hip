@@ -72,6 +72,15 @@ struct Ctx {
     // (system-scope atomic, only ever on a failure path); finish_timing reads it after the stream synchronisation every
     // entry point ends with -- no copy, no extra launch -- and turns a non-zero word into HADI_ERR_INTERNAL.
     int *err_host = nullptr, *err_dev = nullptr;
+    // Pinned staging arena for the small host-side vectors of a call (per-instance parameters, dividend tables, dispatch order,
+    // selectors, status words).  A copy out of pageable memory blocks the host and its source has to outlive it -- every such
+    // vector used to cost a stream synchronisation in the middle of a call (three per Jacobian: ~0.15 ms of a 1.7 ms call on
+    // the calibration grids).  Copies out of this arena are truly asynchronous; it is rewound at the start of every entry point
+    // (each ends with a stream synchronisation, so nothing of the previous call is in flight) and grown there when a call asked
+    // for more than it holds (the request that did not fit takes the old copy-and-synchronise path once).
+    char *pin = nullptr;
+    size_t pin_cap = 0, pin_used = 0, pin_want = 0;
+    int pin_dirty = 0;  // copies out of the arena may be in flight (cleared by the stream synchronisation that ends a call)
     int debug_fault = 0;  // test hook (hadi_set_tuning "debug_fault"): HADI_DEBUG_* bits handed to the sweep kernels
     // instance-resident launch (hadi_team_kernel): -1 automatic, 0 never, 1 whenever the shape allows it; team_failed is set
     // when a team could not form or a team barrier timed out once on this handle (the automatic choice then stays away)
@@ -132,6 +141,45 @@ int ensure(Ctx *c, DevBuf &b, size_t bytes) {
 template <class T>
 T *ptr(DevBuf &b) {
     return static_cast<T *>(b.p);
+}
+
+// Start of an entry point: nothing of the previous call is in flight (it ended with a stream synchronisation).
+void pin_rewind(Ctx *c) {
+    if (c->pin_dirty && c->stream) (void)hipStreamSynchronize(c->stream);  // (a call that left through an error path)
+    c->pin_dirty = 0;
+    if (c->pin_want > c->pin_cap) {
+        if (c->pin) (void)hipHostFree(c->pin);
+        c->pin = nullptr; c->pin_cap = 0;
+        const size_t want = c->pin_want + c->pin_want / 2 + 4096;
+        void *q = nullptr;
+        if (hipHostMalloc(&q, want, hipHostMallocDefault) == hipSuccess) { c->pin = static_cast<char *>(q); c->pin_cap = want; }
+    }
+    c->pin_used = 0;
+    c->pin_want = 0;
+}
+// `bytes` of pinned staging memory, or nullptr if the arena cannot hold them (the caller then takes the synchronising path).
+void *pin_alloc(Ctx *c, size_t bytes) {
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    c->pin_want += need;
+    if (!c->pin || c->pin_used + need > c->pin_cap) return nullptr;
+    void *q = c->pin + c->pin_used;
+    c->pin_used += need;
+    return q;
+}
+// Host -> device copy of a small host vector: through the pinned arena (asynchronous, the source may die at once), or, if it
+// does not fit, straight from the caller's memory followed by a stream synchronisation.
+int stage_to_device(Ctx *c, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return HADI_OK;
+    void *q = pin_alloc(c, bytes);
+    if (q) {
+        std::memcpy(q, src, bytes);
+        c->pin_dirty = 1;
+        HIP_TRY(c, hipMemcpyAsync(dst, q, bytes, hipMemcpyHostToDevice, c->stream));
+        return HADI_OK;
+    }
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HADI_OK;
 }
 
 int grid1d(size_t n, int block = 256, int cap = 4096) {
@@ -275,21 +323,25 @@ hipError_t raise_all_lds_limits() {
     return raise_lds_limit(hadi_pass_b1<16, true>);
 }
 
-int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
-    const int state_bytes = d.prec == HADI_STATE_FP32 ? 4 : 8;
-    if (hadi_make_plan(d.m1, d.m2, d.n, 8 * c->cu_count, &pl, c->tune, state_bytes))
-        return fail(c, HADI_ERR_UNSUPPORTED, "grid %dx%d not supported (need m1 >= 2, m2 >= 3 and (m1 + 16)(m2 + 1) < 2^28)", d.m1, d.m2);
-    const bool seq_shape = pl.row_seq || pl.col_seq;  // shapes beyond the streaming kernels: the sequential passes
-    if (seq_shape && (d.scheme != HADI_SCHEME_DOUGLAS || d.prec != HADI_STATE_FP64))
-        return fail(c, HADI_ERR_UNSUPPORTED, "grids with m1 > 1024 or m2 > %d run Douglas sweeps with the fp64 state only", HADI_MAX_P * HADI_LC - 1);
+// ---- run_sweep, part 1: how the batch is cut ---------------------------------------------------------------------------
+struct SubBatch { int off, cnt; HadiPlan pl; int lane; };  // lane: 0 = the handle's stream, 1 = its second stream
+struct BatchPlan {
+    std::vector<SubBatch> subs;
+    bool two_streams = false;
+    int fork_before = 0;  // the second stream forks off right before this sub-batch is enqueued
+};
+// Sub-batches (whole rounds of one instance per CU + the remainder) and the one-or-two-streams decision.  `pl` is the plan of
+// the whole batch on entry and the plan the caller sees (layout, table sizes) on exit.
+int plan_batches(Ctx *c, const SweepDesc &d, HadiPlan &pl, int state_bytes, bool seq_shape, BatchPlan &bp) {
+    std::vector<SubBatch> &subs = bp.subs;
+    bool &two_streams = bp.two_streams;
+    int &fork_before = bp.fork_before;
     // Large batches on grids where ONE round of the one-block-per-CU kernels (cu_count instances) already moves more than
     // the 256 MB memory-side cache holds: the two passes of a step then re-use each other's data only while the batch is
     // one round deep (measured at 512x256: 512 instances at once ran the column pass 6 % slower per instance than 256;
     // 384 at once: 0.188 + 0.205 ms per step against 0.173 + 0.177 as 256 + 128).  Instances are independent, so the time
     // loop runs sub-batch by sub-batch -- whole rounds of cu_count instances plus the remainder (a remainder below a
     // quarter round rides with the last full round) -- each with the launch geometry of its own size.
-    struct SubBatch { int off, cnt; HadiPlan pl; int lane; };  // lane: 0 = the handle's stream, 1 = its second stream
-    std::vector<SubBatch> subs;
     // (the strip kernels scale the A1 action by (1 - theta) / theta and keep the s-convection weights multiplied by
     // theta dt (r_d - r_f): hadi_strip_step)
     const bool no_strips = !(d.theta > 0.0) || d.r_d == d.r_f;
@@ -317,8 +369,6 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     // pass would leave a partial round of CUs idle (hadi_plan_row_idle); the full rounds before it run on one stream.
     // Instances are independent and the two passes of a step stay ordered within their own stream.
     const bool streams_ok = d.scheme == HADI_SCHEME_DOUGLAS && !d.debug && !c->profiling && d.n >= 2 && !seq_shape;
-    bool two_streams = false;
-    int fork_before = 0;  // the second stream forks off right before this sub-batch is enqueued
     auto split_last = [&]() -> int {
         const SubBatch last = subs.back();
         const int h0 = (last.cnt + 1) / 2;
@@ -350,6 +400,202 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         }
     }
     if (two_streams) pl = subs[0].pl;
+    return HADI_OK;
+}
+
+// ---- run_sweep, part 2: which kernel runs a pass -----------------------------------------------------------------------
+// Everything the choice depends on (the selection rules themselves: hadi_plan.h and DESIGN.md section 4.1).
+struct PassEnv {
+    const HadiPlan &pl;      // launch geometry of THIS sub-batch
+    const HadiLayout &L;
+    int nsb;                 // instances of the sub-batch
+    hipStream_t q;
+    int nstep;
+    bool american, amp, xstep, f32;  // amp: P representation; xstep: this step runs on the explicit (U, lambda_bar) pair
+    int col_prefetch;
+};
+// Row pass of one time step.  mode: 0 Douglas, 1 / 2 Craig-Sneyd predictor / corrector.
+void launch_row_pass(const PassEnv &e, const HadiSweepArgs &ar, int mode) {
+    const HadiPlan &pl = e.pl; const HadiLayout &L = e.L; const int nsb = e.nsb, nstep = e.nstep; hipStream_t q = e.q;
+    const bool american = e.american, amp = e.amp, xstep = e.xstep, f32 = e.f32;
+    if (pl.row_seq) {  // more than 1024 s-intervals: one lane per v-row, sequential along s
+        const dim3 g((unsigned)(nsb * ((L.nrows + 63) / 64))), b(64);
+        if (american) hipLaunchKernelGGL((hadi_pass_a_seq<1>), g, b, 0, q, ar, nstep);
+        else hipLaunchKernelGGL((hadi_pass_a_seq<0>), g, b, 0, q, ar, nstep);
+        return;
+    }
+    if (pl.use_pairs && pl.use_strip && mode == 0 && !f32) {  // 4 nodes per lane: two strips per wavefront
+        const dim3 g(pl.grid_as), b(64 * HADI_PAIR_WAVES);
+        if (amp && !xstep) hipLaunchKernelGGL((hadi_pass_a_pairs<2>), g, b, pl.smem_pairs_amp, q, ar, nstep);
+        else if (american) hipLaunchKernelGGL((hadi_pass_a_pairs<1>), g, b, pl.smem_pairs_eu, q, ar, nstep);
+        else hipLaunchKernelGGL((hadi_pass_a_pairs<0>), g, b, pl.smem_pairs_eu, q, ar, nstep);
+        return;
+    }
+    if (amp && !xstep && pl.use_strip && mode == 0) {  // P representation on barrier-free strips
+        const dim3 g(pl.grid_as), b(64 * HADI_STRIP_WAVES(L.B));
+        const size_t sm = pl.smem_as + (size_t)L.rowp * sizeof(double);  // + the payoff row
+        if (L.G == 2) {  // paired strips (two wavefronts per row)
+            hipLaunchKernelGGL((hadi_pass_a_strip<8, 2, double, 2>), g, b, sm, q, ar, nstep);
+            return;
+        }
+        switch (L.B) {
+            case 8: hipLaunchKernelGGL((hadi_pass_a_strip<8, 2>), g, b, sm, q, ar, nstep); break;
+            case 4: hipLaunchKernelGGL((hadi_pass_a_strip<4, 2>), g, b, sm, q, ar, nstep); break;
+            default: hipLaunchKernelGGL((hadi_pass_a_strip<2, 2>), g, b, sm, q, ar, nstep); break;
+        }
+        return;
+    }
+    if (amp && !xstep) {
+        switch (L.B * 10 + L.G) {
+            case 11: launch_pass_a_amp<1, 1, 1, 2>(pl, ar, nstep, q); break;
+            case 21: launch_pass_a_amp<2, 1, 1, 2>(pl, ar, nstep, q); break;
+            case 41: launch_pass_a_amp<4, 1, 1, 2>(pl, ar, nstep, q); break;
+            case 81: launch_pass_a_amp<8, 1, 1, 1>(pl, ar, nstep, q); break;
+            default: launch_pass_a_amp<8, 2, 1, 1>(pl, ar, nstep, q); break;
+        }
+        return;
+    }
+    if (f32 && pl.use_strip && L.B == 8 && L.G == 2) {  // fp32 state, 512 < m1 <= 1024: paired strips
+        hipLaunchKernelGGL((hadi_pass_a_strip<8, false, float, 2>), dim3(pl.grid_as), dim3(512), pl.smem_as, q, ar, nstep);
+        return;
+    }
+    if (f32 && pl.use_strip && L.B == 8) {  // fp32 state, 8 nodes per lane, large batch: strips with a ring of floats
+        const size_t smem = (size_t)8 * 4 * L.rowp * sizeof(float) + (size_t)4 * 64 * L.B * sizeof(double);
+        hipLaunchKernelGGL((hadi_pass_a_strip<8, false, float>), dim3(pl.grid_as), dim3(512), smem, q, ar, nstep);
+        return;
+    }
+    if (f32) {  // fp32 state: shared-ring kernel for the other shapes
+        switch (L.B * 10 + L.G) {
+            case 11: launch_pass_a_f32<1, 1, 1, 2>(pl, ar, nstep, q); break;
+            case 21: launch_pass_a_f32<2, 1, 1, 2>(pl, ar, nstep, q); break;
+            case 41: launch_pass_a_f32<4, 1, 1, 2>(pl, ar, nstep, q); break;
+            case 81: launch_pass_a_f32<8, 1, 1, 1>(pl, ar, nstep, q); break;
+            default: launch_pass_a_f32<8, 2, 1, 1>(pl, ar, nstep, q); break;
+        }
+        return;
+    }
+    if (pl.use_strip && mode == 0 && L.G == 2) {  // paired strips (Douglas step, two wavefronts per row)
+        if (american) hipLaunchKernelGGL((hadi_pass_a_strip<8, 1, double, 2>), dim3(pl.grid_as), dim3(512), pl.smem_as, q, ar, nstep);
+        else hipLaunchKernelGGL((hadi_pass_a_strip<8, false, double, 2>), dim3(pl.grid_as), dim3(512), pl.smem_as, q, ar, nstep);
+        return;
+    }
+    if (pl.use_strip && mode == 0) {  // barrier-free strips (Douglas step, one wavefront per row)
+        const dim3 g(pl.grid_as), b(64 * HADI_STRIP_WAVES(L.B));
+        switch (L.B * 2 + (american ? 1 : 0)) {
+            case 16: hipLaunchKernelGGL((hadi_pass_a_strip<8, false>), g, b, pl.smem_as, q, ar, nstep); break;
+            case 17: hipLaunchKernelGGL((hadi_pass_a_strip<8, true>), g, b, pl.smem_as, q, ar, nstep); break;
+            case 8: hipLaunchKernelGGL((hadi_pass_a_strip<4, false>), g, b, pl.smem_as, q, ar, nstep); break;
+            case 9: hipLaunchKernelGGL((hadi_pass_a_strip<4, true>), g, b, pl.smem_as, q, ar, nstep); break;
+            case 4: hipLaunchKernelGGL((hadi_pass_a_strip<2, false>), g, b, pl.smem_as, q, ar, nstep); break;
+            default: hipLaunchKernelGGL((hadi_pass_a_strip<2, true>), g, b, pl.smem_as, q, ar, nstep); break;
+        }
+        return;
+    }
+    switch (L.B * 10 + L.G) {
+        case 11: launch_pass_a<1, 1, 1, 2>(pl, ar, nstep, q, mode); break;
+        case 21: launch_pass_a<2, 1, 1, 2>(pl, ar, nstep, q, mode); break;
+        case 41: launch_pass_a<4, 1, 1, 2>(pl, ar, nstep, q, mode); break;
+        case 81: launch_pass_a<8, 1, 1, 1>(pl, ar, nstep, q, mode); break;
+        default: launch_pass_a<8, 2, 1, 1>(pl, ar, nstep, q, mode); break;
+    }
+}
+
+// Column pass of one time step.
+void launch_col_pass(const PassEnv &e, const HadiSweepArgs &ar) {
+    const HadiPlan &pl = e.pl; const HadiLayout &L = e.L; const int nsb = e.nsb, nstep = e.nstep; hipStream_t q = e.q;
+    const bool american = e.american, amp = e.amp, xstep = e.xstep, f32 = e.f32;
+    // up to 8 chunks: 512-thread blocks with two register buffers (2 waves per SIMD); 9..16 chunks: the
+    // 1024-thread block leaves 128 VGPRs per lane, which only the single-buffer kernel fits
+    // (measured at 1024x512: 0.250 vs 0.382 ms/launch for the double-buffered code, which spills)
+    const dim3 g(pl.grid_b), b(pl.block_b);
+    if (pl.col_seq) {  // more than 16 chunks of v-rows: one lane per storage column, sequential along v
+        const dim3 gs((unsigned)(nsb * pl.ctiles)), bs(64);
+        if (american) hipLaunchKernelGGL((hadi_pass_b_seq<1>), gs, bs, 0, q, ar, nstep);
+        else hipLaunchKernelGGL((hadi_pass_b_seq<0>), gs, bs, 0, q, ar, nstep);
+        return;
+    }
+    if (amp && !xstep) {
+        if (L.P <= 8) hipLaunchKernelGGL((hadi_pass_b<8, 2>), g, b, pl.smem_b, q, ar, nstep);
+        else hipLaunchKernelGGL((hadi_pass_b1<16, 2>), g, b, pl.smem_b, q, ar, nstep);
+        return;
+    }
+    if (f32) {
+        if (L.P <= 8) hipLaunchKernelGGL((hadi_pass_b<8, false, float>), g, b, pl.smem_b, q, ar, nstep);
+        else if (e.col_prefetch) hipLaunchKernelGGL((hadi_pass_b2<16, float, HADI_B2_NPF(4)>), g, b, pl.smem_b2, q, ar, nstep);
+        else hipLaunchKernelGGL((hadi_pass_b1<16, false, float>), g, b, pl.smem_b, q, ar, nstep);
+        return;
+    }
+    if (L.P <= 8) {
+        if (american) hipLaunchKernelGGL((hadi_pass_b<8, true>), g, b, pl.smem_b, q, ar, nstep);
+        else hipLaunchKernelGGL((hadi_pass_b<8, false>), g, b, pl.smem_b, q, ar, nstep);
+    } else {
+        if (american) hipLaunchKernelGGL((hadi_pass_b1<16, true>), g, b, pl.smem_b, q, ar, nstep);
+        else if (e.col_prefetch) hipLaunchKernelGGL((hadi_pass_b2<16, double, HADI_B2_NPF(8)>), g, b, pl.smem_b2, q, ar, nstep);
+        else hipLaunchKernelGGL((hadi_pass_b1<16, false>), g, b, pl.smem_b, q, ar, nstep);
+    }
+}
+
+// ---- run_sweep, part 3: the kernels of the streaming path in words (hadi_describe_last_sweep) ------------------------
+std::string describe_streaming_path(const Ctx *c, const HadiPlan &pl, const BatchPlan &bp, bool american, bool amp, bool cs, bool f32) {
+    const HadiLayout &L = pl.L;
+    const std::vector<SubBatch> &subs = bp.subs;
+    const int nsub = (int)subs.size();
+    const bool two_streams = bp.two_streams;
+    const int fork_before = bp.fork_before;
+    std::string last_path;
+    char buf[256];
+    char rowk[96];
+    if (amp && pl.use_strip && !cs && L.G == 2) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,AM-P,double,2> (paired strips of %d rows, no lambda_bar array)", pl.RS);
+    else if (amp && pl.use_strip && !cs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<%d,AM-P> (strips of %d rows, no lambda_bar array)", L.B, pl.RS);
+    else if (amp) std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,AM-P> (tiles of %d rows, no lambda_bar array)", L.B, L.G, pl.W, pl.NG, pl.PD, pl.R);
+    else if (f32 && pl.use_strip && L.B == 8 && L.G == 2) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,EU,float,2> (paired strips of %d rows, fp32 state)", pl.RS);
+    else if (f32 && pl.use_strip && L.B == 8) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,EU,float> (strips of %d rows, fp32 state)", pl.RS);
+    else if (f32) std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,EU,float> (tiles of %d rows, fp32 state)", L.B, L.G, pl.W, pl.NG, pl.PD, pl.R);
+    else if (pl.use_strip && !cs && L.G == 2) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,%s,double,2> (paired strips of %d rows)", american ? "AM" : "EU", pl.RS);
+    else if (pl.use_strip && !cs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<%d,%s> (strips of %d rows)", L.B, american ? "AM" : "EU", pl.RS);
+    else std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,%s%s> (tiles of %d rows)", L.B, L.G, pl.W, pl.NG, pl.PD,
+                       american ? "AM" : "EU", cs ? ",CS" : "", pl.R);
+    if (pl.use_pairs && pl.use_strip && !cs && !f32)
+        std::snprintf(rowk, sizeof rowk, "hadi_pass_a_pairs<%s> (two strips of %d rows per wavefront%s)", amp ? "AM-P" : american ? "AM" : "EU", pl.RS,
+                      amp ? ", no lambda_bar array" : "");
+    if (pl.row_seq) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_seq<%s> (one lane per v-row, sequential along s)", american ? "AM" : "EU");
+    if (pl.col_seq)
+        std::snprintf(buf, sizeof buf, "row pass %s; column pass hadi_pass_b_seq<%s> (one lane per column, sequential along v)", rowk, american ? "AM" : "EU");
+    else
+        std::snprintf(buf, sizeof buf, "row pass %s; column pass %s<%d,%s> (%d chunks of %d rows, %d column tiles per block)", rowk,
+                      L.P <= 8 ? "hadi_pass_b" : (!american && c->col_prefetch) ? "hadi_pass_b2" : "hadi_pass_b1", L.P <= 8 ? 8 : 16,
+                      amp ? "AM-P" : american ? "AM" : "EU", L.P, HADI_LC, pl.btpw);
+    last_path = buf;
+    if (nsub > 1) {
+        bool same = true;
+        for (auto &sbt : subs) same = same && sbt.cnt == subs[0].cnt;
+        if (same) last_path += "; " + std::to_string(nsub) + " sub-batches of " + std::to_string(subs[0].cnt) + " instances";
+        else {
+            last_path += "; " + std::to_string(nsub) + " sub-batches of";
+            for (auto &sbt : subs) last_path += " " + std::to_string(sbt.cnt);
+            last_path += " instances (each with the geometry of its own size)";
+        }
+        if (two_streams && fork_before > 0) last_path += ", the last two side by side on two streams";
+        else if (two_streams) last_path += ", side by side on two streams";
+    }
+    return last_path;
+}
+
+int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
+    const int state_bytes = d.prec == HADI_STATE_FP32 ? 4 : 8;
+    if (hadi_make_plan(d.m1, d.m2, d.n, 8 * c->cu_count, &pl, c->tune, state_bytes))
+        return fail(c, HADI_ERR_UNSUPPORTED, "grid %dx%d not supported (need m1 >= 2, m2 >= 3 and (m1 + 16)(m2 + 1) < 2^28)", d.m1, d.m2);
+    const bool seq_shape = pl.row_seq || pl.col_seq;  // shapes beyond the streaming kernels: the sequential passes
+    if (seq_shape && (d.scheme != HADI_SCHEME_DOUGLAS || d.prec != HADI_STATE_FP64))
+        return fail(c, HADI_ERR_UNSUPPORTED, "grids with m1 > 1024 or m2 > %d run Douglas sweeps with the fp64 state only", HADI_MAX_P * HADI_LC - 1);
+    BatchPlan bp;
+    {
+        const int rcp = plan_batches(c, d, pl, state_bytes, seq_shape, bp);
+        if (rcp) return rcp;
+    }
+    const std::vector<SubBatch> &subs = bp.subs;
+    const bool two_streams = bp.two_streams;
+    const int fork_before = bp.fork_before;
     const int nsub = (int)subs.size();
     const HadiLayout &L = pl.L;
     const bool american = d.variant == HADI_AM || d.variant == HADI_AM_DIV;
@@ -381,7 +627,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
 
     hipStream_t s = c->stream;
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
-    HIP_TRY(c, hipMemcpyAsync(c->par8.p, d.par8.data(), 8 * 8 * n, hipMemcpyHostToDevice, s));
+    if ((rc = stage_to_device(c, c->par8.p, d.par8.data(), 8 * 8 * n))) return rc;
     // Discrete dividends: host-built table "which dividend does instance k pay at the start of step n" (one shared
     // row when the batch has a single (N, delta_t)), plus the set of steps where anybody pays.
     std::vector<int> div_flags;
@@ -402,10 +648,10 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         if ((rc = ensure(c, c->div_flag, div_flags.size() * sizeof(int))) || (rc = ensure(c, c->div_amt, d.num_div * 8)) ||
             (rc = ensure(c, c->div_pct, d.num_div * 8)))
             return rc;
-        HIP_TRY(c, hipMemcpyAsync(c->div_flag.p, div_flags.data(), div_flags.size() * sizeof(int), hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(c->div_amt.p, d.div_amounts, d.num_div * 8, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(c->div_pct.p, d.div_pcts, d.num_div * 8, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipStreamSynchronize(s));  // pageable staging: the vectors may be reused by the next call
+        if ((rc = stage_to_device(c, c->div_flag.p, div_flags.data(), div_flags.size() * sizeof(int))) ||
+            (rc = stage_to_device(c, c->div_amt.p, d.div_amounts, (size_t)d.num_div * 8)) ||
+            (rc = stage_to_device(c, c->div_pct.p, d.div_pcts, (size_t)d.num_div * 8)))
+            return rc;
     }
     // identity padding rows of Y must read as zeros in the column pass (the row pass never writes them)
     HIP_TRY(c, hipMemsetAsync(c->Y.p, 0, st, s));
@@ -537,119 +783,9 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                     hipLaunchKernelGGL(hadi_narrow_kernel, dim3(grid1d(tot)), dim3(256), 0, q, L, Ub, reinterpret_cast<float *>(a.U), tot);
             }
             if (prof) HIP_TRY(c, hipEventRecord(c->kev[ev0 + 4 * (nstep - 1) + 0], q));
-            auto row_pass = [&](const HadiSweepArgs &ar, int mode) {
-                if (pl.row_seq) {  // more than 1024 s-intervals: one lane per v-row, sequential along s
-                    const dim3 g((unsigned)(nsb * ((L.nrows + 63) / 64))), b(64);
-                    if (american) hipLaunchKernelGGL((hadi_pass_a_seq<1>), g, b, 0, q, ar, nstep);
-                    else hipLaunchKernelGGL((hadi_pass_a_seq<0>), g, b, 0, q, ar, nstep);
-                    return;
-                }
-                if (pl.use_pairs && pl.use_strip && mode == 0 && !f32) {  // 4 nodes per lane: two strips per wavefront
-                    const dim3 g(pl.grid_as), b(64 * HADI_PAIR_WAVES);
-                    if (amp && !xstep) hipLaunchKernelGGL((hadi_pass_a_pairs<2>), g, b, pl.smem_pairs_amp, q, ar, nstep);
-                    else if (american) hipLaunchKernelGGL((hadi_pass_a_pairs<1>), g, b, pl.smem_pairs_eu, q, ar, nstep);
-                    else hipLaunchKernelGGL((hadi_pass_a_pairs<0>), g, b, pl.smem_pairs_eu, q, ar, nstep);
-                    return;
-                }
-                if (amp && !xstep && pl.use_strip && mode == 0) {  // P representation on barrier-free strips
-                    const dim3 g(pl.grid_as), b(64 * HADI_STRIP_WAVES(L.B));
-                    const size_t sm = pl.smem_as + (size_t)L.rowp * sizeof(double);  // + the payoff row
-                    if (L.G == 2) {  // paired strips (two wavefronts per row)
-                        hipLaunchKernelGGL((hadi_pass_a_strip<8, 2, double, 2>), g, b, sm, q, ar, nstep);
-                        return;
-                    }
-                    switch (L.B) {
-                        case 8: hipLaunchKernelGGL((hadi_pass_a_strip<8, 2>), g, b, sm, q, ar, nstep); break;
-                        case 4: hipLaunchKernelGGL((hadi_pass_a_strip<4, 2>), g, b, sm, q, ar, nstep); break;
-                        default: hipLaunchKernelGGL((hadi_pass_a_strip<2, 2>), g, b, sm, q, ar, nstep); break;
-                    }
-                    return;
-                }
-                if (amp && !xstep) {
-                    switch (L.B * 10 + L.G) {
-                        case 11: launch_pass_a_amp<1, 1, 1, 2>(pl, ar, nstep, q); break;
-                        case 21: launch_pass_a_amp<2, 1, 1, 2>(pl, ar, nstep, q); break;
-                        case 41: launch_pass_a_amp<4, 1, 1, 2>(pl, ar, nstep, q); break;
-                        case 81: launch_pass_a_amp<8, 1, 1, 1>(pl, ar, nstep, q); break;
-                        default: launch_pass_a_amp<8, 2, 1, 1>(pl, ar, nstep, q); break;
-                    }
-                    return;
-                }
-                if (f32 && pl.use_strip && L.B == 8 && L.G == 2) {  // fp32 state, 512 < m1 <= 1024: paired strips
-                    hipLaunchKernelGGL((hadi_pass_a_strip<8, false, float, 2>), dim3(pl.grid_as), dim3(512), pl.smem_as, q, ar, nstep);
-                    return;
-                }
-                if (f32 && pl.use_strip && L.B == 8) {  // fp32 state, 8 nodes per lane, large batch: strips with a ring of floats
-                    const size_t smem = (size_t)8 * 4 * L.rowp * sizeof(float) + (size_t)4 * 64 * L.B * sizeof(double);
-                    hipLaunchKernelGGL((hadi_pass_a_strip<8, false, float>), dim3(pl.grid_as), dim3(512), smem, q, ar, nstep);
-                    return;
-                }
-                if (f32) {  // fp32 state: shared-ring kernel for the other shapes
-                    switch (L.B * 10 + L.G) {
-                        case 11: launch_pass_a_f32<1, 1, 1, 2>(pl, ar, nstep, q); break;
-                        case 21: launch_pass_a_f32<2, 1, 1, 2>(pl, ar, nstep, q); break;
-                        case 41: launch_pass_a_f32<4, 1, 1, 2>(pl, ar, nstep, q); break;
-                        case 81: launch_pass_a_f32<8, 1, 1, 1>(pl, ar, nstep, q); break;
-                        default: launch_pass_a_f32<8, 2, 1, 1>(pl, ar, nstep, q); break;
-                    }
-                    return;
-                }
-                if (pl.use_strip && mode == 0 && L.G == 2) {  // paired strips (Douglas step, two wavefronts per row)
-                    if (american) hipLaunchKernelGGL((hadi_pass_a_strip<8, 1, double, 2>), dim3(pl.grid_as), dim3(512), pl.smem_as, q, ar, nstep);
-                    else hipLaunchKernelGGL((hadi_pass_a_strip<8, false, double, 2>), dim3(pl.grid_as), dim3(512), pl.smem_as, q, ar, nstep);
-                    return;
-                }
-                if (pl.use_strip && mode == 0) {  // barrier-free strips (Douglas step, one wavefront per row)
-                    const dim3 g(pl.grid_as), b(64 * HADI_STRIP_WAVES(L.B));
-                    switch (L.B * 2 + (american ? 1 : 0)) {
-                        case 16: hipLaunchKernelGGL((hadi_pass_a_strip<8, false>), g, b, pl.smem_as, q, ar, nstep); break;
-                        case 17: hipLaunchKernelGGL((hadi_pass_a_strip<8, true>), g, b, pl.smem_as, q, ar, nstep); break;
-                        case 8: hipLaunchKernelGGL((hadi_pass_a_strip<4, false>), g, b, pl.smem_as, q, ar, nstep); break;
-                        case 9: hipLaunchKernelGGL((hadi_pass_a_strip<4, true>), g, b, pl.smem_as, q, ar, nstep); break;
-                        case 4: hipLaunchKernelGGL((hadi_pass_a_strip<2, false>), g, b, pl.smem_as, q, ar, nstep); break;
-                        default: hipLaunchKernelGGL((hadi_pass_a_strip<2, true>), g, b, pl.smem_as, q, ar, nstep); break;
-                    }
-                    return;
-                }
-                switch (L.B * 10 + L.G) {
-                    case 11: launch_pass_a<1, 1, 1, 2>(pl, ar, nstep, q, mode); break;
-                    case 21: launch_pass_a<2, 1, 1, 2>(pl, ar, nstep, q, mode); break;
-                    case 41: launch_pass_a<4, 1, 1, 2>(pl, ar, nstep, q, mode); break;
-                    case 81: launch_pass_a<8, 1, 1, 1>(pl, ar, nstep, q, mode); break;
-                    default: launch_pass_a<8, 2, 1, 1>(pl, ar, nstep, q, mode); break;
-                }
-            };
-            auto col_pass = [&](const HadiSweepArgs &ar) {
-                // up to 8 chunks: 512-thread blocks with two register buffers (2 waves per SIMD); 9..16 chunks: the
-                // 1024-thread block leaves 128 VGPRs per lane, which only the single-buffer kernel fits
-                // (measured at 1024x512: 0.250 vs 0.382 ms/launch for the double-buffered code, which spills)
-                const dim3 g(pl.grid_b), b(pl.block_b);
-                if (pl.col_seq) {  // more than 16 chunks of v-rows: one lane per storage column, sequential along v
-                    const dim3 gs((unsigned)(nsb * pl.ctiles)), bs(64);
-                    if (american) hipLaunchKernelGGL((hadi_pass_b_seq<1>), gs, bs, 0, q, ar, nstep);
-                    else hipLaunchKernelGGL((hadi_pass_b_seq<0>), gs, bs, 0, q, ar, nstep);
-                    return;
-                }
-                if (amp && !xstep) {
-                    if (L.P <= 8) hipLaunchKernelGGL((hadi_pass_b<8, 2>), g, b, pl.smem_b, q, ar, nstep);
-                    else hipLaunchKernelGGL((hadi_pass_b1<16, 2>), g, b, pl.smem_b, q, ar, nstep);
-                    return;
-                }
-                if (f32) {
-                    if (L.P <= 8) hipLaunchKernelGGL((hadi_pass_b<8, false, float>), g, b, pl.smem_b, q, ar, nstep);
-                    else if (c->col_prefetch) hipLaunchKernelGGL((hadi_pass_b2<16, float, HADI_B2_NPF(4)>), g, b, pl.smem_b2, q, ar, nstep);
-                    else hipLaunchKernelGGL((hadi_pass_b1<16, false, float>), g, b, pl.smem_b, q, ar, nstep);
-                    return;
-                }
-                if (L.P <= 8) {
-                    if (american) hipLaunchKernelGGL((hadi_pass_b<8, true>), g, b, pl.smem_b, q, ar, nstep);
-                    else hipLaunchKernelGGL((hadi_pass_b<8, false>), g, b, pl.smem_b, q, ar, nstep);
-                } else {
-                    if (american) hipLaunchKernelGGL((hadi_pass_b1<16, true>), g, b, pl.smem_b, q, ar, nstep);
-                    else if (c->col_prefetch) hipLaunchKernelGGL((hadi_pass_b2<16, double, HADI_B2_NPF(8)>), g, b, pl.smem_b2, q, ar, nstep);
-                    else hipLaunchKernelGGL((hadi_pass_b1<16, false>), g, b, pl.smem_b, q, ar, nstep);
-                }
-            };
+            const PassEnv env{pl, L, nsb, q, nstep, american, amp, xstep, f32, c->col_prefetch};
+            auto row_pass = [&](const HadiSweepArgs &ar, int mode) { launch_row_pass(env, ar, mode); };
+            auto col_pass = [&](const HadiSweepArgs &ar) { launch_col_pass(env, ar); };
             if (d.debug == 2) {  // diagnostics: one column solve of the packed input (moved to Y), nothing else
                 HIP_TRY(c, hipMemcpyAsync(a.Y, a.U, f32 ? st / 2 : st, hipMemcpyDeviceToDevice, q));
                 col_pass(a);
@@ -726,8 +862,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                 return d.par8[(size_t)x * 8 + 5] > d.par8[(size_t)y * 8 + 5];
             });
             if ((rc = ensure(c, c->order, sizeof(int) * n))) return rc;
-            HIP_TRY(c, hipMemcpyAsync(c->order.p, order.data(), sizeof(int) * n, hipMemcpyHostToDevice, s));
-            HIP_TRY(c, hipStreamSynchronize(s));  // pageable staging vector leaves scope
+            if ((rc = stage_to_device(c, c->order.p, order.data(), sizeof(int) * n))) return rc;
             sm.order = ptr<int>(c->order);
         }
         sm.flag_stride = flag_stride;
@@ -765,43 +900,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         return HADI_OK;
     }
 
-    {
-        char buf[256];
-        char rowk[96];
-        if (amp && pl.use_strip && !cs && L.G == 2) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,AM-P,double,2> (paired strips of %d rows, no lambda_bar array)", pl.RS);
-        else if (amp && pl.use_strip && !cs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<%d,AM-P> (strips of %d rows, no lambda_bar array)", L.B, pl.RS);
-        else if (amp) std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,AM-P> (tiles of %d rows, no lambda_bar array)", L.B, L.G, pl.W, pl.NG, pl.PD, pl.R);
-        else if (f32 && pl.use_strip && L.B == 8 && L.G == 2) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,EU,float,2> (paired strips of %d rows, fp32 state)", pl.RS);
-        else if (f32 && pl.use_strip && L.B == 8) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,EU,float> (strips of %d rows, fp32 state)", pl.RS);
-        else if (f32) std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,EU,float> (tiles of %d rows, fp32 state)", L.B, L.G, pl.W, pl.NG, pl.PD, pl.R);
-        else if (pl.use_strip && !cs && L.G == 2) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,%s,double,2> (paired strips of %d rows)", american ? "AM" : "EU", pl.RS);
-        else if (pl.use_strip && !cs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<%d,%s> (strips of %d rows)", L.B, american ? "AM" : "EU", pl.RS);
-        else std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,%s%s> (tiles of %d rows)", L.B, L.G, pl.W, pl.NG, pl.PD,
-                           american ? "AM" : "EU", cs ? ",CS" : "", pl.R);
-        if (pl.use_pairs && pl.use_strip && !cs && !f32)
-            std::snprintf(rowk, sizeof rowk, "hadi_pass_a_pairs<%s> (two strips of %d rows per wavefront%s)", amp ? "AM-P" : american ? "AM" : "EU", pl.RS,
-                          amp ? ", no lambda_bar array" : "");
-        if (pl.row_seq) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_seq<%s> (one lane per v-row, sequential along s)", american ? "AM" : "EU");
-        if (pl.col_seq)
-            std::snprintf(buf, sizeof buf, "row pass %s; column pass hadi_pass_b_seq<%s> (one lane per column, sequential along v)", rowk, american ? "AM" : "EU");
-        else
-            std::snprintf(buf, sizeof buf, "row pass %s; column pass %s<%d,%s> (%d chunks of %d rows, %d column tiles per block)", rowk,
-                          L.P <= 8 ? "hadi_pass_b" : (!american && c->col_prefetch) ? "hadi_pass_b2" : "hadi_pass_b1", L.P <= 8 ? 8 : 16,
-                          amp ? "AM-P" : american ? "AM" : "EU", L.P, HADI_LC, pl.btpw);
-        c->last_path = buf;
-        if (nsub > 1) {
-            bool same = true;
-            for (auto &sbt : subs) same = same && sbt.cnt == subs[0].cnt;
-            if (same) c->last_path += "; " + std::to_string(nsub) + " sub-batches of " + std::to_string(subs[0].cnt) + " instances";
-            else {
-                c->last_path += "; " + std::to_string(nsub) + " sub-batches of";
-                for (auto &sbt : subs) c->last_path += " " + std::to_string(sbt.cnt);
-                c->last_path += " instances (each with the geometry of its own size)";
-            }
-            if (two_streams && fork_before > 0) c->last_path += ", the last two side by side on two streams";
-            else if (two_streams) c->last_path += ", side by side on two streams";
-        }
-    }
+    c->last_path = describe_streaming_path(c, pl, bp, american, amp, cs, f32);
     c->last_nsub = nsub;
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     // ---- instance-resident launch: up to 8 large European instances, one per XCD, whole time loop in one kernel ----------
@@ -914,6 +1013,7 @@ int finish_timing(Ctx *c, const SweepDesc &d, const HadiPlan &pl) {
     hipStream_t s = c->stream;
     HIP_TRY(c, hipEventRecord(c->ev[3], s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    c->pin_dirty = 0;
     // the sticky device error word (see Ctx::err_host): whatever a kernel of this call reported is visible now
     const int deverr = __atomic_exchange_n(c->err_host, 0, __ATOMIC_ACQ_REL);
     float ms = 0;
@@ -1046,11 +1146,10 @@ int rebuild_v_device(Ctx *c, int n, int m2, const std::vector<double> &v0i) {
     if ((rc = ensure(c, c->v0_i, (size_t)n * 8)) || (rc = ensure(c, c->g_v, (size_t)n * (m2 + 1) * 8)) ||
         (rc = ensure(c, c->g_dv, (size_t)n * m2 * 8)))
         return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->v0_i.p, v0i.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    if ((rc = stage_to_device(c, c->v0_i.p, v0i.data(), (size_t)n * 8))) return rc;
     hipLaunchKernelGGL(hadi_rebuild_variance_kernel, dim3(n), dim3(256), (size_t)2 * (m2 + 1) * sizeof(double), c->stream, m2, n,
                        ptr<double>(c->v0_i), 5.0, 5.0 / 500, ptr<double>(c->g_v), ptr<double>(c->g_dv));
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream));  // v0i is the caller's (pageable) vector
     return HADI_OK;
 }
 
@@ -1066,6 +1165,7 @@ int solve_common(Ctx *c, const hadi_problem *p, bool rebuild_v, bool pick, doubl
     if (debug == 2 && p->variant != HADI_EU && p->variant != HADI_DIV)
         return fail(c, HADI_ERR_UNSUPPORTED, "hadi_debug_col_solve is the plain A2 solve (no projection): European variants only");
     DeviceGuard guard(c->device);
+    pin_rewind(c);
     const int n = p->n_instances, m1 = p->m1, m2 = p->m2;
     const size_t m = (size_t)(m1 + 1) * (m2 + 1);
     SweepDesc d;
@@ -1091,13 +1191,11 @@ int solve_common(Ctx *c, const hadi_problem *p, bool rebuild_v, bool pick, doubl
         build_v(m2, V_0, 5.0, 5.0 / 500, hv.data(), hdv.data());
         if ((rc = ensure(c, c->src_v, (m2 + 1) * 8)) || (rc = ensure(c, c->src_dv, m2 * 8))) return rc;
         if ((rc = ensure(c, c->g_v, (size_t)n * (m2 + 1) * 8)) || (rc = ensure(c, c->g_dv, (size_t)n * m2 * 8))) return rc;
-        HIP_TRY(c, hipMemcpyAsync(c->src_v.p, hv.data(), (m2 + 1) * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->src_dv.p, hdv.data(), m2 * 8, hipMemcpyHostToDevice, c->stream));
+        if ((rc = stage_to_device(c, c->src_v.p, hv.data(), (size_t)(m2 + 1) * 8)) || (rc = stage_to_device(c, c->src_dv.p, hdv.data(), (size_t)m2 * 8))) return rc;
         hipLaunchKernelGGL(hadi_bcast_rows_kernel, dim3(grid1d((size_t)n * (m2 + 1))), dim3(256), 0, c->stream, m2 + 1, n,
                            ptr<double>(c->src_v), (const int *)nullptr, ptr<double>(c->g_v));
         hipLaunchKernelGGL(hadi_bcast_rows_kernel, dim3(grid1d((size_t)n * m2)), dim3(256), 0, c->stream, m2, n,
                            ptr<double>(c->src_dv), (const int *)nullptr, ptr<double>(c->g_dv));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));  // hv/hdv leave scope
         d.d_vec_v = ptr<double>(c->g_v);
         d.d_delta_v = ptr<double>(c->g_dv);
     } else {
@@ -1156,6 +1254,7 @@ int jacobian_common(Ctx *c, const hadi_problem *p, double S_0, double V_0, doubl
     int rc = check_problem(c, p, false, false);
     if (rc) return rc;
     DeviceGuard guard(c->device);
+    pin_rewind(c);
     if (!p->U_0) return fail(c, HADI_ERR_INVALID, "U_0 (initial condition) is required for the Jacobian");
     if (!J || !base_prices) return fail(c, HADI_ERR_INVALID, "J / base_prices missing");
     const int n0 = p->n_instances, m1 = p->m1, m2 = p->m2, G = 6;
@@ -1193,7 +1292,7 @@ int jacobian_common(Ctx *c, const hadi_problem *p, double S_0, double V_0, doubl
         (rc = ensure(c, c->g_dv, (size_t)n * m2 * 8)))
         return rc;
     hipStream_t s = c->stream;
-    HIP_TRY(c, hipMemcpyAsync(c->sel_a.p, sel_a.data(), n * sizeof(int), hipMemcpyHostToDevice, s));
+    if ((rc = stage_to_device(c, c->sel_a.p, sel_a.data(), n * sizeof(int)))) return rc;
     hipLaunchKernelGGL(hadi_bcast_rows_kernel, dim3(grid1d((size_t)n * (m1 + 1))), dim3(256), 0, s, m1 + 1, n, src_s,
                        ptr<int>(c->sel_a), ptr<double>(c->g_s));
     hipLaunchKernelGGL(hadi_bcast_rows_kernel, dim3(grid1d((size_t)n * m1)), dim3(256), 0, s, m1, n, src_ds,
@@ -1206,16 +1305,16 @@ int jacobian_common(Ctx *c, const hadi_problem *p, double S_0, double V_0, doubl
     } else {
         build_v(m2, V_0, 5.0, 5.0 / 500, hv.data(), hdv.data());
         build_v(m2, V_0 + eps, 5.0, 5.0 / 500, hv.data() + m2 + 1, hdv.data() + m2);
-        HIP_TRY(c, hipMemcpyAsync(c->sel_b.p, sel_b.data(), n * sizeof(int), hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(c->v0_i.p, v0i.data(), n * 8, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(c->src_v.p, hv.data(), 2 * (m2 + 1) * 8, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(c->src_dv.p, hdv.data(), 2 * m2 * 8, hipMemcpyHostToDevice, s));
+        if ((rc = stage_to_device(c, c->sel_b.p, sel_b.data(), n * sizeof(int))) || (rc = stage_to_device(c, c->v0_i.p, v0i.data(), (size_t)n * 8)) ||
+            (rc = stage_to_device(c, c->src_v.p, hv.data(), (size_t)2 * (m2 + 1) * 8)) || (rc = stage_to_device(c, c->src_dv.p, hdv.data(), (size_t)2 * m2 * 8)))
+            return rc;
         hipLaunchKernelGGL(hadi_bcast_rows_kernel, dim3(grid1d((size_t)n * (m2 + 1))), dim3(256), 0, s, m2 + 1, n,
                            ptr<double>(c->src_v), ptr<int>(c->sel_b), ptr<double>(c->g_v));
         hipLaunchKernelGGL(hadi_bcast_rows_kernel, dim3(grid1d((size_t)n * m2)), dim3(256), 0, s, m2, n,
                            ptr<double>(c->src_dv), ptr<int>(c->sel_b), ptr<double>(c->g_dv));
     }
-    HIP_TRY(c, hipStreamSynchronize(s));  // host vectors + natU/natOut staging are reused below
+    // (no synchronisation here: the host vectors above went through the pinned arena, and the device-side staging buffers natU /
+    // natOut are only reused by later operations of the same stream)
     d.d_vec_s = ptr<double>(c->g_s); d.d_delta_s = ptr<double>(c->g_ds);
     d.d_vec_v = ptr<double>(c->g_v); d.d_delta_v = ptr<double>(c->g_dv);
     // every solve starts from U_0 (jacobian_computation.cpp:307-309); payoff for American = U_0 too
@@ -1240,8 +1339,10 @@ int jacobian_common(Ctx *c, const hadi_problem *p, double S_0, double V_0, doubl
         HIP_TRY(c, hipMemcpyAsync(J, dJ, (size_t)n0 * 5 * 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipMemcpyAsync(base_prices, db, (size_t)n0 * 8, hipMemcpyDeviceToHost, s));
     }
-    std::vector<int> hs(n);
-    HIP_TRY(c, hipMemcpyAsync(hs.data(), c->status.p, n * sizeof(int), hipMemcpyDeviceToHost, s));
+    std::vector<int> hs_fallback;
+    int *hs = static_cast<int *>(pin_alloc(c, (size_t)n * sizeof(int)));  // (pinned: the copy does not block the host)
+    if (!hs) { hs_fallback.resize(n); hs = hs_fallback.data(); }
+    HIP_TRY(c, hipMemcpyAsync(hs, c->status.p, n * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipGetLastError());
     if ((rc = finish_timing(c, d, pl))) return rc;
     for (int k = 0; k < n0; k++)
@@ -1277,6 +1378,7 @@ void release_handle(Ctx *c) {
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->err_host) (void)hipHostFree(c->err_host);
+    if (c->pin) (void)hipHostFree(c->pin);
     delete c;
 }
 
@@ -1346,6 +1448,8 @@ int hadi_create(hadi_ctx **out, int device_id) {
     ok = ok && hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&c->err_host), 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
     if (ok) {
+        c->pin_want = (size_t)1 << 20;  // 1 MB to start with (3000 instances' parameter rows are 192 KB)
+        pin_rewind(c);
         *c->err_host = 0;
         ok = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->err_dev), c->err_host, 0) == hipSuccess;
     }

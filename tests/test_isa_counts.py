@@ -36,7 +36,7 @@ def kernels():
 def test_python_mirrors_match_the_source():
     """The formulas above are mirrors of hadi_put_block_stores / HADI_ROW_PAD / HADI_STRIP_NS: tie them to the source text."""
     csrc = os.path.join(ROOT, "pde_based_heston_solver_gpu_accelerated_amd", "csrc")
-    k = open(os.path.join(csrc, "hadi_kernels.h")).read()
+    k = "".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)) if f.startswith("hadi_k"))
     c = open(os.path.join(csrc, "hadi_core.h")).read()
     assert "return B == 1 ? 1 : (sizeof(T) == 4 && B >= 4) ? B / 4 : B / 2;" in k
     assert "for (int k = 0; k < NA; k++) aft[k] += hadi_put_block_stores<B, T>();" in k      # strips
@@ -92,7 +92,7 @@ def test_pair_strip_kernels_issue_the_dma_pieces_and_stores_the_waits_count(kern
     tails), four fetch sites (three in the prologue, one in the loop; the P representation fetches row js instead of the row
     4 ahead), HADI_PAIR_STORES = 4 counted row stores per step (one copy of the step)."""
     csrc = os.path.join(ROOT, "pde_based_heston_solver_gpu_accelerated_amd", "csrc")
-    k = open(os.path.join(csrc, "hadi_kernels.h")).read()
+    k = "".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)) if f.startswith("hadi_k"))
     assert "#define HADI_PAIR_DMA 6" in k and "#define HADI_PAIR_STORES 4" in k
     seen = 0
     for name, body in kernels.items():
