@@ -437,8 +437,7 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
     if (logical >= a.n_inst * a.bgroups) return;  // grid padded to a multiple of 8 (whole block: uniform)
     const int binst = logical / a.bgroups, grp = logical - binst * a.bgroups;
     const int inst = a.n_inst - 1 - binst;
-    const HadiInstPar ip = a.ipar[inst];
-    if (n > ip.N) return;  // whole block: uniform
+    const HadiInstPar ip = a.ipar[inst];  // (requested here, consumed behind the first tile's loads: see hadi_pass_a_strip)
     const int nrows = a.L.nrows_pad;
     c.nrows = a.L.nrows;
     c.rowp = a.L.rowp;
@@ -451,10 +450,8 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
     c.Lb = hadi_make_buf(c.Li, (AMER == 1) ? (size_t)a.L.inst_stride * sizeof(double) : 0);
     c.P0i = AMER ? a.U0 + (size_t)inst * a.L.inst_stride : nullptr;
     c.pay1d = AMER ? (a.pay_mis[inst] == 0) : 0;
-    c.inv_dt = 1.0 / ip.dt;
     c.american = a.american; c.debug = a.debug;
     c.pos_m1 = a.pos_m1;
-    c.dt = ip.dt;
     c.tabl = nullptr;
     const HadiTileSet ts = hadi_pb_tiles(a, grp);
     const int cnt = ts.cnt;
@@ -466,6 +463,9 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
 #endif
     double ya[HADI_LC], yb[HADI_LC];
     hadi_pb_load<T>(c, tile(0), ya);
+    if (n > ip.N) return;  // whole block: uniform (this instance has fewer time steps; the loads above land in dead registers)
+    c.inv_dt = 1.0 / ip.dt;
+    c.dt = ip.dt;
     const bool am_fast = (AMER == 2) || (AMER == 1 && c.pay1d != 0);  // block-uniform
     // the chunk's table (identical for every column) is spread over the lanes' registers once per block
     hadi_pb_load_table(c, a.pb + ((size_t)inst * nrows + c.ja) * HADI_PBW);
@@ -542,8 +542,7 @@ __global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, in
     if (logical >= a.n_inst * a.bgroups) return;  // grid padded to a multiple of 8 (whole block: uniform)
     const int binst = logical / a.bgroups, grp = logical - binst * a.bgroups;
     const int inst = a.n_inst - 1 - binst;
-    const HadiInstPar ip = a.ipar[inst];
-    if (n > ip.N) return;  // whole block: uniform
+    const HadiInstPar ip = a.ipar[inst];  // (requested here, consumed behind the first tile's loads: see hadi_pass_a_strip)
     const int nrows = a.L.nrows_pad;
     c.nrows = a.L.nrows;
     c.rowp = a.L.rowp;
@@ -556,10 +555,8 @@ __global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, in
     c.Lb = hadi_make_buf(c.Li, (AMER == 1) ? (size_t)a.L.inst_stride * sizeof(double) : 0);
     c.P0i = AMER ? a.U0 + (size_t)inst * a.L.inst_stride : nullptr;
     c.pay1d = AMER ? (a.pay_mis[inst] == 0) : 0;
-    c.inv_dt = 1.0 / ip.dt;
     c.american = a.american; c.debug = a.debug;
     c.pos_m1 = a.pos_m1;
-    c.dt = ip.dt;
     c.tabl = nullptr;
     const HadiTileSet ts = hadi_pb_tiles(a, grp);
     const int cnt = ts.cnt;
@@ -571,6 +568,9 @@ __global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, in
 #endif
     double y[HADI_LC];
     hadi_pb_load<T>(c, tile(0), y);
+    if (n > ip.N) return;  // whole block: uniform
+    c.inv_dt = 1.0 / ip.dt;
+    c.dt = ip.dt;
     // the chunk's table (identical for every column) is spread over the lanes' registers once per block
     hadi_pb_load_table(c, a.pb + ((size_t)inst * nrows + c.ja) * HADI_PBW);
     hadi_pb_setup_lds<HADI_PB_MF != 0>(c, smem, a.rinv + (size_t)inst * 16 * c.P * c.P, 2);

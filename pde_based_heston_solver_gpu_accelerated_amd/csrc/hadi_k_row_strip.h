@@ -464,8 +464,10 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     const int logical = hadi_xcd_remap(blockIdx.x, gridDim.x);
     if (logical >= total) return;
     const int inst = logical / a.sblocks, sb = logical - inst * a.sblocks;
+    // The instance's parameter block is REQUESTED here and CONSUMED behind the prologue's row fetches (round 4): consumed at
+    // once -- `if (n > ip.N) return` -- its memory round trip (1 - 2 us, one per launch and wavefront, nothing to overlap it
+    // with) stood in front of every other load of the prologue; a launch of short strips is mostly prologue.
     const HadiInstPar ip = a.ipar[inst];
-    if (n > ip.N) return;
     const int nrows = a.L.nrows, npad = a.L.nrows_pad, rowp = a.L.rowp;
     double *coef = reinterpret_cast<double *>(reinterpret_cast<T *>(smem) + (size_t)NPAIR * NS * rowp);
     // P representation: the payoff row (it depends on s only: v-row 0 of the packed payoff) behind the coefficient arrays;
@@ -483,12 +485,6 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     double *const xch0 = coef + 4 * 64 * B * G + (AMER == 2 ? rowp : 0);  // the pairs' exchange buffers (behind the payoff row)
     c.xch = xch0 + pair * 16;
     c.err = a.err; c.debug = a.debug;
-    c.dt = hadi_uniform_d(ip.dt); c.thdt = hadi_uniform_d(ip.thdt);
-    c.c1 = hadi_uniform_d(1.0 + ip.thdt * ip.half_rd);
-    c.kap = hadi_uniform_d((ip.dt - ip.thdt) / ip.thdt);  // the host keeps theta = 0 off this kernel
-    c.hr0 = hadi_uniform_d(ip.hr0); c.inv0 = hadi_uniform_d(1.0 / (1.0 + ip.thdt * ip.hr0));
-    c.e_nm1 = hadi_uniform_d(exp(ip.bc_rate * ip.dt * (n - 1)));  // device_solver.hpp:238
-    c.e_n = hadi_uniform_d(exp(ip.bc_rate * ip.dt * n));          // device_solver.hpp:246
     const T *__restrict__ Ub = reinterpret_cast<const T *>(a.U) + (size_t)inst * a.L.inst_stride;
     c.Yi = reinterpret_cast<T *>(a.Y) + (size_t)inst * a.L.inst_stride;
     c.Li = (AMER == 1) ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
@@ -496,7 +492,6 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     // P representation: 1/dt, and which node is s_max (lambda_bar stays 0 there, as in hadi_row_step)
     c.inv_dt = 0.0; c.m1_lane = -1; c.m1_r = -1;
     if constexpr (AMER == 2) {
-        c.inv_dt = hadi_uniform_d(1.0 / ip.dt);
         const int e1 = a.L.m1 - 1;  // node i = m1 is element m1 - 1 of the row's 64 B G interior nodes
         if (e1 / (64 * B) == half) {
             c.m1_lane = (e1 - half * 64 * B) / B;
@@ -573,6 +568,20 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
         c0vec = (half == 0 && lane < 4 && row_ok(rr)) ? (double)Ub[(ptrdiff_t)rr * rowp + c0slot] : 0.0;
         if constexpr (G > 1) evec = (lane < 4 && row_ok(rr)) ? (double)Ub[(ptrdiff_t)rr * rowp + epos] : 0.0;
     }
+    // ---- the instance's parameters are consumed here, behind the row fetches (see the top) ----
+    if (n > ip.N) {  // (block-uniform: this instance has fewer time steps -- multi-maturity batches)
+#if !defined(HADI_EMU)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA of this wavefront may outlive it
+#endif
+        return;
+    }
+    c.dt = hadi_uniform_d(ip.dt); c.thdt = hadi_uniform_d(ip.thdt);
+    c.c1 = hadi_uniform_d(1.0 + ip.thdt * ip.half_rd);
+    c.kap = hadi_uniform_d((ip.dt - ip.thdt) / ip.thdt);  // the host keeps theta = 0 off this kernel
+    c.hr0 = hadi_uniform_d(ip.hr0); c.inv0 = hadi_uniform_d(1.0 / (1.0 + ip.thdt * ip.hr0));
+    c.e_nm1 = hadi_uniform_d(exp(ip.bc_rate * ip.dt * (n - 1)));  // device_solver.hpp:238
+    c.e_n = hadi_uniform_d(exp(ip.bc_rate * ip.dt * n));          // device_solver.hpp:246
+    if constexpr (AMER == 2) c.inv_dt = hadi_uniform_d(1.0 / ip.dt);
     {   // s-coefficient arrays to LDS; the two beta arrays scaled by -theta dt (r_d - r_f) on the way (hadi_strip_step)
         const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B * G;
         const double mq = -(ip.thdt * ip.q);
@@ -1030,8 +1039,7 @@ __global__ void __launch_bounds__(64 * HADI_PAIR_WAVES, 2) hadi_pass_a_pairs(Had
     const int logical = hadi_xcd_remap(blockIdx.x, gridDim.x);
     if (logical >= total) return;
     const int inst = logical / a.sblocks, sb = logical - inst * a.sblocks;
-    const HadiInstPar ip = a.ipar[inst];
-    if (n > ip.N) return;
+    const HadiInstPar ip = a.ipar[inst];  // (requested here, consumed behind the row fetches: hadi_pass_a_strip)
     const int nrows = a.L.nrows;
     double *ring = smem + (size_t)wave * NS * HADI_PAIR_SLOT;
     double *coef = smem + (size_t)NWV * NS * HADI_PAIR_SLOT;
@@ -1048,12 +1056,6 @@ __global__ void __launch_bounds__(64 * HADI_PAIR_WAVES, 2) hadi_pass_a_pairs(Had
 
     HadiStripCtxT<double> c;
     c.lane = lane; c.rowp = ROWP; c.coef = coef; c.half = 0; c.xch = nullptr; c.err = a.err; c.debug = a.debug;
-    c.dt = hadi_uniform_d(ip.dt); c.thdt = hadi_uniform_d(ip.thdt);
-    c.c1 = hadi_uniform_d(1.0 + ip.thdt * ip.half_rd);
-    c.kap = hadi_uniform_d((ip.dt - ip.thdt) / ip.thdt);
-    c.hr0 = hadi_uniform_d(ip.hr0); c.inv0 = hadi_uniform_d(1.0 / (1.0 + ip.thdt * ip.hr0));
-    c.e_nm1 = hadi_uniform_d(exp(ip.bc_rate * ip.dt * (n - 1)));  // device_solver.hpp:238
-    c.e_n = hadi_uniform_d(exp(ip.bc_rate * ip.dt * n));          // device_solver.hpp:246
     const double *__restrict__ Ub = a.U + (size_t)inst * a.L.inst_stride;
     double *__restrict__ Yb = a.Y + (size_t)inst * a.L.inst_stride;
     const double *__restrict__ Lb = (AMER == 1) ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
@@ -1061,7 +1063,6 @@ __global__ void __launch_bounds__(64 * HADI_PAIR_WAVES, 2) hadi_pass_a_pairs(Had
     c.b2r = a.b2row + (size_t)inst * ROWP;
     c.inv_dt = 0.0; c.m1_lane = -1; c.m1_r = -1;
     if constexpr (AMER == 2) {
-        c.inv_dt = hadi_uniform_d(1.0 / ip.dt);
         c.m1_lane = (a.L.m1 - 1) >> 3;
         c.m1_r = (a.L.m1 - 1) & 7;
     }
@@ -1104,6 +1105,20 @@ __global__ void __launch_bounds__(64 * HADI_PAIR_WAVES, 2) hadi_pass_a_pairs(Had
 #pragma unroll
         for (int r = 0; r < 8; r++) um2[r] = um1[r] = u0[r] = 0.0;
     }
+    // ---- the instance's parameters are consumed here, behind the row fetches ----
+    if (n > ip.N) {  // (block-uniform: multi-maturity batches)
+#if !defined(HADI_EMU)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA of this wavefront may outlive it
+#endif
+        return;
+    }
+    c.dt = hadi_uniform_d(ip.dt); c.thdt = hadi_uniform_d(ip.thdt);
+    c.c1 = hadi_uniform_d(1.0 + ip.thdt * ip.half_rd);
+    c.kap = hadi_uniform_d((ip.dt - ip.thdt) / ip.thdt);
+    c.hr0 = hadi_uniform_d(ip.hr0); c.inv0 = hadi_uniform_d(1.0 / (1.0 + ip.thdt * ip.hr0));
+    c.e_nm1 = hadi_uniform_d(exp(ip.bc_rate * ip.dt * (n - 1)));  // device_solver.hpp:238
+    c.e_n = hadi_uniform_d(exp(ip.bc_rate * ip.dt * n));          // device_solver.hpp:246
+    if constexpr (AMER == 2) c.inv_dt = hadi_uniform_d(1.0 / ip.dt);
     {
         const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 256;
         const double mq = -(ip.thdt * ip.q);

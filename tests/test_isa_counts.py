@@ -25,7 +25,9 @@ def kernels():
     import kernel_regs
     _, asm = kernel_regs.collect()
     out = {}
-    for m in re.finditer(r"^(_Z\w+):.*?\n(.*?)^\s*s_endpgm", asm, re.S | re.M):
+    # (a kernel's text runs to its .Lfunc_end label: an early exit -- e.g. the strips' "this instance has fewer time steps" -- puts an
+    # s_endpgm in the middle)
+    for m in re.finditer(r"^(_Z\w+):.*?\n(.*?)^\.Lfunc_end\d+:", asm, re.S | re.M):
         name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
         if name.startswith("void hadi_pass_a"):
             out[name.replace("(HadiSweepArgs, int)", "").replace("void ", "")] = m.group(2)
