@@ -463,13 +463,14 @@ __global__ void __launch_bounds__(64 * MAXP) hadi_pass_b(HadiSweepArgs a, int n)
 #endif
     double ya[HADI_LC], yb[HADI_LC];
     hadi_pb_load<T>(c, tile(0), ya);
-    if (n > ip.N) return;  // whole block: uniform (this instance has fewer time steps; the loads above land in dead registers)
-    c.inv_dt = 1.0 / ip.dt;
-    c.dt = ip.dt;
     const bool am_fast = (AMER == 2) || (AMER == 1 && c.pay1d != 0);  // block-uniform
     // the chunk's table (identical for every column) is spread over the lanes' registers once per block
     hadi_pb_load_table(c, a.pb + ((size_t)inst * nrows + c.ja) * HADI_PBW);
     hadi_pb_setup_lds<HADI_PB_MF != 0>(c, smem, a.rinv + (size_t)inst * 16 * c.P * c.P, 2);
+    // the instance's parameters are consumed HERE, behind the first tile's loads and the tables' (hadi_pass_a_strip)
+    if (n > ip.N) return;  // whole block: uniform (this instance has fewer time steps; the loads above land in dead registers)
+    c.inv_dt = 1.0 / ip.dt;
+    c.dt = ip.dt;
     __syncthreads();
     if constexpr (AMER != 0) {
         if (am_fast) {
@@ -568,12 +569,12 @@ __global__ void __launch_bounds__(64 * MAXP, 4) hadi_pass_b1(HadiSweepArgs a, in
 #endif
     double y[HADI_LC];
     hadi_pb_load<T>(c, tile(0), y);
-    if (n > ip.N) return;  // whole block: uniform
-    c.inv_dt = 1.0 / ip.dt;
-    c.dt = ip.dt;
     // the chunk's table (identical for every column) is spread over the lanes' registers once per block
     hadi_pb_load_table(c, a.pb + ((size_t)inst * nrows + c.ja) * HADI_PBW);
     hadi_pb_setup_lds<HADI_PB_MF != 0>(c, smem, a.rinv + (size_t)inst * 16 * c.P * c.P, 2);
+    if (n > ip.N) return;  // whole block: uniform (consumed behind the first tile's loads and the tables')
+    c.inv_dt = 1.0 / ip.dt;
+    c.dt = ip.dt;
     __syncthreads();
     // (fp32 state: holding the NEXT tile in 33 float registers so that its loads fly during the solve was tried -- 66 + 33 +
     // 10 table registers leave too few of the 128 for the reduced-system loop, the kernel spills 18 registers and the

@@ -568,6 +568,16 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
         c0vec = (half == 0 && lane < 4 && row_ok(rr)) ? (double)Ub[(ptrdiff_t)rr * rowp + c0slot] : 0.0;
         if constexpr (G > 1) evec = (lane < 4 && row_ok(rr)) ? (double)Ub[(ptrdiff_t)rr * rowp + epos] : 0.0;
     }
+    // the shared arrays' global loads are issued before the parameter block is consumed as well: the scaling by it and the
+    // LDS stores follow below (two dependent memory round trips of the prologue become one)
+    constexpr int NCOPY = (4 * 64 * B * G) / (64 * NWV);
+    static_assert(NCOPY * 64 * NWV == 4 * 64 * B * G, "coefficient arrays: whole rounds of the block");
+    double sc_tmp[NCOPY];
+    {
+        const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B * G;
+#pragma unroll
+        for (int q = 0; q < NCOPY; q++) sc_tmp[q] = sc[threadIdx.x + q * 64 * NWV];
+    }
     // ---- the instance's parameters are consumed here, behind the row fetches (see the top) ----
     if (n > ip.N) {  // (block-uniform: this instance has fewer time steps -- multi-maturity batches)
 #if !defined(HADI_EMU)
@@ -583,9 +593,12 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     c.e_n = hadi_uniform_d(exp(ip.bc_rate * ip.dt * n));          // device_solver.hpp:246
     if constexpr (AMER == 2) c.inv_dt = hadi_uniform_d(1.0 / ip.dt);
     {   // s-coefficient arrays to LDS; the two beta arrays scaled by -theta dt (r_d - r_f) on the way (hadi_strip_step)
-        const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 64 * B * G;
         const double mq = -(ip.thdt * ip.q);
-        for (int e = threadIdx.x; e < 4 * 64 * B * G; e += 64 * NWV) coef[e] = (e < 2 * 64 * B * G) ? mq * sc[e] : sc[e];
+#pragma unroll
+        for (int q = 0; q < NCOPY; q++) {
+            const int e = threadIdx.x + q * 64 * NWV;
+            coef[e] = (e < 2 * 64 * B * G) ? mq * sc_tmp[q] : sc_tmp[q];
+        }
     }
     if constexpr (AMER == 2) {
         const double *__restrict__ pg = a.U0 + (size_t)inst * a.L.inst_stride;
@@ -1105,6 +1118,12 @@ __global__ void __launch_bounds__(64 * HADI_PAIR_WAVES, 2) hadi_pass_a_pairs(Had
 #pragma unroll
         for (int r = 0; r < 8; r++) um2[r] = um1[r] = u0[r] = 0.0;
     }
+    double sc_tmp[4];  // (the shared arrays' global loads before the parameter block is consumed: hadi_pass_a_strip)
+    {
+        const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 256;
+#pragma unroll
+        for (int q = 0; q < 4; q++) sc_tmp[q] = sc[threadIdx.x + q * 64 * NWV];
+    }
     // ---- the instance's parameters are consumed here, behind the row fetches ----
     if (n > ip.N) {  // (block-uniform: multi-maturity batches)
 #if !defined(HADI_EMU)
@@ -1120,9 +1139,12 @@ __global__ void __launch_bounds__(64 * HADI_PAIR_WAVES, 2) hadi_pass_a_pairs(Had
     c.e_n = hadi_uniform_d(exp(ip.bc_rate * ip.dt * n));          // device_solver.hpp:246
     if constexpr (AMER == 2) c.inv_dt = hadi_uniform_d(1.0 / ip.dt);
     {
-        const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 256;
         const double mq = -(ip.thdt * ip.q);
-        for (int e = threadIdx.x; e < 4 * 256; e += 64 * NWV) coef[e] = (e < 2 * 256) ? mq * sc[e] : sc[e];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int e = threadIdx.x + q * 64 * NWV;
+            coef[e] = (e < 2 * 256) ? mq * sc_tmp[q] : sc_tmp[q];
+        }
     }
     if constexpr (AMER == 2) {
         const double *__restrict__ pg = a.U0 + (size_t)inst * a.L.inst_stride;
