@@ -662,6 +662,9 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
         const int j = js + dir * t;
         HADI_STAMPC(30);  // carry + loop
         HadiSRow srow;
+        // (round 4, measured and dropped: requesting the entry one step AHEAD -- at the end of the step before, the first one in
+        // the prologue -- keeps 24 scalar registers live across the loop edge; at 106 SGPRs the compiler parks them in VGPR
+        // lanes (two variants even spill to scratch): row pass +1.2 % at 33-row strips, +3 % at 9 rows, +6.5 % on paired strips)
         hadi_sload_issue(a.rowc + ((size_t)inst * nrows + j) * HADI_RC + HADI_SRC0, srow);  // flies during the DMA wait
         hadi_wave_rendezvous();
         // the row D ahead goes to the slot of row j (of row j - 1 when one slot is kept behind): that row is in registers,

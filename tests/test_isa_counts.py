@@ -106,3 +106,19 @@ def test_pair_strip_kernels_issue_the_dma_pieces_and_stores_the_waits_count(kern
         assert n_st >= 4, (name, n_st)
         seen += 1
     assert seen == 3
+
+
+def test_no_row_kernel_with_counted_waits_touches_scratch():
+    """The counted `s_waitcnt vmcnt(n)` of the strip and pair-strip kernels know the LDS-DMA pieces and the result stores of a
+    row step and nothing else: a register spilled into scratch is reloaded by a vector-memory operation inside the row loop
+    that the count does not include -- the wait would pass with a DMA piece still in flight (and, at best, the reload drains
+    the prefetch).  No such kernel may have a scratch segment or a spilled VGPR (compiler metadata, tools/kernel_regs.py)."""
+    import kernel_regs
+    rows, _ = kernel_regs.collect()
+    seen = 0
+    for name, vgpr, sgpr, spills, scratch, lds in rows:
+        if "hadi_pass_a_strip<" in name or "hadi_pass_a_pairs<" in name:
+            assert spills == 0 and scratch == 0, (name, vgpr, spills, scratch)
+            assert vgpr <= 256
+            seen += 1
+    assert seen >= 17
