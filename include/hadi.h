@@ -198,6 +198,12 @@ int hadi_get_timing(const hadi_ctx *ctx, hadi_timing *out);
  *                 behind its full rounds of one instance per CU) in two exactly when the plan's row pass leaves 4 % or more
  *                 of its CU-rounds idle (hadi_plan_row_idle) -- a function of the grid shape and the batch size alone.
  *                 With 2 the sub-batches of a large batch alternate between the streams; DESIGN.md section 7
+ *   "col_prefetch" 0 (default) / 1: European sweeps of 9 .. 16 chunks (264 <= m2 <= 527) on hadi_pass_b2 -- part of the next column
+ *                 tile prefetched into LDS by LDS-DMA -- instead of hadi_pass_b1; "tile_interleave" 0 (default) / 1: the blocks of
+ *                 an instance walk their column tiles interleaved.  Both measured within +-2 % (profiles/r04_colpass_ab.txt);
+ *                 same bits as the default path
+ *   "graph_max_melems" hipGraph replay of the time loop for batches of up to this many Mi state elements (default 8; larger
+ *                 batches are not launch-bound: measured equal)
  *   "device_vgrid" v-grids of compute_base_prices / compute_jacobian rebuilt per instance on the device (default 1;
  *                 0 = built once on the host with glibc sinh/asinh and broadcast -- bit-identical to the reference's
  *                 host-side Grid, needs one shared V_0)
@@ -211,7 +217,9 @@ int hadi_get_timing(const hadi_ctx *ctx, hadi_timing *out);
  *                 return HADI_ERR_INTERNAL instead of a field solved with stale exchange values; 128 = one block of every
  *                 team of an instance-resident launch deserts before the first team barrier -- the launch must time out,
  *                 and the call must still return the right field (from the two-launches-per-step path); 16 / 32 / 64 =
- *                 timing diagnostics of that launch (row phase / column phase / barriers skipped: results are wrong) */
+ *                 timing diagnostics of that launch (row phase / column phase / barriers skipped: results are wrong); 256 / 512 =
+ *                 timing diagnostics of the column pass (tiles loaded and stored but not solved / solved without the reduced
+ *                 system: results are wrong; tools/colpass_ab.py) */
 int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value);
 int hadi_get_tuning(const hadi_ctx *ctx, const char *key, int *value);
 /* Device the handle runs on: name, CU count, gcn arch string (for bench reports). */

@@ -46,6 +46,7 @@ struct Ctx {
     std::vector<GraphEntry> graphs;
     unsigned long long graph_clock = 0;
     int use_graph = 1;
+    int graph_max_melems = 8;  // hipGraph replay for batches of up to this many Mi state elements (hadi_set_tuning "graph_max_melems")
     int use_small = 1;  // LDS-resident one-launch path for small grids
     int small_seq = -1;  // ... European / dividend sweeps on the one-wavefront-per-instance kernel: -1 by batch size, 0 never, 1 always
     int use_amp = 1;    // American sweeps without the lambda_bar array when the payoff depends on s only
@@ -942,7 +943,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     // Small batches are launch-bound (2*N dependent launches of a few microseconds each): replay the loop
     // from a cached hipGraph.  Every kernel argument is baked into the nodes, so the key is everything they
     // depend on; the library's own buffers are stable between calls.
-    const bool graphable = c->use_graph && !prof && !d.debug && (long long)d.n * L.inst_stride <= (8ll << 20);
+    const bool graphable = c->use_graph && !prof && !d.debug && (long long)d.n * L.inst_stride <= ((long long)c->graph_max_melems << 20);
     if (graphable) {
         std::string key;
         auto put = [&](const void *p_, size_t nbytes) { key.append(static_cast<const char *>(p_), nbytes); };
@@ -1493,6 +1494,7 @@ int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value) {
     else if (!std::strcmp(key, "small_pairs")) c->small_pairs = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "streams")) c->streams = value == 2 ? 2 : (value == 1 ? 1 : 0);
     else if (!std::strcmp(key, "col_prefetch")) c->col_prefetch = value ? 1 : 0;
+    else if (!std::strcmp(key, "graph_max_melems")) c->graph_max_melems = value > 0 ? value : 0;
     else if (!std::strcmp(key, "tile_interleave")) c->tile_il = value ? 1 : 0;
     else if (!std::strcmp(key, "strip")) c->tune.strip = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "debug_fault")) c->debug_fault = value;
@@ -1529,6 +1531,7 @@ int hadi_get_tuning(const hadi_ctx *ctx, const char *key, int *value) {
     else if (!std::strcmp(key, "small_pairs")) *value = c->small_pairs;
     else if (!std::strcmp(key, "streams")) *value = c->streams;
     else if (!std::strcmp(key, "col_prefetch")) *value = c->col_prefetch;
+    else if (!std::strcmp(key, "graph_max_melems")) *value = c->graph_max_melems;
     else if (!std::strcmp(key, "tile_interleave")) *value = c->tile_il;
     else if (!std::strcmp(key, "strip")) *value = c->tune.strip;
     else if (!std::strcmp(key, "debug_fault")) *value = c->debug_fault;

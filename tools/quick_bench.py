@@ -73,6 +73,9 @@ CASES = {
         "c2am": ["--workload", "c3", "--m1", "512", "--m2", "256", "--timesteps", "1000", "--instances", "256"],
         "g700x300": ["--workload", "c2", "--m1", "700", "--m2", "300", "--timesteps", "500", "--instances", "128"],
         "c5f64_pf0": ["--workload", "c5", "--state", "fp64", "--tuning", "col_prefetch=0"]}.items()},
+    **{"%s_gr" % nm: base + ["--tuning", "graph_max_melems=4096"] for nm, base in {
+        "c2": ["--workload", "c2"], "c3": ["--workload", "c3"], "c5f64": ["--workload", "c5", "--state", "fp64"], "c2_64": ["--workload", "c2", "--instances", "64"],
+        "c2_128": ["--workload", "c2", "--instances", "128"]}.items()},
     "c2ring": ["--workload", "c2", "--tuning", "strip=0"], "c2am": ["--workload", "c3", "--m1", "512", "--m2", "256", "--timesteps", "1000", "--instances", "256"], "c5": ["--workload", "c5"], "c5f64": ["--workload", "c5", "--state", "fp64"], "c4": ["--workload", "c4"],
 }
 argv = sys.argv[1:]
