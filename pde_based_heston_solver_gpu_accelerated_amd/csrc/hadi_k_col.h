@@ -301,6 +301,36 @@ HADI_DEV HADI_FORCEINLINE void hadi_pb_store(const HadiPassBCtx &c, int ctile, d
         // Identity padding rows then see the payoff instead of 0: their results are never read.
         const bool pay1d = (AMER == 2) || c.pay1d != 0;
         const double pay_col = pay1d ? c.P0i[colc] : 0.0;
+        if constexpr (AMER == 2) {
+            // P representation in the single-buffer kernel (round 4): the old P of the tile is fetched in TWO batches of raw
+            // buffer loads (17 + 16 rows: with the tile's 33 solved values that is what 128 VGPRs hold), each followed by its
+            // projections and stores, then the reloads of the next tile.  Row by row -- load P_old, project, store, reload --
+            // every load sat behind the store of the row before it (one array, offsets the compiler cannot tell apart):
+            // 1024x512 x64 American puts, column pass 0.203 -> see DESIGN.md section 5.
+            constexpr int H0 = (HADI_LC + 1) / 2;
+            const unsigned voff = (unsigned)colc * 8u, voffs = valid ? voff : HADI_BUF_DROP;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int k0 = h ? H0 : 0, k1 = h ? HADI_LC : H0;
+                double po[H0];
+#pragma unroll
+                for (int k = k0; k < k1; k++) po[k - k0] = hadi_buf_load(c.Ub, voff, row0 + (unsigned)k * rstride);
+#pragma unroll
+                for (int k = k0; k < k1; k++) {
+                    double lamo = fmax(0.0, (pay_col - po[k - k0]) * c.inv_dt);
+                    if (is_smax) lamo = 0.0;
+                    hadi_buf_store(c.Ub, voffs, row0 + (unsigned)k * rstride, y[k] - dt * lamo);
+                }
+            }
+            if constexpr (RELOAD) {
+#pragma unroll
+                for (int k = 0; k < HADI_LC; k++) y[k] = hadi_buf_load(c.Yb, voffn, row0 + (unsigned)k * rstride);
+            }
+            HADI_STAMPB(22);  // projection + store issue
+            return;
+        }
+        // (the explicit (U, lambda_bar) pair in the same two batches was measured and dropped: with the runtime choice between the
+        // one-dimensional and the general payoff both loops are live, 122 registers spill, 0.28 -> 0.315 ms per launch)
 #pragma unroll
         for (int k = 0; k < HADI_LC; k++) {
             const size_t off = (size_t)k * c.rowp;
