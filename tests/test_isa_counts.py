@@ -23,8 +23,8 @@ STRIP_NS = lambda B, G, es: (3 if es == 8 else 4) if G == 2 else 4              
 @pytest.fixture(scope="module")
 def kernels():
     import kernel_regs
-    _, asm = kernel_regs.collect()
-    out = {}
+    rows, asm = kernel_regs.collect()
+    out = {"__rows__": rows}
     # (a kernel's text runs to its .Lfunc_end label: an early exit -- e.g. the strips' "this instance has fewer time steps" -- puts an
     # s_endpgm in the middle)
     for m in re.finditer(r"^(_Z\w+):.*?\n(.*?)^\.Lfunc_end\d+:", asm, re.S | re.M):
@@ -108,15 +108,13 @@ def test_pair_strip_kernels_issue_the_dma_pieces_and_stores_the_waits_count(kern
     assert seen == 3
 
 
-def test_no_row_kernel_with_counted_waits_touches_scratch():
+def test_no_row_kernel_with_counted_waits_touches_scratch(kernels):
     """The counted `s_waitcnt vmcnt(n)` of the strip and pair-strip kernels know the LDS-DMA pieces and the result stores of a
     row step and nothing else: a register spilled into scratch is reloaded by a vector-memory operation inside the row loop
     that the count does not include -- the wait would pass with a DMA piece still in flight (and, at best, the reload drains
     the prefetch).  No such kernel may have a scratch segment or a spilled VGPR (compiler metadata, tools/kernel_regs.py)."""
-    import kernel_regs
-    rows, _ = kernel_regs.collect()
     seen = 0
-    for name, vgpr, sgpr, spills, scratch, lds in rows:
+    for name, vgpr, sgpr, spills, scratch, lds in kernels["__rows__"]:
         if "hadi_pass_a_strip<" in name or "hadi_pass_a_pairs<" in name:
             assert spills == 0 and scratch == 0, (name, vgpr, spills, scratch)
             assert vgpr <= 256
