@@ -908,7 +908,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     // (hadi_team_kernel; the reference runs every instance's time loop inside one kernel, device_solver.hpp:83-88,226-265).
     // Chosen automatically for batches of up to 8 instances on the full 256-CU device; any failure of the team protocol is
     // recorded by the kernel, checked here, and the batch is solved again on the streaming path below.
-    const bool team_shape = d.n <= 8 && L.G == 1 && (L.B == 8 || L.B == 4) && L.P <= 8 && !seq_shape && d.variant == HADI_EU && !cs && !f32 &&
+    const bool team_shape = d.n <= 8 && L.G == 1 && (L.B == 8 || L.B == 4) && L.P <= 8 && !seq_shape && (d.variant == HADI_EU || d.variant == HADI_DIV) && !cs && !f32 &&
                             !d.debug && !prof && d.theta > 0.0 && d.r_d != d.r_f && c->cu_count == 256;
     // (a caller who pins the streaming kernels' geometry -- hadi_set_tuning "strip", "row_tile", "col_groups", "strip_blocks" --
     // gets those kernels)
@@ -918,8 +918,12 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         HIP_TRY(c, hipMemsetAsync(c->team.p, 0, 512 * sizeof(int), s));
         HadiTeamArgs ta;
         ta.form = ptr<int>(c->team); ta.bar = ptr<int>(c->team) + 64; ta.nb = c->cu_count / 8; ta.N = d.Nmax;
+        ta.div_flag = have_div ? ptr<int>(c->div_flag) : nullptr; ta.flag_stride = flag_stride;
+        ta.div_amounts = have_div ? ptr<double>(c->div_amt) : nullptr; ta.div_pcts = have_div ? ptr<double>(c->div_pct) : nullptr;
+        ta.vec_s = d.d_vec_s;
         ta.stamps = reinterpret_cast<unsigned long long *>(ptr<int>(c->team) + 384);
-        const size_t smem = ((size_t)4 * 64 * L.B + hadi_pb_mf_doubles(L.P) + (size_t)L.P * HADI_LC * HADI_PBW) * sizeof(double) + 64;
+        const size_t smem = ((size_t)4 * 64 * L.B + hadi_pb_mf_doubles(L.P) + (size_t)L.P * HADI_LC * HADI_PBW +
+                             (have_div ? (size_t)(L.m1 + 2) + (size_t)8 * L.rowp : 0)) * sizeof(double) + 64;
         if (L.B == 8) hipLaunchKernelGGL((hadi_team_kernel<8>), dim3(c->cu_count), dim3(512), smem, s, a, ta);
         else hipLaunchKernelGGL((hadi_team_kernel<4>), dim3(c->cu_count), dim3(512), smem, s, a, ta);
         HIP_TRY(c, hipGetLastError());

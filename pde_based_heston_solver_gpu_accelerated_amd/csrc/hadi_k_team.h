@@ -26,6 +26,11 @@ struct HadiTeamArgs {
     int *bar;    // [8] monotonic barrier counters, one per XCD (zeroed before the launch), each on a cache line of its own
     int nb;      // blocks per team
     int N;       // time steps
+    // discrete dividends (HADI_DIV; nullptr = none): the host-built table "which dividend does instance k pay at the START of step
+    // n" (hadi_dividend_steps), amounts / percentages, the s-grids in natural order
+    const int *div_flag;
+    int flag_stride;
+    const double *div_amounts, *div_pcts, *vec_s;
     unsigned long long *stamps;  // diagnostic build only (HADI_TEAM_STAMPS): [16]
 };
 #define HADI_DEVERR_TEAM 2  // instance-resident launch: a team did not form, a team barrier timed out, or a block moved
@@ -146,7 +151,10 @@ __global__ void __launch_bounds__(512, 2) hadi_team_kernel(HadiSweepArgs a, Hadi
     double *rtsh = zsh + (size_t)n4 * 64;
     double *tprod = rtsh + (size_t)n4 * hadi_pb_mp(P);
     double *tabl = tprod + (size_t)hadi_pb_mp(P) * 64;  // the column-pass chunk tables, [P][HADI_LC][HADI_PBW]
-    int *flags = reinterpret_cast<int *>(tabl + (size_t)P * HADI_LC * HADI_PBW);  // [0] rank of this block in its team, [1] dead
+    // discrete dividends only: the instance's s-grid (natural order) and one row of scratch per wavefront
+    double *sgrid = tabl + (size_t)P * HADI_LC * HADI_PBW;
+    double *drow = sgrid + (ta.div_flag ? (a.L.m1 + 2) : 0) + (size_t)wave * a.L.rowp;
+    int *flags = reinterpret_cast<int *>(sgrid + (ta.div_flag ? (a.L.m1 + 2) + (size_t)8 * a.L.rowp : 0));  // [0] rank of this block in its team, [1] dead
     if (threadIdx.x == 0) {
 #if defined(HADI_EMU)
         flags[0] = __atomic_fetch_add(ta.form + xcc, 1, __ATOMIC_SEQ_CST);
@@ -170,6 +178,10 @@ __global__ void __launch_bounds__(512, 2) hadi_team_kernel(HadiSweepArgs a, Hadi
         hadi_pb_stage_rt(a.rinv + (size_t)inst * 16 * P * P, P, rtsh, 512);
         const double *__restrict__ pg = a.pb + (size_t)inst * a.L.nrows_pad * HADI_PBW;
         for (int e = threadIdx.x; e < P * HADI_LC * HADI_PBW; e += 512) tabl[e] = pg[e];
+        if (ta.div_flag) {
+            const double *__restrict__ sg = ta.vec_s + (size_t)inst * (a.L.m1 + 1);
+            for (int e = threadIdx.x; e <= a.L.m1; e += 512) sgrid[e] = sg[e];
+        }
     }
     __syncthreads();
 
@@ -209,6 +221,62 @@ __global__ void __launch_bounds__(512, 2) hadi_team_kernel(HadiSweepArgs a, Hadi
         if (!unit_e) e_cur = exp(ip.bc_rate * ip.dt * n);
         c.e_n = hadi_uniform_d(e_cur);
         HADI_TSTAMP(0, false);
+        // ---- discrete dividend at the START of the step (device_solver.hpp:426-517; hadi_dividend_kernel) -----------------------
+        // The jump acts on every v-row by itself: a wavefront copies its row of U (written by other CUs in the column phase:
+        // coherent loads) to its LDS scratch row, then every lane rebuilds its nodes by linear interpolation at the ex-dividend
+        // spot and stores them in place.  One team barrier more on the <= num_dividends steps that pay.
+        {
+            const int dv = ta.div_flag ? ta.div_flag[(size_t)inst * ta.flag_stride + n - 1] : -1;  // (wave-uniform)
+            if (dv >= 0) {
+                const double amount = ta.div_amounts[dv], pct = ta.div_pcts[dv];
+                const int m1 = a.L.m1;
+                for (int j = wt; j < nrows; j += nwt) {
+                    double *r0 = Ui + (size_t)j * rowp;
+                    double rv[B];
+                    hadi_get_block_l2<B>(cb.Ub, r0, (unsigned)j * (unsigned)rowp * 8u, lane, rv);
+                    const double c00 = hadi_get_l2(cb.Ub, r0 + c0slot, ((unsigned)j * (unsigned)rowp + (unsigned)c0slot) * 8u);
+                    hadi_wave_rendezvous();
+                    hadi_put_block<B, 1>(drow, 0, lane, rv);
+                    if (lane == 0) drow[c0slot] = c00;
+                    hadi_wave_rendezvous();  // (one wavefront: LDS writes are visible to its own later reads; the emulator needs the barrier)
+#if !defined(HADI_EMU)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                    auto jump = [&](int i) -> double {
+                        const double new_s = sgrid[i] * (1.0 - pct) - amount;
+                        double out = ip.put ? drow[c0slot] : 0.0;  // ex-dividend spot <= 0: a call is worth 0, a put its s = 0 value
+                        if (new_s > 0) {
+                            int lo = 0, hi = m1 + 1;  // first k in [0, m1] with s[k] > new_s, 0 if none
+                            while (lo < hi) {
+                                const int mid = (lo + hi) >> 1;
+                                if (sgrid[mid] > new_s) hi = mid;
+                                else lo = mid + 1;
+                            }
+                            const int idx = (lo <= m1) ? lo : 0;
+                            if (idx > 0) {
+                                const double s_low = sgrid[idx - 1], s_high = sgrid[idx];
+                                const double weight = (new_s - s_low) / (s_high - s_low);
+                                out = (1.0 - weight) * drow[hadi_pos(B, 1, idx - 1)] + weight * drow[hadi_pos(B, 1, idx)];
+                            } else {
+                                out = drow[c0slot];
+                            }
+                        }
+                        return out;
+                    };
+                    double nv[B];
+#pragma unroll
+                    for (int r = 0; r < B; r++) {
+                        const int i = 1 + B * lane + r;
+                        nv[r] = (i <= m1) ? jump(i) : 0.0;  // (slots beyond m1 are zero pads)
+                    }
+                    const double n0 = jump(0);
+                    hadi_put_block<B, 1>(r0, 0, lane, nv);
+                    if (lane == 0) r0[c0slot] = n0;
+                }
+                arrivals += nb;
+                if (!hadi_team_barrier(bar, arrivals, xcc, flags + 1, a.err)) return;
+            }
+        }
         // ---- row phase ---------------------------------------------------------------------------------------------
         for (int j = (a.debug & HADI_DEBUG_TEAM_NO_ROWS) ? nrows : wt; j < nrows; j += nwt) {
             HadiSRow srow;

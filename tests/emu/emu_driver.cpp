@@ -259,11 +259,13 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
     if (dividend) hadi_dividend_steps(N, dt, ndiv, ddates, flags.data(), N);
     if (use_small == 4) {  // instance-resident launch (hadi_team_kernel) with teams of ONE block: the emulator runs the blocks of a
                            // grid one after the other, so the team barrier is trivially met; indexing and arithmetic are real
-        if (american || dividend || cs || f32 || n_inst > 8 || L.G != 1 || (L.B != 8 && L.B != 4) || L.P > 8) return 3;
+        if (american || cs || f32 || n_inst > 8 || L.G != 1 || (L.B != 8 && L.B != 4) || L.P > 8) return 3;
         std::vector<int> team(512, 0);
         HadiTeamArgs ta;
         ta.form = team.data(); ta.bar = team.data() + 64; ta.nb = 1; ta.N = N; ta.stamps = nullptr;
-        const size_t smem = ((size_t)4 * 64 * L.B + hadi_pb_mf_doubles(L.P) + (size_t)L.P * HADI_LC * HADI_PBW) * sizeof(double) + 64;
+        ta.div_flag = dividend ? flags.data() : nullptr; ta.flag_stride = 0; ta.div_amounts = damounts; ta.div_pcts = dpcts; ta.vec_s = vec_s;
+        const size_t smem = ((size_t)4 * 64 * L.B + hadi_pb_mf_doubles(L.P) + (size_t)L.P * HADI_LC * HADI_PBW +
+                             (dividend ? (size_t)(L.m1 + 2) + (size_t)8 * L.rowp : 0)) * sizeof(double) + 64;
         if (L.B == 8) emu::launch(8, 512, [&]() { hadi_team_kernel<8>(a, ta); }, smem);
         else emu::launch(8, 512, [&]() { hadi_team_kernel<4>(a, ta); }, smem);
         emu::launch(8, 64, [&]() { hadi_unpack_kernel(L, n_inst, dU.data(), U); });

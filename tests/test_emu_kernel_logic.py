@@ -446,6 +446,8 @@ def test_instance_resident_team_kernel(emu):
     _run(emu, 300, 40, 2, [100.0, 93.0], O.EU, 8, small=4)           # 8 nodes per lane, 2 chunks
     _run(emu, 200, 100, 1, [100.0], O.EU, 8, r_f=0.01, small=4)      # 4 nodes per lane, 4 chunks
     _run(emu, 260, 20, 2, [100.0], O.EU, 8, small=4, put=True)       # one chunk: no exchange barrier
+    _run(emu, 200, 40, 6, [100.0, 95.0], O.DIV, 8, small=4)          # discrete dividends: the jump inside the time loop (4 nodes per lane)
+    _run(emu, 300, 20, 12, [100.0], O.DIV, 8, small=4, put=True)     # ... 8 nodes per lane, put data (ex-dividend spot <= 0 takes the s = 0 value)
     _run(emu, 512, 256, 1, [100.0], O.EU, 8, small=4)                # the benchmarked shape: 257 rows, 8 chunks, 9 column tiles
 
 

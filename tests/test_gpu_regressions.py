@@ -155,27 +155,30 @@ def test_rendezvous_timeout_fails_the_call(solver, strip):
 
 
 # ---- instance-resident launch (hadi_team_kernel) ----------------------------------------------------------------------------
-def _team_case(m1, m2, N, strikes, put=False, r_f=0.0):
+def _team_case(m1, m2, N, strikes, put=False, r_f=0.0, div=False):
     grids = H.GridViewsBatch.for_strikes(m1, m2, Cm.S_0, Cm.V_0, strikes)
     U0 = grids.put_payoff(strikes) if put else grids.call_payoff(strikes)
     from oracle import oracle as O
-    p = O.make_params(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, r_f, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, O.EU,
-                      option_type=O.PUT if put else O.CALL, strikes=np.array(strikes) if put else None)
+    p = O.make_params(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, r_f, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, O.DIV if div else O.EU,
+                      Cm.DIVS if div else None, option_type=O.PUT if put else O.CALL, strikes=np.array(strikes) if put else None)
     Uo, _, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0)
     kw = dict(option_type=H.PUT, strikes=strikes) if put else {}
+    if div:
+        kw.update(variant=H.DIV, dividends=H.Dividends(*Cm.DIVS))
     return grids, U0, Uo, kw
 
 
-@pytest.mark.parametrize("m1,m2,N,n,put,r_f", [(512, 256, 12, 1, False, 0.0), (512, 256, 6, 8, False, 0.01), (300, 140, 10, 3, True, 0.0),
-                                               (256, 128, 10, 5, False, 0.0), (200, 30, 8, 2, False, 0.02), (400, 263, 5, 2, True, 0.01)])
-def test_instance_resident_launch_vs_oracle_and_streaming_path(solver, m1, m2, N, n, put, r_f):
+@pytest.mark.parametrize("m1,m2,N,n,put,r_f,div", [(512, 256, 12, 1, False, 0.0, False), (512, 256, 6, 8, False, 0.01, False), (300, 140, 10, 3, True, 0.0, False),
+                                                   (256, 128, 10, 5, False, 0.0, False), (200, 30, 8, 2, False, 0.02, False), (400, 263, 5, 2, True, 0.01, False),
+                                                   (512, 256, 12, 2, False, 0.0, True), (256, 128, 24, 8, True, 0.01, True), (300, 140, 6, 1, False, 0.0, True)])
+def test_instance_resident_launch_vs_oracle_and_streaming_path(solver, m1, m2, N, n, put, r_f, div):
     """Batches of up to 8 large European instances run their whole time loop in ONE launch, every instance kept in the L2 of
     one XCD by a team of 32 blocks (hadi_team_kernel; the reference runs all N steps of an instance inside one kernel,
     device_solver.hpp:83-88,226-265).  Full field against the oracle (1e-10) and against the two-launches-per-step path
     (1e-11: same operators, the row step of the strip kernels against the shared-ring one); 8 and 4 nodes per lane, 1 .. 8
     column chunks, call and put boundary data, r_f != 0 (the boundary time factors then need an exp per step)."""
     strikes = Cm.strikes_for(n)
-    grids, U0, Uo, kw = _team_case(m1, m2, N, strikes, put, r_f)
+    grids, U0, Uo, kw = _team_case(m1, m2, N, strikes, put, r_f, div)  # (div: discrete dividends -- the jump runs inside the launch)
     res = {}
     for mode in (1, 0):
         solver.set_tuning("team_launch", mode)
