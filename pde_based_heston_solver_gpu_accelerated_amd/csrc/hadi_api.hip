@@ -58,6 +58,7 @@ struct Ctx {
     // hadi_pass_b2 -- part of the next tile prefetched into LDS -- instead of hadi_pass_b1 for European sweeps of 9 .. 16 chunks
     int tile_il = 0;
     int col_prefetch = 0;
+    int cs_strips = 1;       // Craig-Sneyd row passes on the barrier-free strips where the plan chose strips (0: shared ring, as before round 4)
     int streams = 0;       // hadi_set_tuning "streams": 0 automatic (hadi_plan_row_idle), 1 one stream, 2 two streams side by side
     hipStream_t stream2 = nullptr;                 // the second stream of a two-stream sweep
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
@@ -414,6 +415,7 @@ struct PassEnv {
     int nstep;
     bool american, amp, xstep, f32;  // amp: P representation; xstep: this step runs on the explicit (U, lambda_bar) pair
     int col_prefetch;
+    bool cs_strips;                  // Craig-Sneyd row passes on strips where the plan chose strips (tuning key "cs_strips", default on)
 };
 // Row pass of one time step.  mode: 0 Douglas, 1 / 2 Craig-Sneyd predictor / corrector.
 void launch_row_pass(const PassEnv &e, const HadiSweepArgs &ar, int mode) {
@@ -472,6 +474,23 @@ void launch_row_pass(const PassEnv &e, const HadiSweepArgs &ar, int mode) {
             case 41: launch_pass_a_f32<4, 1, 1, 2>(pl, ar, nstep, q); break;
             case 81: launch_pass_a_f32<8, 1, 1, 1>(pl, ar, nstep, q); break;
             default: launch_pass_a_f32<8, 2, 1, 1>(pl, ar, nstep, q); break;
+        }
+        return;
+    }
+    if (pl.use_strip && mode != 0 && !pl.use_pairs && e.cs_strips) {  // Craig-Sneyd predictor / corrector on strips (European, fp64)
+        const dim3 g(pl.grid_as), b(64 * HADI_STRIP_WAVES(L.B));
+        if (L.G == 2) {
+            if (mode == 1) hipLaunchKernelGGL((hadi_pass_a_strip<8, 0, double, 2, 1>), g, b, pl.smem_as, q, ar, nstep);
+            else hipLaunchKernelGGL((hadi_pass_a_strip<8, 0, double, 2, 2>), g, b, pl.smem_as, q, ar, nstep);
+            return;
+        }
+        switch (L.B * 4 + mode) {
+            case 33: hipLaunchKernelGGL((hadi_pass_a_strip<8, 0, double, 1, 1>), g, b, pl.smem_as, q, ar, nstep); break;
+            case 34: hipLaunchKernelGGL((hadi_pass_a_strip<8, 0, double, 1, 2>), g, b, pl.smem_as, q, ar, nstep); break;
+            case 17: hipLaunchKernelGGL((hadi_pass_a_strip<4, 0, double, 1, 1>), g, b, pl.smem_as, q, ar, nstep); break;
+            case 18: hipLaunchKernelGGL((hadi_pass_a_strip<4, 0, double, 1, 2>), g, b, pl.smem_as, q, ar, nstep); break;
+            case 9: hipLaunchKernelGGL((hadi_pass_a_strip<2, 0, double, 1, 1>), g, b, pl.smem_as, q, ar, nstep); break;
+            default: hipLaunchKernelGGL((hadi_pass_a_strip<2, 0, double, 1, 2>), g, b, pl.smem_as, q, ar, nstep); break;
         }
         return;
     }
@@ -552,6 +571,8 @@ std::string describe_streaming_path(const Ctx *c, const HadiPlan &pl, const Batc
     else if (f32 && pl.use_strip && L.B == 8 && L.G == 2) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,EU,float,2> (paired strips of %d rows, fp32 state)", pl.RS);
     else if (f32 && pl.use_strip && L.B == 8) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,EU,float> (strips of %d rows, fp32 state)", pl.RS);
     else if (f32) std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,EU,float> (tiles of %d rows, fp32 state)", L.B, L.G, pl.W, pl.NG, pl.PD, pl.R);
+    else if (pl.use_strip && cs && c->cs_strips && !pl.use_pairs && L.G == 2) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,EU,double,2,CS> (paired strips of %d rows)", pl.RS);
+    else if (pl.use_strip && cs && c->cs_strips && !pl.use_pairs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<%d,EU,double,1,CS> (strips of %d rows)", L.B, pl.RS);
     else if (pl.use_strip && !cs && L.G == 2) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<8,%s,double,2> (paired strips of %d rows)", american ? "AM" : "EU", pl.RS);
     else if (pl.use_strip && !cs) std::snprintf(rowk, sizeof rowk, "hadi_pass_a_strip<%d,%s> (strips of %d rows)", L.B, american ? "AM" : "EU", pl.RS);
     else std::snprintf(rowk, sizeof rowk, "hadi_pass_a<%d,%d,%d,%d,%d,%s%s> (tiles of %d rows)", L.B, L.G, pl.W, pl.NG, pl.PD,
@@ -784,7 +805,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                     hipLaunchKernelGGL(hadi_narrow_kernel, dim3(grid1d(tot)), dim3(256), 0, q, L, Ub, reinterpret_cast<float *>(a.U), tot);
             }
             if (prof) HIP_TRY(c, hipEventRecord(c->kev[ev0 + 4 * (nstep - 1) + 0], q));
-            const PassEnv env{pl, L, nsb, q, nstep, american, amp, xstep, f32, c->col_prefetch};
+            const PassEnv env{pl, L, nsb, q, nstep, american, amp, xstep, f32, c->col_prefetch, c->cs_strips != 0};
             auto row_pass = [&](const HadiSweepArgs &ar, int mode) { launch_row_pass(env, ar, mode); };
             auto col_pass = [&](const HadiSweepArgs &ar) { launch_col_pass(env, ar); };
             if (d.debug == 2) {  // diagnostics: one column solve of the packed input (moved to Y), nothing else
@@ -961,7 +982,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         for (const auto &sbt : subs) {  // the launch geometry of EVERY sub-batch is baked into the nodes (unequal halves on two
                                         // streams, a tuning change that flips only the second sub-batch's plan)
             const HadiPlan &q = sbt.pl;
-            const int geo[] = {c->col_prefetch, c->tile_il, sbt.lane, fork_before, sbt.off, sbt.cnt, q.R, q.ntiles, q.grid_a, (int)q.smem_a, q.use_strip, q.use_pairs, q.RS, q.sblocks, q.grid_as,
+            const int geo[] = {c->col_prefetch, c->cs_strips, c->tile_il, sbt.lane, fork_before, sbt.off, sbt.cnt, q.R, q.ntiles, q.grid_a, (int)q.smem_a, q.use_strip, q.use_pairs, q.RS, q.sblocks, q.grid_as,
                                (int)q.smem_as, q.ctiles, q.btpw, q.bgroups, q.grid_b, q.block_b, (int)q.smem_b, q.row_seq, q.col_seq, q.W, q.NG, q.PD};
             put(geo, sizeof(geo));
         }
@@ -1498,6 +1519,7 @@ int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value) {
     else if (!std::strcmp(key, "small_pairs")) c->small_pairs = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "streams")) c->streams = value == 2 ? 2 : (value == 1 ? 1 : 0);
     else if (!std::strcmp(key, "col_prefetch")) c->col_prefetch = value ? 1 : 0;
+    else if (!std::strcmp(key, "cs_strips")) c->cs_strips = value ? 1 : 0;
     else if (!std::strcmp(key, "graph_max_melems")) c->graph_max_melems = value > 0 ? value : 0;
     else if (!std::strcmp(key, "tile_interleave")) c->tile_il = value ? 1 : 0;
     else if (!std::strcmp(key, "strip")) c->tune.strip = value < 0 ? -1 : (value ? 1 : 0);
@@ -1535,6 +1557,7 @@ int hadi_get_tuning(const hadi_ctx *ctx, const char *key, int *value) {
     else if (!std::strcmp(key, "small_pairs")) *value = c->small_pairs;
     else if (!std::strcmp(key, "streams")) *value = c->streams;
     else if (!std::strcmp(key, "col_prefetch")) *value = c->col_prefetch;
+    else if (!std::strcmp(key, "cs_strips")) *value = c->cs_strips;
     else if (!std::strcmp(key, "graph_max_melems")) *value = c->graph_max_melems;
     else if (!std::strcmp(key, "tile_interleave")) *value = c->tile_il;
     else if (!std::strcmp(key, "strip")) *value = c->tune.strip;

@@ -26,6 +26,7 @@ template <class T>
 struct HadiStripCtxT {
     const double *coef;  // LDS: Bm, Bp, Dm, Dp, each 64*B doubles in row layout
     T *Yi;               // instance base of Y
+    double *R1i, *C2i;   // instance bases of the Craig-Sneyd carry-over arrays (MODE 1 writes, MODE 2 reads)
     const double *Li;    // instance base of lambda_bar (American)
     const double *b2r;   // instance b2 row (global)
     int lane, rowp;
@@ -57,6 +58,59 @@ HADI_DEV HADI_FORCEINLINE int hadi_flag_load(int *f) {
 #endif
 }
 
+// Craig-Sneyd corrector on strips: the R1 and C2 rows of a step are REGISTER loads, and they must not be the compiler's.
+// hipcc retires a load with `s_waitcnt vmcnt(k)`, k = the younger vector-memory operations IT knows of; the LDS-DMA
+// prefetch is inline asm, so its k would be too small by the DMA pieces in flight and every such wait would drain the
+// prefetch.  These loads are inline asm as well (the compiler sees values that are "ready" at once) and are retired by
+// the kernel's own counted wait before hadi_asm_block_take() hands the registers over -- the same bookkeeping as for the
+// ring rows: vector-memory operations of a wavefront retire in issue order.
+template <int B>
+struct HadiAsmBlock {
+#if defined(HADI_EMU)
+    double v[B], c0;
+#else
+    hadi_u32x4 q[B / 2];
+    hadi_u32x2 c0;
+#endif
+};
+// issues B / 2 + 1 vector loads: this lane's block of the row (hadi_get_block's pairs) and the row's i = 0 value
+template <int B, int G>
+HADI_DEV HADI_FORCEINLINE int hadi_asm_block_issue(const double *row, int half, int lane, HadiAsmBlock<B> &r) {
+#if defined(HADI_EMU)
+    hadi_get_block<B, G>(row, half, lane, r.v);
+    r.c0 = row[64 * B * G];
+#else
+#pragma unroll
+    for (int q = 0; q < B / 2; q++)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r.q[q]) : "v"(row + q * 128 * G + 128 * half + 2 * lane) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(r.c0) : "v"(row + 64 * B * G) : "memory");
+#endif
+    return B / 2 + 1;
+}
+#define HADI_ASM_BLOCK_LOADS(B) ((B) / 2 + 1)
+// call only behind the counted wait that retired the loads
+template <int B>
+HADI_DEV HADI_FORCEINLINE void hadi_asm_block_take(HadiAsmBlock<B> &r, double (&u)[B], double &c0) {
+#if defined(HADI_EMU)
+    for (int k = 0; k < B; k++) u[k] = r.v[k];
+    c0 = r.c0;
+#else
+#pragma unroll
+    for (int q = 0; q < B / 2; q++) {
+        asm volatile("" : "+v"(r.q[q]));  // (orders the reads below behind the wait, an asm volatile as well)
+        u[2 * q] = __hiloint2double((int)r.q[q].y, (int)r.q[q].x);
+        u[2 * q + 1] = __hiloint2double((int)r.q[q].w, (int)r.q[q].z);
+    }
+    asm volatile("" : "+v"(r.c0));
+    c0 = __hiloint2double((int)r.c0.y, (int)r.c0.x);
+#endif
+}
+template <int B>
+struct HadiCsRow { double r1[B], c2[B], r1c0, c2c0; };  // MODE 2: R1 and C2 of the step's row (block and i = 0 column)
+
+// MODE 0: Douglas step.  MODE 1 / 2: predictor / corrector of Craig-Sneyd exactly as in hadi_row_step (solver.hpp:781-907):
+// MODE 1 is a Douglas row step that also stores R1 = Y1rhs - dt/2 A0U and C2; MODE 2 takes its rows from Y2, forms
+// R1 + dt/2 A0 Y2, runs the same A1 solve and adds C2 (cs: the two rows, loaded by the caller).  European sweeps only.
 // AMER: 0 European, 1 American with the explicit (U, lambda_bar) pair (lambda_bar loaded here), 2 American in the P
 // representation: the caller rebuilt U = max(P, U_0) on the five rows and hands over the raw P of row j (p_raw) and
 // lambda_bar of the i = 0 column; lambda_bar = max(0, (U_0 - P)/dt) = (U - P)/dt is formed here, right before the sweep
@@ -65,15 +119,17 @@ HADI_DEV HADI_FORCEINLINE int hadi_flag_load(int *f) {
 // the values, on the rows behind / at / ahead of j, of the one node next to this half that belongs to the partner; the
 // tridiagonal system is split at the boundary exactly as in hadi_row_step (second right-hand side through the cyclic
 // reduction, 2x2 system exchanged through LDS), with a rendezvous of the two wavefronts only.
-template <int B, int AMER, bool LAST, class T = double, int G = 1, int CREG = 0>
+template <int B, int AMER, bool LAST, class T = double, int G = 1, int CREG = 0, int MODE = 0>
 HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j, const double (&rt)[HADI_RCL],
                                                const double (&um2)[B], const double (&um1)[B], const double (&u0)[B],
                                                const double (&up1)[B], const double (&up2)[B], double c0m2, double c0m1,
                                                double c00, double c0p1, double c0p2, const double (&p_raw)[B],
                                                double lamc0_in, const T *next_row, double (&u_next)[B],
                                                double eb = 0.0, double e0 = 0.0, double ea = 0.0, const T *raw_row = nullptr,
-                                               const double *pay_row = nullptr, const double *cf = nullptr) {
+                                               const double *pay_row = nullptr, const double *cf = nullptr,
+                                               const HadiCsRow<B> *cs = nullptr) {
     static_assert(G == 1 || (G == 2 && (AMER == 0 || sizeof(T) == 8)), "paired strips: American sweeps with the fp64 state only");
+    static_assert(MODE == 0 || (AMER == 0 && sizeof(T) == 8), "Craig-Sneyd: European sweeps, fp64 state");
     const int lane = c.lane, rowp = c.rowp;
     const int half = (G > 1) ? c.half : 0;
     // P representation: where the raw P of row j comes from -- its ring slot again (8 nodes per lane, one wavefront per row:
@@ -114,7 +170,17 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
     const double a1c0 = -c.hr0 * c00;  // A1 row 0: empty for the call (hr0 = 0), the reaction term for the put
     double y0c0 = c00 + dt * (a2c0 + a1c0 + (b1c0 + b2c0) * e_nm1 + lamc0);
     y0c0 = y0c0 + thdt * (b1c0 * e_n - (a1c0 + b1c0 * e_nm1));
-    const double c2c0 = thdt * (b2c0 * e_n - (a2c0 + b2c0 * e_nm1));
+    double c2c0 = thdt * (b2c0 * e_n - (a2c0 + b2c0 * e_nm1));
+    if constexpr (MODE == 1) {  // A0 is zero on i = 0: R1 = Y1rhs there
+        if (lane == 0 && first_half) {
+            c.R1i[(size_t)j * rowp + c0slot] = y0c0;
+            c.C2i[(size_t)j * rowp + c0slot] = c2c0;
+        }
+    }
+    if constexpr (MODE == 2) {
+        y0c0 = cs->r1c0;
+        c2c0 = cs->c2c0;
+    }
     const double x0 = y0c0 * c.inv0;  // A1 row 0 is decoupled: the identity for the call (hes_a1_kernels.hpp:56-61)
     const double yout_c0 = x0 + c2c0;
 
@@ -173,6 +239,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
     const double b1l = (lane == b1lane) ? b1val * cb1 : 0.0;  // this row's b1 entry, in the lane that owns its node
 
     double lam[B], b2v[B];
+    double r1v[B], c2v[B];  // (MODE 1)
     if constexpr (AMER == 1) hadi_get_block<B, G>(c.Li + (size_t)j * rowp, half, lane, lam);
     if constexpr (AMER == 2) {
         // 8 nodes per lane: the raw P of row j is read again from its ring slot, which stays intact through this step (the
@@ -192,7 +259,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
             }
         }
     }
-    if constexpr (LAST) hadi_get_block<B, G>(c.b2r, half, lane, b2v);
+    if constexpr (LAST && MODE != 2) hadi_get_block<B, G>(c.b2r, half, lane, b2v);
 
     // ---- Y0 (device_solver.hpp:236-250) fused with the forward sweep of the in-lane Thomas ----------
     // The s-coefficients are read pair by pair inside the sweep (a compiler barrier keeps hipcc from hoisting all 16
@@ -270,13 +337,19 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
         // theta dt A1 U = -il uL - iu uR + (1 - im) u0   (c1 - c2 = 1)
         const double T1 = fma(-iu[r], uR, fma(-il, uL, fma(-im, u0r, u0r)));
         const double A0U = Bm[r] * tl - (Bm[r] + Bp[r]) * tt[r] + Bp[r] * tr;
-        double S = A0U + A2U[r];
-        if constexpr (LAST) S += b2v[r] * e_nm1;
-        if constexpr (AMER) S += lam[r];
-        double y = fma(dt, S, u0r);
-        y = fma(kap, T1, y);
-        y = fma(b1l, (r == b1r) ? 1.0 : 0.0, y);  // wave-uniform selector: one FMA with a scalar operand (a scalar branch
-                                                  // around a single add measured slower: 0.1108 vs 0.1099 ms per launch)
+        double y;
+        if constexpr (MODE == 2) {
+            y = fma(0.5 * dt, A0U, cs->r1[r]);  // A0U is A0 applied to Y2 here
+        } else {
+            double S = A0U + A2U[r];
+            if constexpr (LAST) S += b2v[r] * e_nm1;
+            if constexpr (AMER) S += lam[r];
+            y = fma(dt, S, u0r);
+            y = fma(kap, T1, y);
+            y = fma(b1l, (r == b1r) ? 1.0 : 0.0, y);  // wave-uniform selector: one FMA with a scalar operand (a scalar branch
+                                                      // around a single add measured slower: 0.1108 vs 0.1099 ms per launch)
+            if constexpr (MODE == 1) r1v[r] = fma(-0.5 * dt, A0U, y);
+        }
         if (r == 0 && lane == 0 && first_half) {  // x_0 is known: move it to the right-hand side
             y -= il * x0;
             il = 0.0;
@@ -420,9 +493,15 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
         if (r < NB) x = ys[r] - XL * ps[r] - X * gs[r];
         else x = X;
         double corr;
-        if constexpr (LAST) corr = thdt * (b2v[r] * e_n - (A2U[r] + b2v[r] * e_nm1));
+        if constexpr (MODE == 2) corr = cs->c2[r];
+        else if constexpr (LAST) corr = thdt * (b2v[r] * e_n - (A2U[r] + b2v[r] * e_nm1));
         else corr = -thdt * A2U[r];
         yo[r] = x + corr;
+        if constexpr (MODE == 1) c2v[r] = corr;
+    }
+    if constexpr (MODE == 1) {  // (two more row stores per step: the kernel's counted waits add them)
+        hadi_put_block<B, G>(c.R1i + (size_t)j * rowp, half, lane, r1v);
+        hadi_put_block<B, G>(c.C2i + (size_t)j * rowp, half, lane, c2v);
     }
     // Plain global stores on purpose.  Raw BUFFER stores here (SGPR row offset, one 32-bit lane offset: two VGPRs and the
     // 64-bit address arithmetic saved, 0.5 % faster) were tried in round 2 and are WRONG for this kernel: the counted vmcnt
@@ -442,7 +521,10 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
 // wait -- no wavefront ever reads ring data its partner fetched, except the one boundary node, see below).  LDS:
 // [4 pairs][NS slots][rowp] + 4 coefficient arrays of 1024 + the pairs' exchange buffers; with an fp64 state only NS = 3
 // slots fit the 160 KB (rows j+1, j+2 landed, j+3 in flight), with an fp32 state 4 as above.
-template <int B, int AMER, class T = double, int G = 1>
+// MODE 1 / 2: predictor / corrector row pass of a Craig-Sneyd step (European, fp64 state).  The corrector's R1 and C2 rows
+// are register loads retired by this kernel's own counted waits (HadiAsmBlock): the row of step t + 1 is requested at the top
+// of step t, BEFORE that step's DMA, so that retiring it at the top of step t + 1 leaves the DMA batches of step t in flight.
+template <int B, int AMER, class T = double, int G = 1, int MODE = 0>
 #ifndef HADI_STRIP_OCC_B4
 #define HADI_STRIP_OCC_B4 2
 #endif
@@ -451,6 +533,7 @@ template <int B, int AMER, class T = double, int G = 1>
 __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4 ? HADI_STRIP_OCC_B4 : AMER == 2 ? 3 : 4)) hadi_pass_a_strip(HadiSweepArgs a, int n) {
     static_assert(sizeof(T) == 8 || AMER == 0, "the fp32-state sweep is European only");
     static_assert(G == 1 || (G == 2 && B == 8), "paired strips: 8 nodes per lane");
+    static_assert(MODE == 0 || (AMER == 0 && sizeof(T) == 8), "Craig-Sneyd: European sweeps, fp64 state");
     HADI_DYN_SMEM(double, smem);
     constexpr int NS = HADI_STRIP_NS(B, G, (int)sizeof(T)), NWV = HADI_STRIP_WAVES(B), NPAIR = NWV / G, c0slot = 64 * B * G;
     // American P representation at 8 nodes per lane: one slot stays BEHIND the prefetch -- row j itself, whose raw P the step
@@ -488,6 +571,8 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     const T *__restrict__ Ub = reinterpret_cast<const T *>(a.U) + (size_t)inst * a.L.inst_stride;
     c.Yi = reinterpret_cast<T *>(a.Y) + (size_t)inst * a.L.inst_stride;
     c.Li = (AMER == 1) ? a.LAM + (size_t)inst * a.L.inst_stride : nullptr;
+    c.R1i = MODE ? a.R1 + (size_t)inst * a.L.inst_stride : nullptr;
+    c.C2i = MODE ? a.C2 + (size_t)inst * a.L.inst_stride : nullptr;
     c.b2r = a.b2row + (size_t)inst * rowp;
     // P representation: 1/dt, and which node is s_max (lambda_bar stays 0 there, as in hadi_row_step)
     c.inv_dt = 0.0; c.m1_lane = -1; c.m1_r = -1;
@@ -516,10 +601,20 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     // finds them in L2 instead of fetching them again ~100 us later (HBM reads of this pass 9.8 -> ~9 B per node).
     // Below, "behind" = rows already passed (registers), "ahead" = rows still to come (LDS ring / in flight); for a
     // descending strip the row-table scalars of the +1/+2 and -1/-2 neighbours simply swap roles.
-    const int dir = (((sb * NPAIR + pair) & 1) == 0) ? 1 : -1;
+    // Round 4: EVEN strips come down, ODD strips go up, so the strips 2k and 2k+1 -- always in the same block -- START on
+    // either side of their common boundary.  What one of them has behind it at the start (two rows) is what the other starts
+    // on and has one ahead: those rows are read from the partner's ring after the prologue's barrier instead of from memory a
+    // second time, and the strip's own first row comes through its ring as well (`shared` below): cnt + 2 rows per strip by
+    // LDS-DMA and nothing else, where cnt + 1 + 3 were read.
+    const int sidx = sb * NPAIR + pair;
+    const int dir = (sidx & 1) ? 1 : -1;
     const int cnt = j1 - j0;
     const int js = dir > 0 ? j0 : j1 - 1;
     auto row_ok = [&](int jj) { return jj >= 0 && jj < npad; };
+    // (wave-uniform) the partner strip exists; a last strip without one keeps the register loads of its rows behind
+    const bool shared = has_strip && (sidx ^ 1) * a.RS < nrows;
+    const T *pring = reinterpret_cast<T *>(smem) + (size_t)(pair ^ 1) * NS * rowp;
+    auto pslot = [&](int jj) { return pring + (size_t)((NS & (NS - 1)) == 0 ? (jj & (NS - 1)) : (jj + 12) % NS) * rowp; };
     // ---- prologue: the next rows ahead to the ring, the two rows behind and the first row to registers ----
     // aft[k] = vector-memory instructions issued after the DMA of the row 2 + k ahead: aft[0] belongs to the row that is
     // waited for next, the row NS - 1 ahead is the youngest DMA (nothing behind it yet)
@@ -531,7 +626,7 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     // round trips overlap instead of following each other (a launch of short strips is mostly prologue: 64 instances of
     // 512x256, 9-row strips: 0.0380 -> see DESIGN.md section 5).
     if (has_strip) {
-        if constexpr (KEEP) fetch(js);  // (the first row too: the step reads its raw P from the ring)
+        if (KEEP || shared) fetch(js);  // (the first row too: the step reads its raw P from the ring / `shared` above)
         fetch(js + dir);
         fetch(js + 2 * dir);
 #pragma unroll
@@ -541,6 +636,12 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
             for (int k = 0; k < NA; k++)
                 if (k + 2 < q) aft[k] += zq;
         }
+    }
+    HadiAsmBlock<B> nr1, nc2;  // MODE 2: R1 / C2 of the NEXT step's row, in flight (the first row's: retired by the prologue's full wait)
+    if constexpr (MODE == 2) {
+        const size_t ro = (size_t)(has_strip ? js : 0) * rowp;
+        hadi_asm_block_issue<B, G>(c.R1i + ro, half, lane, nr1);
+        hadi_asm_block_issue<B, G>(c.C2i + ro, half, lane, nc2);
     }
     // rows behind by 2, behind by 1 (carried in the state's own type: with an fp32 state they are exact floats and cost
     // half the registers), current row (double: used throughout the step)
@@ -561,9 +662,11 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     for (int r = 0; r < B; r++) t2[r] = t1[r] = u0[r] = 0.0;
     c0vec = 0.0;
     if (has_strip) {
-        if (row_ok(js - 2 * dir)) hadi_get_block<B, G, T>(Ub + (ptrdiff_t)(js - 2 * dir) * rowp, half, lane, t2);
-        if (row_ok(js - dir)) hadi_get_block<B, G, T>(Ub + (ptrdiff_t)(js - dir) * rowp, half, lane, t1);
-        hadi_get_block<B, G, T>(Ub + (size_t)js * rowp, half, lane, u0);
+        if (!shared) {
+            if (row_ok(js - 2 * dir)) hadi_get_block<B, G, T>(Ub + (ptrdiff_t)(js - 2 * dir) * rowp, half, lane, t2);
+            if (row_ok(js - dir)) hadi_get_block<B, G, T>(Ub + (ptrdiff_t)(js - dir) * rowp, half, lane, t1);
+            hadi_get_block<B, G, T>(Ub + (size_t)js * rowp, half, lane, u0);
+        }
         const int rr = js + (lane - 2) * dir;
         c0vec = (half == 0 && lane < 4 && row_ok(rr)) ? (double)Ub[(ptrdiff_t)rr * rowp + c0slot] : 0.0;
         if constexpr (G > 1) evec = (lane < 4 && row_ok(rr)) ? (double)Ub[(ptrdiff_t)rr * rowp + epos] : 0.0;
@@ -608,7 +711,17 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     if constexpr (G > 1) {  // the pairs' exchange buffers (values + rendezvous tokens, all zero: no row has token 0)
         if (threadIdx.x < NPAIR * 16) xch0[threadIdx.x] = 0.0;
     }
-    __syncthreads();  // the only block-wide barrier: the coefficient arrays are shared
+    hadi_wait_vmcnt(0);  // this wavefront's prologue rows have landed (the partner reads two of them behind the barrier)
+    __syncthreads();     // the coefficient arrays are shared
+    if (shared) {
+        hadi_get_block<B, G, T>(pslot(js - 2 * dir), half, lane, t2);  // = the partner's row one ahead
+        hadi_get_block<B, G, T>(pslot(js - dir), half, lane, t1);      // = the partner's first row
+        hadi_get_block<B, G, T>(slot(js), half, lane, u0);
+#if !defined(HADI_EMU)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    }
+    __syncthreads();  // ... and nobody's first fetch of the loop lands in a slot its partner is still reading
     if (!has_strip) return;
     // 8 nodes per lane, European fp64 (the headline kernel): two of the four arrays fit the registers left over (224 -> 250
     // VGPRs, no spill): 8 of the 16 coefficient reads per row step less on the LDS pipe, +0.7 % on 512x256 x256 (three
@@ -616,7 +729,7 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
 #ifndef HADI_STRIP_CREG8
 #define HADI_STRIP_CREG8 2
 #endif
-    constexpr int CREG = (B <= HADI_STRIP_CREG_MAX_B && G == 1) ? 1 : (B == 8 && G == 1 && AMER == 0 && sizeof(T) == 8) ? HADI_STRIP_CREG8 : 0;
+    constexpr int CREG = (B <= HADI_STRIP_CREG_MAX_B && G == 1) ? 1 : (B == 8 && G == 1 && AMER == 0 && sizeof(T) == 8 && MODE == 0) ? HADI_STRIP_CREG8 : 0;
     double cf[4 * B];
     if constexpr (CREG) {
 #pragma unroll
@@ -658,6 +771,7 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     c.stamp_acc_ = stamp_store_;
 #endif
     HADI_STAMP_DECL(c.stamp_acc_)
+    int regs_after = 0;  // MODE 2: vector-memory operations issued behind the register loads of the coming step's R1 / C2 rows
     for (int t = 0; t < cnt; t++) {
         const int j = js + dir * t;
         HADI_STAMPC(30);  // carry + loop
@@ -666,12 +780,29 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
         // the prologue -- keeps 24 scalar registers live across the loop edge; at 106 SGPRs the compiler parks them in VGPR
         // lanes (two variants even spill to scratch): row pass +1.2 % at 33-row strips, +3 % at 9 rows, +6.5 % on paired strips)
         hadi_sload_issue(a.rowc + ((size_t)inst * nrows + j) * HADI_RC + HADI_SRC0, srow);  // flies during the DMA wait
+        HadiCsRow<B> csrow;
+        if constexpr (MODE == 2) {
+            // this step's R1 / C2 rows have landed once at most the operations issued behind them are in flight -- the DMA and
+            // the row stores of the step before; then the next row's are requested, ahead of this step's DMA
+            hadi_wait_vmcnt(regs_after);
+            hadi_asm_block_take<B>(nr1, csrow.r1, csrow.r1c0);
+            hadi_asm_block_take<B>(nc2, csrow.c2, csrow.c2c0);
+            int nl = 0;
+            if (t + 1 < cnt) {
+                const size_t ro = (size_t)(j + dir) * rowp;
+                nl = hadi_asm_block_issue<B, G>(c.R1i + ro, half, lane, nr1) + hadi_asm_block_issue<B, G>(c.C2i + ro, half, lane, nc2);
+            }
+#pragma unroll
+            for (int k = 0; k < NA; k++) aft[k] += nl;
+            regs_after = 0;
+        }
         hadi_wave_rendezvous();
         // the row D ahead goes to the slot of row j (of row j - 1 when one slot is kept behind): that row is in registers,
         // and this wavefront's last read of the slot (in the previous step) has been retired there.  Issued BEFORE the
         // wait below, so that the prefetch does not queue behind it.
         int z = 0;
         if (t + D <= cnt + 1) z = fetch(j + D * dir);
+        regs_after += z;
         hadi_wait_vmcnt(aft[0] + z);  // the row two ahead has landed (the row one ahead landed a step earlier)
         HADI_STAMPC(24);  // wait for the DMA
 #pragma unroll
@@ -735,10 +866,13 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
                 xb_ = fmax(xb_, pay_e); x0_ = fmax(x0_, pay_e); xa_ = fmax(xa_, pay_e);
             }
         }
-        if (j == nrows - 1) hadi_strip_step<B, AMER, true, T, G, CREG>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_, slot(j), payl, cf);
-        else hadi_strip_step<B, AMER, false, T, G, CREG>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_, slot(j), payl, cf);
+        if (MODE != 2 && j == nrows - 1) hadi_strip_step<B, AMER, (MODE != 2), T, G, CREG, MODE>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_, slot(j), payl, cf, &csrow);
+        else hadi_strip_step<B, AMER, false, T, G, CREG, MODE>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_, slot(j), payl, cf, &csrow);
+        // the row's vector stores (the i = 0 stores are not counted: lower bound); the predictor stores R1 and C2 as well
+        constexpr int NST = (MODE == 1 ? 3 : 1) * hadi_put_block_stores<B, T>();
 #pragma unroll
-        for (int k = 0; k < NA; k++) aft[k] += hadi_put_block_stores<B, T>();  // the row's vector stores (the i = 0 store is not counted: lower bound)
+        for (int k = 0; k < NA; k++) aft[k] += NST;
+        regs_after += NST;
         double enew = 0.0;
         if constexpr (G > 1) {
             // The partner's boundary node of the row TWO ahead, from the partner's half of the ring slot.  Safe here and only
@@ -1067,8 +1201,15 @@ __global__ void __launch_bounds__(64 * HADI_PAIR_WAVES, 2) hadi_pass_a_pairs(Had
     const int cntA = HADI_UNIFORM(j0A < nrows ? ((j0A + a.RS < nrows ? j0A + a.RS : nrows) - j0A) : 0);
     const int cntB = HADI_UNIFORM(j0B < nrows ? ((j0B + a.RS < nrows ? j0B + a.RS : nrows) - j0B) : 0);
     const int j0 = H ? j0B : j0A, cnt = H ? cntB : cntA;
-    const int dir = ((sb * NWV + wave) & 1) ? -1 : 1;  // (both strips of a wavefront walk the same way)
-    const int js = dir > 0 ? j0 : j0 + cnt - 1;
+    // Strip A comes DOWN, strip B goes UP: the two strips of a wavefront start on either side of their common boundary b = j0B
+    // (A on row b - 1, B on row b).  The rows one strip has behind it at the start are then exactly the rows the other one
+    // starts on and has one ahead -- they are taken from the other half's ring slots, and the first row from the strip's own:
+    // the prologue fetches 3 (4) rows per strip by LDS-DMA and nothing else (before round 4, both strips walking the same
+    // way: 3 (4) + 3 register rows, 12 rows per wavefront where 6 are distinct -- the launch's fill burst, all wavefronts at
+    // once, is what this pass loses most to).  Strip A of this wavefront and strip B of the one before it END on neighbouring
+    // rows at about the same time, as the alternating directions of hadi_pass_a_strip do.
+    const int dir = H ? 1 : -1;
+    const int js = H ? j0B : j0A + cntA - 1;
 
     HadiStripCtxT<double> c;
     c.lane = lane; c.rowp = ROWP; c.coef = coef; c.half = 0; c.xch = nullptr; c.err = a.err; c.debug = a.debug;
@@ -1089,7 +1230,7 @@ __global__ void __launch_bounds__(64 * HADI_PAIR_WAVES, 2) hadi_pass_a_pairs(Had
     const int c0_off = 512 + 16 * H;
     const double *__restrict__ rtab = a.rowc + (size_t)inst * nrows * HADI_RC + HADI_SRC0;
     auto clampj = [&](int jj) { return jj < 0 ? 0 : (jj >= nrows ? nrows - 1 : jj); };
-    const int jsA = dir > 0 ? j0A : j0A + cntA - 1, jsB = dir > 0 ? j0B : j0B + cntB - 1;  // (wave-uniform)
+    const int jsA = j0A + cntA - 1, jsB = j0B;  // (wave-uniform)
 
     // ---- prologue (memory round trips first, then the shared copies and the block's only barrier: hadi_pass_a_strip) ----
     // step index t <-> row js + dir t; the ring slot of a row is its step index mod NS
@@ -1100,7 +1241,8 @@ __global__ void __launch_bounds__(64 * HADI_PAIR_WAVES, 2) hadi_pass_a_pairs(Had
 #pragma unroll
     for (int k = 0; k < NA; k++) aft[k] = 0;
     if (cntA > 0) {
-        if constexpr (AMER == 2) hadi_pair_fetch(grow(js), slot(0), lane);
+        // the first row too (slot 0; European: the loop's first fetch reuses that slot once the row sits in registers)
+        hadi_pair_fetch(grow(js), slot(0), lane);
         hadi_pair_fetch(grow(js + dir), slot(1), lane);
         hadi_pair_fetch(grow(js + 2 * dir), slot(2), lane);
 #pragma unroll
@@ -1110,17 +1252,13 @@ __global__ void __launch_bounds__(64 * HADI_PAIR_WAVES, 2) hadi_pass_a_pairs(Had
             for (int k = 0; k < NA; k++)
                 if (k + 2 < q) aft[k] += HADI_PAIR_DMA;
         }
-        hadi_pair_get(grow(js - 2 * dir) + 4 * h, 128, um2);
-        hadi_pair_get(grow(js - dir) + 4 * h, 128, um1);
-        hadi_pair_get(grow(js) + 4 * h, 128, u0);
         if (h == 0) {  // the i = 0 values of the rows js - 2 .. js + 1 (steps -2 .. 1)
 #pragma unroll
             for (int q = -2; q <= 1; q++) hist[(q + 4) & 3] = grow(js + q * dir)[c0slot];
         }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 8; r++) um2[r] = um1[r] = u0[r] = 0.0;
     }
+#pragma unroll
+    for (int r = 0; r < 8; r++) um2[r] = um1[r] = u0[r] = 0.0;
     double sc_tmp[4];  // (the shared arrays' global loads before the parameter block is consumed: hadi_pass_a_strip)
     {
         const double *__restrict__ sc = a.scoef + (size_t)inst * 4 * 256;
@@ -1155,6 +1293,20 @@ __global__ void __launch_bounds__(64 * HADI_PAIR_WAVES, 2) hadi_pass_a_pairs(Had
     }
     __syncthreads();
     if (cntA == 0) return;
+    {   // the first row from this half's slot 0; the rows behind from the OTHER half's slots: its first row is this strip's
+        // row behind by one, its row one ahead this strip's row behind by two (rows outside the grid are clamped on both
+        // sides alike and only ever meet zero weights).  Every DMA of the prologue has landed: the coefficient copy above
+        // consumed loads that were issued behind them (the wait is spelled out all the same).
+        hadi_wait_vmcnt(0);
+        hadi_wave_rendezvous();
+        const int other_off = chunk_off ^ 64;  // (the half index is bit 6 of the offset)
+        hadi_pair_get(slot(0) + chunk_off, 256, u0);
+        hadi_pair_get(slot(0) + other_off, 256, um1);
+        hadi_pair_get(slot(1) + other_off, 256, um2);
+#if !defined(HADI_EMU)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // retired before the loop's first fetch reuses slot 0
+#endif
+    }
     if constexpr (AMER == 2) {  // U = max(P, U_0) on the rows behind
         double pay[8];
         hadi_pair_get(payl + 4 * h, 128, pay);
@@ -1174,8 +1326,8 @@ __global__ void __launch_bounds__(64 * HADI_PAIR_WAVES, 2) hadi_pass_a_pairs(Had
         const int j = js + dir * t;      // this half's row (meaningless once t >= cnt: clamped)
         const bool act = t < cnt;
         HadiSRow srA, srB;  // both halves' row-table entries through the scalar cache; they fly during the DMA wait
-        hadi_sload_issue(rtab + (size_t)clampj(jsA + dir * t) * HADI_RC, srA);
-        hadi_sload_issue(rtab + (size_t)clampj(jsB + dir * t) * HADI_RC, srB);
+        hadi_sload_issue(rtab + (size_t)clampj(jsA - t) * HADI_RC, srA);
+        hadi_sload_issue(rtab + (size_t)clampj(jsB + t) * HADI_RC, srB);
         hadi_wave_rendezvous();
         int z = 0;
         if (t + D <= cntA + 1) {  // into the slot of the row that has just left the ring
@@ -1197,14 +1349,11 @@ __global__ void __launch_bounds__(64 * HADI_PAIR_WAVES, 2) hadi_pass_a_pairs(Had
             double rtA[HADI_RCL], rtB[HADI_RCL];
             hadi_sload_wait(srA, rtA);
             hadi_sload_wait(srB, rtB);
-            if (dir < 0) {  // descending: the rows behind are j+1, j+2 -- swap the neighbour weights (scalar registers)
+            {   // strip A descends: its rows behind are j+1, j+2 -- swap the neighbour weights (scalar registers)
                 double w;
                 w = rtA[RC_WMS - HADI_SRC0]; rtA[RC_WMS - HADI_SRC0] = rtA[RC_WPS - HADI_SRC0]; rtA[RC_WPS - HADI_SRC0] = w;
                 w = rtA[RC_L2 - HADI_SRC0]; rtA[RC_L2 - HADI_SRC0] = rtA[RC_U2 - HADI_SRC0]; rtA[RC_U2 - HADI_SRC0] = w;
                 w = rtA[RC_L1 - HADI_SRC0]; rtA[RC_L1 - HADI_SRC0] = rtA[RC_U1 - HADI_SRC0]; rtA[RC_U1 - HADI_SRC0] = w;
-                w = rtB[RC_WMS - HADI_SRC0]; rtB[RC_WMS - HADI_SRC0] = rtB[RC_WPS - HADI_SRC0]; rtB[RC_WPS - HADI_SRC0] = w;
-                w = rtB[RC_L2 - HADI_SRC0]; rtB[RC_L2 - HADI_SRC0] = rtB[RC_U2 - HADI_SRC0]; rtB[RC_U2 - HADI_SRC0] = w;
-                w = rtB[RC_L1 - HADI_SRC0]; rtB[RC_L1 - HADI_SRC0] = rtB[RC_U1 - HADI_SRC0]; rtB[RC_U1 - HADI_SRC0] = w;
             }
             // to per-lane registers under the halves' exec masks (RC_LAST is not needed: is_last below)
 #pragma unroll

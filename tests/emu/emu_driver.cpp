@@ -19,6 +19,7 @@ thread_local int t_lane;
 static HadiTuning g_tune;
 static int g_err = 0, g_debug = 0;  // the handle's device error word and the "debug_fault" test hook
 static int g_tile_il = 0;           // "tile_interleave": the column pass's blocks take their full tiles interleaved (opt-in, as in the library)
+static int g_cs_strips = 1;         // "cs_strips": Craig-Sneyd row passes on strips where the plan chose strips (default, as in the library)
 static int g_col_prefetch = 0;      // "col_prefetch": hadi_pass_b2 for European sweeps of 9 .. 16 chunks (opt-in, as in the library)
 extern "C" int emu_take_error() { const int e = g_err; g_err = 0; return e; }
 extern "C" int emu_set_tuning(const char *key, int value) {
@@ -30,8 +31,9 @@ extern "C" int emu_set_tuning(const char *key, int value) {
     else if (k == "pair_strips") g_tune.pair_strips = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "col_groups") g_tune.col_groups = value > 0 ? value : 0;
     else if (k == "col_prefetch") g_col_prefetch = value ? 1 : 0;
+    else if (k == "cs_strips") g_cs_strips = value ? 1 : 0;
     else if (k == "tile_interleave") g_tile_il = value ? 1 : 0;
-    else if (k == "reset") { g_tune = HadiTuning(); g_debug = 0; g_col_prefetch = 0; g_tile_il = 0; }
+    else if (k == "reset") { g_tune = HadiTuning(); g_debug = 0; g_col_prefetch = 0; g_tile_il = 0; g_cs_strips = 1; }
     else return 1;
     return 0;
 }
@@ -56,6 +58,23 @@ static int run_row_pass(const HadiPlan &pl, const HadiSweepArgs &a, int n, int m
     if (pl.use_pairs && pl.use_strip && mode == 0) {  // two strips per wavefront (4 nodes per lane)
         if (a.american) emu::launch(pl.grid_as, 64 * HADI_PAIR_WAVES, [&]() { hadi_pass_a_pairs<1>(a, n); }, pl.smem_pairs_eu);
         else emu::launch(pl.grid_as, 64 * HADI_PAIR_WAVES, [&]() { hadi_pass_a_pairs<0>(a, n); }, pl.smem_pairs_eu);
+        return 0;
+    }
+    if (pl.use_strip && mode != 0 && !pl.use_pairs && g_cs_strips) {  // Craig-Sneyd on strips: same choice as hadi_api.hip
+        const unsigned nt = 64 * HADI_STRIP_WAVES(pl.L.B);
+        if (pl.L.G == 2) {
+            if (mode == 1) emu::launch(pl.grid_as, nt, [&]() { hadi_pass_a_strip<8, 0, double, 2, 1>(a, n); }, pl.smem_as);
+            else emu::launch(pl.grid_as, nt, [&]() { hadi_pass_a_strip<8, 0, double, 2, 2>(a, n); }, pl.smem_as);
+            return 0;
+        }
+        switch (pl.L.B * 4 + mode) {
+            case 33: emu::launch(pl.grid_as, nt, [&]() { hadi_pass_a_strip<8, 0, double, 1, 1>(a, n); }, pl.smem_as); break;
+            case 34: emu::launch(pl.grid_as, nt, [&]() { hadi_pass_a_strip<8, 0, double, 1, 2>(a, n); }, pl.smem_as); break;
+            case 17: emu::launch(pl.grid_as, nt, [&]() { hadi_pass_a_strip<4, 0, double, 1, 1>(a, n); }, pl.smem_as); break;
+            case 18: emu::launch(pl.grid_as, nt, [&]() { hadi_pass_a_strip<4, 0, double, 1, 2>(a, n); }, pl.smem_as); break;
+            case 9: emu::launch(pl.grid_as, nt, [&]() { hadi_pass_a_strip<2, 0, double, 1, 1>(a, n); }, pl.smem_as); break;
+            default: emu::launch(pl.grid_as, nt, [&]() { hadi_pass_a_strip<2, 0, double, 1, 2>(a, n); }, pl.smem_as); break;
+        }
         return 0;
     }
     if (pl.use_strip && mode == 0 && pl.L.G == 2) {  // paired strips

@@ -183,6 +183,23 @@ def test_craig_sneyd_predictor_corrector(emu):
     _run(emu, 100, 20, 2, [100.0], O.EU, 8, scheme=1)
 
 
+def test_craig_sneyd_on_barrier_free_strips(emu):
+    """Round 4: predictor (MODE 1: the Douglas strip step that also stores R1 and C2) and corrector (MODE 2: rows of Y2
+    through the ring, the R1 / C2 rows of each step as register loads retired by the kernel's own counted waits) on
+    hadi_pass_a_strip at 2, 4 and 8 nodes per lane and on paired strips (m1 > 512); strips with and without a partner,
+    descending and ascending, the b2 row, r_f != 0 (b1 along the anti-diagonal), several instances.  The emulator checks
+    arithmetic and indexing; the waits are what libhadi_strict.so checks on hardware."""
+    emu.emu_set_tuning(b"strip", 1)
+    try:
+        _run(emu, 100, 33, 3, [100.0, 92.0], O.EU, 1, r_f=0.01, scheme=1)   # 2 nodes per lane
+        _run(emu, 200, 40, 2, [100.0], O.EU, 1, scheme=1)                   # 4 nodes per lane
+        _run(emu, 300, 54, 2, [104.0], O.EU, 1, r_f=0.02, scheme=1)         # 8 nodes per lane
+        _run(emu, 512, 26, 2, [100.0], O.EU, 1, scheme=1)                   # full width, strips of 4 rows (7 strips: one without partner)
+        _run(emu, 700, 26, 2, [100.0], O.EU, 1, r_f=0.01, scheme=1)         # paired strips
+    finally:
+        emu.emu_set_tuning(b"reset", 0)
+
+
 def test_small_grid_lds_resident_kernel(emu):
     # whole instance in LDS, one launch for the time loop: all four variants on the reference's 50x25 grid
     _run(emu, 50, 25, 6, [100.0, 95.0], O.EU, 8, small=1)

@@ -693,18 +693,38 @@ def test_american_sweeps_of_wide_grids_on_paired_strips(solver, forced_strips, m
     assert np.abs(lam - lo).max() <= 1e-8 * max(1.0, np.abs(lo).max())
 
 
-def test_craig_sneyd_sweeps_of_wide_grids_stay_on_the_shared_ring(solver, forced_strips):
-    """The strips run the Douglas step only: with strips forced a Craig-Sneyd sweep at m1 > 512 must still run (and meet the
-    oracle) on the shared-ring kernel."""
-    m1, m2, N, n = 600, 40, 5, 2
+@pytest.mark.parametrize("m1,m2,N,n", [(100, 50, 5, 3), (256, 128, 5, 2), (400, 131, 5, 2), (512, 256, 6, 2), (600, 40, 5, 2), (1024, 100, 4, 1)])
+def test_craig_sneyd_on_strips_vs_oracle_ring_and_full_drains(solver, strict_solver, forced_strips, m1, m2, N, n):
+    """Round 4: predictor and corrector row passes of a Craig-Sneyd step on the barrier-free strips (2, 4, 8 nodes per lane,
+    paired strips above 512 s-intervals).  Full field against the oracle; against the shared-ring kernels (tuning key
+    `cs_strips` = 0: the path of rounds 2 - 3) to round-off; and bit for bit against libhadi_strict.so, whose waits drain
+    everything -- the corrector retires the register loads of its R1 / C2 rows by hand-counted waits."""
     strikes = Cm.strikes_for(n)
     grids, U0 = _batch(m1, m2, strikes)
+    args = (m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids)
     U = U0.copy()
-    solver.CS_scheme(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U)
-    assert "strip" not in solver.describe_last_sweep()
+    solver.CS_scheme(*args, U)
+    d = solver.describe_last_sweep()
+    assert ("hadi_pass_a_strip<8,EU,double,2,CS>" if m1 > 512 else "hadi_pass_a_strip<%d,EU,double,1,CS>" % (2 if m1 <= 128 else 4 if m1 <= 256 else 8)) in d, d
     p = O.make_params(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, O.EU, None, scheme=1)
     Uo, _, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0)
     _assert_field(U, Uo)
+    solver.set_tuning("cs_strips", 0)
+    try:
+        Ur = U0.copy()
+        solver.CS_scheme(*args, Ur)
+        assert "strip" not in solver.describe_last_sweep()
+    finally:
+        solver.set_tuning("cs_strips", 1)
+    assert np.abs(U - Ur).max() <= 1e-11 * np.abs(Uo).max()
+    strict_solver.set_tuning("strip", 1)
+    try:
+        Us = U0.copy()
+        strict_solver.CS_scheme(*args, Us)
+        assert strict_solver.describe_last_sweep() == d
+    finally:
+        strict_solver.set_tuning("strip", -1)
+    assert np.array_equal(U, Us)
 
 
 def test_strips_chosen_by_themselves_at_two_nodes_per_lane(solver):

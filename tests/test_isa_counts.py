@@ -41,7 +41,8 @@ def test_python_mirrors_match_the_source():
     k = "".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)) if f.startswith("hadi_k"))
     c = open(os.path.join(csrc, "hadi_core.h")).read()
     assert "return B == 1 ? 1 : (sizeof(T) == 4 && B >= 4) ? B / 4 : B / 2;" in k
-    assert "for (int k = 0; k < NA; k++) aft[k] += hadi_put_block_stores<B, T>();" in k      # strips
+    assert "constexpr int NST = (MODE == 1 ? 3 : 1) * hadi_put_block_stores<B, T>();" in k      # strips (Craig-Sneyd predictor: + R1, C2)
+    assert "for (int k = 0; k < NA; k++) aft[k] += NST;" in k
     assert "for (int k = 0; k < PD; k++) ya[k] += hadi_put_block_stores<B, T>();" in k       # shared ring
     assert "#define HADI_ROW_PAD(B, ES) ((B) < 4 ? 8 : ((ES) == 4 ? 32 : 16))" in c
     assert "#define HADI_STRIP_NS(B, G, ES) ((G) == 2 ? ((ES) == 8 ? 3 : 4) : ((B) <= 4 ? HADI_STRIP_NS_NARROW : 4))" in c
@@ -57,21 +58,31 @@ def test_strip_kernels_issue_at_least_the_stores_and_exactly_the_dma_pieces_the_
     for name, body in kernels.items():
         if not name.startswith("hadi_pass_a_strip<"):
             continue
-        B, amer, T, G = _args(name)
-        B, G, es = int(B), int(G), 4 if T == "float" else 8
+        B, amer, T, G, mode = _args(name)
+        B, G, es, mode = int(B), int(G), 4 if T == "float" else 8, int(mode)
         n_dma = len(re.findall(r"\bglobal_load_lds_dwordx4\b", body))
         n_st = len(re.findall(r"\bglobal_store_dwordx4\b", body)) + (len(re.findall(r"\bglobal_store_dwordx2\b", body)) if (B == 2 and es == 4) else 0)
-        # fetch(): NS call sites (NS - 1 in the prologue, one in the loop)
+        # fetch(): NS + 1 call sites (the strip's first row and the rows 1 .. NS - 1 ahead in the prologue, one in the loop);
+        # the P representation at 8 nodes per lane keeps one slot behind the prefetch: rows 0 .. NS - 2 ahead, NS sites
+        keep = amer == "2" and B >= 8 and G == 1
+        sites = STRIP_NS(B, G, es) + (0 if keep else 1)
         rowp = 64 * B * G + PAD(B, es)
         if G == 1:
             pieces = -(-(rowp * es // 16) // 64)          # hadi_row_dma_count: whole 1 KiB pieces + the partial one
         else:
             pieces = (B * es // 16) + 1                   # hadi_half_row_to_lds: the half's pieces + the pad piece (low half)
-        assert n_dma == STRIP_NS(B, G, es) * pieces, (name, n_dma)
-        # hadi_strip_step is instantiated twice (last v-row or not): each copy stores the row block once
-        assert n_st >= 2 * STORES(B, es), (name, n_st)
+        assert n_dma == sites * pieces, (name, n_dma)
+        # hadi_strip_step is instantiated twice (last v-row or not): each copy stores the row block once; the Craig-Sneyd
+        # predictor (mode 1) stores R1 and C2 as well, the corrector (mode 2) has one copy of the step
+        assert n_st >= (6 if mode == 1 else 1 if mode == 2 else 2) * STORES(B, es), (name, n_st)
+        if mode == 2:
+            # the R1 / C2 register loads the waits count: B / 2 + 1 per row and array, two issue sites (prologue, loop) --
+            # and no other 16-byte vector load may sit in the kernel's loop, so count them all
+            # (+ the prologue's register loads of three rows for a strip without a partner: compiler loads, outside the loop)
+            n_x4 = len(re.findall(r"\bglobal_load_dwordx4\b", body))
+            assert n_x4 == 2 * 2 * (B // 2) + 3 * (B // 2), (name, n_x4)
         seen += 1
-    assert seen >= 12
+    assert seen >= 20
 
 
 def test_ring_kernels_issue_at_least_the_stores_the_waits_count(kernels):
@@ -91,8 +102,9 @@ def test_ring_kernels_issue_at_least_the_stores_the_waits_count(kernels):
 
 def test_pair_strip_kernels_issue_the_dma_pieces_and_stores_the_waits_count(kernels):
     """hadi_pass_a_pairs: HADI_PAIR_DMA = 6 LDS-DMA instructions per fetch (four 1 KiB pieces of both rows + the two 128-byte
-    tails), four fetch sites (three in the prologue, one in the loop; the P representation fetches row js instead of the row
-    4 ahead), HADI_PAIR_STORES = 4 counted row stores per step (one copy of the step)."""
+    tails), five fetch sites (the first row and the rows 1 .. 3 ahead in the prologue, one in the loop; the P representation
+    keeps the first row's slot and has the rows 1 .. 2 ahead: four), HADI_PAIR_STORES = 4 counted row stores per step (one
+    copy of the step)."""
     csrc = os.path.join(ROOT, "pde_based_heston_solver_gpu_accelerated_amd", "csrc")
     k = "".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)) if f.startswith("hadi_k"))
     assert "#define HADI_PAIR_DMA 6" in k and "#define HADI_PAIR_STORES 4" in k
@@ -102,7 +114,7 @@ def test_pair_strip_kernels_issue_the_dma_pieces_and_stores_the_waits_count(kern
             continue
         n_dma = len(re.findall(r"\bglobal_load_lds_dwordx4\b", body))
         n_st = len(re.findall(r"\bglobal_store_dwordx4\b", body))
-        assert n_dma == 4 * 6, (name, n_dma)
+        assert n_dma == (4 if _args(name)[0] == "2" else 5) * 6, (name, n_dma)
         assert n_st >= 4, (name, n_st)
         seen += 1
     assert seen == 3
