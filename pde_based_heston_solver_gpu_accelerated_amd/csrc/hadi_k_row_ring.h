@@ -89,6 +89,50 @@ HADI_DEV constexpr int hadi_put_block_stores() {
     return B == 1 ? 1 : (sizeof(T) == 4 && B >= 4) ? B / 4 : B / 2;
 }
 
+// Cache policy of the carry-over arrays R1 and C2: non-temporal, loads (a last use) and stores (read again two launches later,
+// after 0.8 GB of other traffic) alike -- written or read with the default policy they take the place of the array the NEXT
+// launch reads (Y, written by this pass) in the 256 MB memory-side cache.
+#ifndef HADI_CS_POLICY
+#define HADI_CS_POLICY " nt"
+#endif
+template <int B, int G>
+HADI_DEV HADI_FORCEINLINE void hadi_put_block_nt(double *row, int half, int lane, const double (&u)[B]) {
+#if defined(HADI_EMU)
+    hadi_put_block<B, G>(row, half, lane, u);
+#else
+    typedef double hadi_d2 __attribute__((ext_vector_type(2)));
+    if constexpr (B == 1) {
+        __builtin_nontemporal_store(u[0], row + 64 * half + lane);
+    } else {
+#pragma unroll
+        for (int q = 0; q < B / 2; q++) {
+            hadi_d2 t;
+            t.x = u[2 * q];
+            t.y = u[2 * q + 1];
+            __builtin_nontemporal_store(t, reinterpret_cast<hadi_d2 *>(row + q * 128 * G + 128 * half + 2 * lane));
+        }
+    }
+#endif
+}
+template <int B, int G>
+HADI_DEV HADI_FORCEINLINE void hadi_get_block_nt(const double *row, int half, int lane, double (&u)[B]) {
+#if defined(HADI_EMU)
+    hadi_get_block<B, G>(row, half, lane, u);
+#else
+    typedef double hadi_d2 __attribute__((ext_vector_type(2)));
+    if constexpr (B == 1) {
+        u[0] = __builtin_nontemporal_load(row + 64 * half + lane);
+    } else {
+#pragma unroll
+        for (int q = 0; q < B / 2; q++) {
+            const hadi_d2 t = __builtin_nontemporal_load(reinterpret_cast<const hadi_d2 *>(row + q * 128 * G + 128 * half + 2 * lane));
+            u[2 * q] = t.x;
+            u[2 * q + 1] = t.y;
+        }
+    }
+#endif
+}
+
 // One v-row: explicit stage, Y0, A1 line solve, A2 right-hand side.  LAST = this is the v-row that
 // carries b2 (hes_boundary_kernels.hpp:62-66); AMER adds lambda_bar (device_solver.hpp:325-331).
 // `active` is wave-uniform; with G = 2 every wave of the block must call this (it contains a barrier).
@@ -219,8 +263,8 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
         if constexpr (AMER == 1) hadi_get_block<B, G>(c.Li + (size_t)j * rowp, half, lane, lam);
         if constexpr (LAST) hadi_get_block<B, G>(c.b2r, half, lane, b2v);
         if constexpr (MODE == 2) {
-            hadi_get_block<B, G>(c.R1i + (size_t)j * rowp, half, lane, r1v);
-            hadi_get_block<B, G>(c.C2i + (size_t)j * rowp, half, lane, c2v);
+            hadi_get_block_nt<B, G>(c.R1i + (size_t)j * rowp, half, lane, r1v);
+            hadi_get_block_nt<B, G>(c.C2i + (size_t)j * rowp, half, lane, c2v);
         }
 
         // ---- Y0 (device_solver.hpp:236-250) fused with the forward sweep of the in-lane Thomas ----------
@@ -475,8 +519,8 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
             if constexpr (MODE == 1) c2v[r] = corr;
         }
         if constexpr (MODE == 1) {
-            hadi_put_block<B, G>(c.R1i + (size_t)j * rowp, half, lane, r1v);
-            hadi_put_block<B, G>(c.C2i + (size_t)j * rowp, half, lane, c2v);
+            hadi_put_block_nt<B, G>(c.R1i + (size_t)j * rowp, half, lane, r1v);
+            hadi_put_block_nt<B, G>(c.C2i + (size_t)j * rowp, half, lane, c2v);
         }
         hadi_put_block<B, G, T>(c.Yi + (size_t)j * rowp, half, lane, yo);
         if (lane == 0 && first_half) c.Yi[(size_t)j * rowp + c0slot] = (T)yout_c0;

@@ -82,8 +82,8 @@ HADI_DEV HADI_FORCEINLINE int hadi_asm_block_issue(const double *row, int half, 
 #else
 #pragma unroll
     for (int q = 0; q < B / 2; q++)
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r.q[q]) : "v"(row + q * 128 * G + 128 * half + 2 * lane) : "memory");
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(r.c0) : "v"(row + 64 * B * G) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" HADI_CS_POLICY : "=&v"(r.q[q]) : "v"(row + q * 128 * G + 128 * half + 2 * lane) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, off" HADI_CS_POLICY : "=&v"(r.c0) : "v"(row + 64 * B * G) : "memory");
 #endif
     return B / 2 + 1;
 }
@@ -500,8 +500,8 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
         if constexpr (MODE == 1) c2v[r] = corr;
     }
     if constexpr (MODE == 1) {  // (two more row stores per step: the kernel's counted waits add them)
-        hadi_put_block<B, G>(c.R1i + (size_t)j * rowp, half, lane, r1v);
-        hadi_put_block<B, G>(c.C2i + (size_t)j * rowp, half, lane, c2v);
+        hadi_put_block_nt<B, G>(c.R1i + (size_t)j * rowp, half, lane, r1v);
+        hadi_put_block_nt<B, G>(c.C2i + (size_t)j * rowp, half, lane, c2v);
     }
     // Plain global stores on purpose.  Raw BUFFER stores here (SGPR row offset, one 32-bit lane offset: two VGPRs and the
     // 64-bit address arithmetic saved, 0.5 % faster) were tried in round 2 and are WRONG for this kernel: the counted vmcnt
