@@ -200,6 +200,9 @@ typedef unsigned hadi_u32x2 __attribute__((ext_vector_type(2)));
 #ifndef HADI_AUX_NT
 #define HADI_AUX_NT 2
 #endif
+#ifndef HADI_AUX_NT_ST   // (stores of the column pass: the same policy unless an experiment overrides it, tools/build_variant.py)
+#define HADI_AUX_NT_ST HADI_AUX_NT
+#endif
 struct HadiBuf { __amdgpu_buffer_rsrc_t r; };
 HADI_DEV HADI_FORCEINLINE HadiBuf hadi_make_buf(const void *base, size_t bytes) {
     return HadiBuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000)};
@@ -225,7 +228,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_buf_store(HadiBuf b, unsigned voff_bytes, un
     hadi_u32x2 d;
     d.x = (unsigned)__double2loint(v);
     d.y = (unsigned)__double2hiint(v);
-    __builtin_amdgcn_raw_buffer_store_b64(d, b.r, voff_bytes, soff_bytes, HADI_AUX_NT);
+    __builtin_amdgcn_raw_buffer_store_b64(d, b.r, voff_bytes, soff_bytes, HADI_AUX_NT_ST);
 }
 #endif
 
@@ -244,7 +247,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_buf_store_t(HadiBuf b, unsigned voff_bytes, 
     if constexpr (sizeof(T) == 8) {
         hadi_buf_store(b, voff_bytes, soff_bytes, v);
     } else {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), b.r, voff_bytes, soff_bytes, HADI_AUX_NT);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), b.r, voff_bytes, soff_bytes, HADI_AUX_NT_ST);
     }
 }
 #endif
@@ -328,7 +331,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_set_prio(int p) {
 // lane reads LDS another lane of the same wavefront wrote.
 HADI_DEV HADI_FORCEINLINE void hadi_wave_rendezvous() {
 #if defined(HADI_EMU)
-    pthread_barrier_wait(&emu::t_wave->bar);
+    emu::wave_barrier();
 #endif
 }
 

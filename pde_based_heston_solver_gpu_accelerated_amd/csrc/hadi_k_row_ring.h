@@ -59,8 +59,24 @@ HADI_DEV HADI_FORCEINLINE void hadi_get_block(const T *row, int half, int lane, 
         }
     }
 }
+#ifndef HADI_ROW_ST_NT   // (experiment: the row pass's result stores non-temporal too -- they are meant to STAY in the memory-side cache)
+#define HADI_ROW_ST_NT 0
+#endif
 template <int B, int G, class T = double>
 HADI_DEV HADI_FORCEINLINE void hadi_put_block(T *row, int half, int lane, const double (&u)[B]) {
+#if HADI_ROW_ST_NT && !defined(HADI_EMU)
+    if constexpr (sizeof(T) == 8 && B >= 2) {
+        typedef double hadi_d2s __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int q = 0; q < B / 2; q++) {
+            hadi_d2s t;
+            t.x = u[2 * q];
+            t.y = u[2 * q + 1];
+            __builtin_nontemporal_store(t, reinterpret_cast<hadi_d2s *>(row + q * 128 * G + 128 * half + 2 * lane));
+        }
+        return;
+    }
+#endif
     if constexpr (sizeof(T) == 4 && B >= 4) {
 #pragma unroll
         for (int q = 0; q < B / 4; q++) {

@@ -81,17 +81,17 @@ def test_dividends_and_chunked_column_pass(emu):
 def test_single_buffer_column_pass_for_more_than_8_chunks(emu):
     # m2 = 270 -> 271 v-rows -> 9 chunks -> the 16-wave single-buffer kernel; few blocks per instance so that a block
     # walks several column tiles (store + reload of the same registers), American adds the projection
-    _run(emu, 130, 265, 1, [97.0], O.AM, 1, r_f=0.01)
+    _run(emu, 70, 265, 1, [97.0], O.AM, 1, r_f=0.01)
     # European sweeps: hadi_pass_b2 (12 rows of the next tile prefetched into LDS, 24 with the fp32 state; one exchange buffer)
     # and, with the prefetch switched off, hadi_pass_b1; 9 and 16 chunks, a short last tile, a block of one tile
     for pf in (1, 0):
         emu.emu_set_tuning(b"col_prefetch", pf)
         emu.emu_set_tuning(b"tile_interleave", pf)  # (with it: the blocks take their full tiles interleaved)
         try:
-            _run(emu, 140, 270, 1, [100.0], O.EU, 1)
+            _run(emu, 100, 270, 1, [100.0], O.EU, 1)
             if pf:
                 _run(emu, 64, 500, 1, [100.0], O.EU, 8, r_f=0.01)      # 16 chunks (1024-thread block), two tiles
-                _run(emu, 140, 270, 1, [100.0], O.EU, 1, scheme=2)     # fp32 state: 16 rows prefetched, 4 rows per DMA instruction
+                _run(emu, 100, 270, 1, [100.0], O.EU, 1, scheme=2)     # fp32 state: 16 rows prefetched, 4 rows per DMA instruction
         finally:
             emu.emu_set_tuning(b"reset", 0)
 
@@ -145,7 +145,7 @@ def test_american_p_representation(emu):
     _run(emu, 40, 12, 4, [100.0, 92.0], O.AM, 4, r_f=0.01, scheme=3)
     _run(emu, 200, 33, 7, [100.0], O.AM_DIV, 8, scheme=3)
     _run(emu, 530, 10, 2, [100.0], O.AM, 8, scheme=3)
-    _run(emu, 140, 265, 1, [97.0], O.AM, 1, scheme=3)
+    _run(emu, 70, 265, 1, [97.0], O.AM, 1, scheme=3)
     # batches large enough for the strip row pass: 8 nodes per lane (payoff row in LDS), with dividend steps in between,
     # and 4-strip blocks at 2 nodes per lane
     _run(emu, 300, 70, 2, [100.0], O.AM, 1, r_f=0.01, scheme=3)
@@ -191,11 +191,10 @@ def test_craig_sneyd_on_barrier_free_strips(emu):
     arithmetic and indexing; the waits are what libhadi_strict.so checks on hardware."""
     emu.emu_set_tuning(b"strip", 1)
     try:
-        _run(emu, 100, 33, 3, [100.0, 92.0], O.EU, 1, r_f=0.01, scheme=1)   # 2 nodes per lane
-        _run(emu, 200, 40, 2, [100.0], O.EU, 1, scheme=1)                   # 4 nodes per lane
-        _run(emu, 300, 54, 2, [104.0], O.EU, 1, r_f=0.02, scheme=1)         # 8 nodes per lane
-        _run(emu, 512, 26, 2, [100.0], O.EU, 1, scheme=1)                   # full width, strips of 4 rows (7 strips: one without partner)
-        _run(emu, 700, 26, 2, [100.0], O.EU, 1, r_f=0.01, scheme=1)         # paired strips
+        _run(emu, 100, 20, 3, [100.0, 92.0], O.EU, 1, r_f=0.01, scheme=1)   # 2 nodes per lane; 21 rows: 4 strips of 6, the last one short
+        _run(emu, 200, 26, 2, [100.0], O.EU, 1, scheme=1)                   # 4 nodes per lane
+        _run(emu, 300, 34, 2, [104.0], O.EU, 1, r_f=0.02, scheme=1)         # 8 nodes per lane: 35 rows, 7 strips of 5 (one without a partner)
+        _run(emu, 700, 20, 2, [100.0], O.EU, 1, r_f=0.01, scheme=1)         # paired strips
     finally:
         emu.emu_set_tuning(b"reset", 0)
 
