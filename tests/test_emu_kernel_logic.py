@@ -35,7 +35,7 @@ def emu():
     return C.CDLL(EMU_SO)
 
 
-def _run(emu, m1, m2, N, strikes, variant, target_waves, r_f=0.0, small=0, scheme=0, put=False):
+def _run(emu, m1, m2, N, strikes, variant, target_waves, r_f=0.0, small=0, scheme=0, put=False, tol=1e-11):
     """scheme: 0 Douglas, 1 Craig-Sneyd, 2 Douglas with the state kept in fp32 between the passes, 3 Douglas with the
     American P representation (no lambda_bar array; explicit pair on step 1 and on dividend steps)."""
     n = len(strikes)
@@ -56,7 +56,7 @@ def _run(emu, m1, m2, N, strikes, variant, target_waves, r_f=0.0, small=0, schem
     assert rc == 0
     scale = np.abs(Uo).max()
     # fp32 state: an fp64 last-bit difference before a store can flip the float rounding (6e-8 relative), per step
-    assert np.abs(U - Uo).max() < (2e-7 * N if scheme == 2 else 1e-11) * scale
+    assert np.abs(U - Uo).max() < (2e-7 * N if scheme == 2 else tol) * scale
     if lamo is not None:
         assert np.abs(lam - lamo).max() < 1e-9 * max(1.0, np.abs(lamo).max())
 
@@ -497,3 +497,61 @@ def test_pair_strips_two_strips_per_wavefront(emu):
         _run(emu, 200, 40, 2, [100.0], O.EU, 1)
     finally:
         emu.emu_set_tuning(b"reset", 0)
+
+
+def _random_case(rng):
+    """One random problem for the emulator sweep below: shape class, variant, scheme and the kernel-selection overrides the
+    library's own tuning keys offer (the generator of tools/fuzz_parity.py is frozen; this one is the emulator's own)."""
+    cls = rng.choice(["one", "two", "four", "eight", "wide", "seq_row", "seq_col", "tall"])
+    m1 = {"one": rng.randint(8, 64), "two": rng.randint(65, 128), "four": rng.randint(129, 256), "eight": rng.randint(257, 512),
+          "wide": rng.randint(513, 1024), "seq_row": rng.randint(1025, 1100), "seq_col": rng.randint(20, 200),
+          "tall": rng.randint(20, 140)}[cls]
+    m2 = {"seq_col": rng.randint(528, 540), "tall": rng.randint(264, 520)}.get(cls, rng.randint(6, 70) if rng.random() < 0.8 else rng.randint(71, 200))
+    seq = cls in ("seq_row", "seq_col")
+    variant = rng.choice([O.EU, O.AM, O.DIV, O.AM_DIV])
+    scheme = 0
+    if not seq:
+        if variant == O.EU and rng.random() < 0.3: scheme = 1
+        elif variant == O.EU and rng.random() < 0.4: scheme = 2   # (the emulator driver has no widen / jump / narrow path for dividends)
+        elif variant in (O.AM, O.AM_DIV) and rng.random() < 0.6: scheme = 3
+    put = scheme in (0, 3) and rng.random() < 0.3
+    tuning = {}
+    if not seq and rng.random() < 0.6: tuning["strip"] = 1
+    if cls == "four" and rng.random() < 0.5: tuning["pair_strips"] = 1
+    if rng.random() < 0.2: tuning["strip_blocks"] = rng.choice([2, 3])
+    if scheme == 1 and rng.random() < 0.3: tuning["cs_strips"] = 0
+    if rng.random() < 0.2: tuning["col_prefetch"] = 1
+    if rng.random() < 0.2: tuning["tile_interleave"] = 1
+    n = rng.choice([1, 1, 2, 3])
+    N = rng.randint(1, 3) if variant in (O.EU, O.AM) else rng.randint(4, 7)   # (the dividends land on steps 2 .. 6)
+    return dict(m1=m1, m2=m2, N=N, strikes=[rng.uniform(85, 115) for _ in range(n)], variant=variant, scheme=scheme, put=put,
+                r_f=rng.choice([0.0, 0.01, 0.03]), target_waves=rng.choice([1, 8]), tuning=tuning)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_shapes_and_kernel_choices_vs_oracle(emu, seed):
+    """Since the emulator runs a wavefront's lanes as fibers (round 4) a sweep costs tenths of a second: 8 x 30 random problems
+    -- every shape class (1 .. 8 nodes per lane, two wavefronts per row, the sequential passes beyond 1024 / 527 intervals,
+    9 .. 16 column chunks), the four variants, Craig-Sneyd, the fp32 state, the P representation, put data, forced strips /
+    pair strips / several blocks per instance / column-pass alternatives -- each against the oracle's full field."""
+    import random
+    rng = random.Random(1000 + seed)
+    for k in range(25):
+        c = _random_case(rng)
+        # well-conditioned s-grids only: S_0 inserted a few 1e-6 beside a node leaves neighbouring intervals 1e5 apart and
+        # cond * eps of round-off in BOTH fp64 solvers -- the GPU campaign sends such instances to the binary128 adjudicator
+        # (DESIGN.md section 2); here the strikes are drawn again
+        for _ in range(50):
+            d = np.diff(Cm.oracle_grids(c["m1"], 8, c["strikes"])[0], axis=1)
+            if np.maximum(d[:, 1:] / d[:, :-1], d[:, :-1] / d[:, 1:]).max() <= 30.0:
+                break
+            c["strikes"] = [rng.uniform(85, 115) for _ in c["strikes"]]
+        for key, val in c["tuning"].items():
+            assert emu.emu_set_tuning(key.encode(), val) == 0
+        try:
+            _run(emu, c["m1"], c["m2"], c["N"], c["strikes"], c["variant"], c["target_waves"], r_f=c["r_f"], scheme=c["scheme"], put=c["put"],
+                 tol=1e-10)  # (the bound of the GPU parity tests)
+        except AssertionError as e:
+            raise AssertionError("seed %d case %d: %r" % (seed, k, c)) from e
+        finally:
+            emu.emu_set_tuning(b"reset", 0)
