@@ -110,7 +110,11 @@ HADI_DEV HADI_FORCEINLINE bool hadi_team_barrier(int *ctr, int target, int xcc_t
 #if defined(HADI_EMU)
         __atomic_fetch_add(ctr, 1, __ATOMIC_SEQ_CST);
         int guard = 0;
-        while (__atomic_load_n(ctr, __ATOMIC_SEQ_CST) < target && ++guard < HADI_TEAM_POLLS) sched_yield();
+        // (host threads: a phase of another block takes tenths of a second here -- back off instead of burning the poll budget)
+        while (__atomic_load_n(ctr, __ATOMIC_SEQ_CST) < target && ++guard < HADI_TEAM_POLLS) {
+            if (guard < 1024) sched_yield();
+            else { struct timespec ts = {0, 100000}; nanosleep(&ts, nullptr); }
+        }
 #else
         // Release side: every wavefront of the block drained its stores above (the vector L1 is write-through: an
         // acknowledged store IS in this XCD's L2), so the counter update itself can be relaxed.  An agent-scope RELEASE
@@ -193,7 +197,7 @@ __global__ void __launch_bounds__(512, 2) hadi_team_kernel(HadiSweepArgs a, Hadi
     c.hr0 = hadi_uniform_d(ip.hr0); c.inv0 = hadi_uniform_d(1.0 / (1.0 + ip.thdt * ip.hr0));
     double *const Ui = a.U + (size_t)inst * a.L.inst_stride;
     c.Yi = a.Y + (size_t)inst * a.L.inst_stride;
-    c.Li = nullptr;
+    c.Li = nullptr; c.R1i = nullptr; c.C2i = nullptr;
     c.b2r = a.b2row + (size_t)inst * rowp;
     c.inv_dt = 0.0; c.m1_lane = -1; c.m1_r = -1;
 

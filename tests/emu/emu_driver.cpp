@@ -20,6 +20,7 @@ static HadiTuning g_tune;
 static int g_err = 0, g_debug = 0;  // the handle's device error word and the "debug_fault" test hook
 static int g_tile_il = 0;           // "tile_interleave": the column pass's blocks take their full tiles interleaved (opt-in, as in the library)
 static int g_cs_strips = 1;         // "cs_strips": Craig-Sneyd row passes on strips where the plan chose strips (default, as in the library)
+static int g_team_blocks = 1;       // "team_blocks": blocks per team of the instance-resident launch (> 1: the grid's blocks run concurrently)
 static int g_col_prefetch = 0;      // "col_prefetch": hadi_pass_b2 for European sweeps of 9 .. 16 chunks (opt-in, as in the library)
 extern "C" int emu_take_error() { const int e = g_err; g_err = 0; return e; }
 extern "C" int emu_set_tuning(const char *key, int value) {
@@ -32,8 +33,9 @@ extern "C" int emu_set_tuning(const char *key, int value) {
     else if (k == "col_groups") g_tune.col_groups = value > 0 ? value : 0;
     else if (k == "col_prefetch") g_col_prefetch = value ? 1 : 0;
     else if (k == "cs_strips") g_cs_strips = value ? 1 : 0;
+    else if (k == "team_blocks") g_team_blocks = value > 0 ? value : 1;
     else if (k == "tile_interleave") g_tile_il = value ? 1 : 0;
-    else if (k == "reset") { g_tune = HadiTuning(); g_debug = 0; g_col_prefetch = 0; g_tile_il = 0; g_cs_strips = 1; }
+    else if (k == "reset") { g_tune = HadiTuning(); g_debug = 0; g_col_prefetch = 0; g_tile_il = 0; g_cs_strips = 1; g_team_blocks = 1; }
     else return 1;
     return 0;
 }
@@ -281,12 +283,15 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
         if (american || cs || f32 || n_inst > 8 || L.G != 1 || (L.B != 8 && L.B != 4) || L.P > 8) return 3;
         std::vector<int> team(512, 0);
         HadiTeamArgs ta;
-        ta.form = team.data(); ta.bar = team.data() + 64; ta.nb = 1; ta.N = N; ta.stamps = nullptr;
+        // "team_blocks" > 1: teams of several blocks, all blocks of the grid running at once (the team barrier, the formation
+        // counters and the row / column-tile split over the blocks are then real); 1: block after block, a team per block
+        const int nb = g_team_blocks;
+        ta.form = team.data(); ta.bar = team.data() + 64; ta.nb = nb; ta.N = N; ta.stamps = nullptr;
         ta.div_flag = dividend ? flags.data() : nullptr; ta.flag_stride = 0; ta.div_amounts = damounts; ta.div_pcts = dpcts; ta.vec_s = vec_s;
         const size_t smem = ((size_t)4 * 64 * L.B + hadi_pb_mf_doubles(L.P) + (size_t)L.P * HADI_LC * HADI_PBW +
                              (dividend ? (size_t)(L.m1 + 2) + (size_t)8 * L.rowp : 0)) * sizeof(double) + 64;
-        if (L.B == 8) emu::launch(8, 512, [&]() { hadi_team_kernel<8>(a, ta); }, smem);
-        else emu::launch(8, 512, [&]() { hadi_team_kernel<4>(a, ta); }, smem);
+        if (L.B == 8) emu::launch(8 * nb, 512, [&]() { hadi_team_kernel<8>(a, ta); }, smem, nb > 1);
+        else emu::launch(8 * nb, 512, [&]() { hadi_team_kernel<4>(a, ta); }, smem, nb > 1);
         emu::launch(8, 64, [&]() { hadi_unpack_kernel(L, n_inst, dU.data(), U); });
         return g_err ? 4 : 0;
     }

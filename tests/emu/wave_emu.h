@@ -8,6 +8,7 @@
 #pragma once
 #include <pthread.h>
 #include <sched.h>
+#include <time.h>
 #include <sys/mman.h>
 
 #include <condition_variable>
@@ -189,32 +190,41 @@ inline void run_wave(BlockState *bs, WaveState *w, unsigned block, unsigned b, u
 // shuffles / barriers, exactly as on hardware with a full EXEC mask; a lane that returns early simply drops out (its wave
 // mates must not depend on it afterwards, which holds for the wave- or block-uniform early exits the kernels use).
 template <class F>
-void launch(unsigned grid, unsigned block, F body, size_t dyn_smem_bytes = 0) {
-    // LDS is NOT zero on a GPU: poison it so that reads of never-written LDS surface here
-    std::vector<double> smem_store((dyn_smem_bytes + 7) / 8 + 2, std::nan(""));
+void launch(unsigned grid, unsigned block, F body, size_t dyn_smem_bytes = 0, bool concurrent = false) {
+    // `concurrent`: all blocks of the grid at once, each with its own LDS -- for kernels whose blocks wait for each other
+    // (the team barrier of the instance-resident launch); otherwise block after block, as rounds 1 - 3 did
     const std::function<void()> fn = body;
-    for (unsigned b = 0; b < grid; b++) {
-        BlockState bs;
-        bs.dyn_smem = reinterpret_cast<unsigned char *>(smem_store.data());
-        const unsigned nw = (block + 63) / 64;
-        bs.live = (int)nw;
-        for (unsigned w = 0; w < nw; w++) {
-            WaveState *ws = new WaveState;
-            ws->nlanes = (int)std::min(64u, block - w * 64);
-            for (int k = 0; k < ws->nlanes; k++) ws->lane[k].tid = w * 64 + k;
-            ws->body = &fn;
-            std::memset(ws->slot, 0, sizeof(ws->slot));
-            bs.waves.push_back(ws);
+    const unsigned nw = (block + 63) / 64;
+    const size_t smem_doubles = (dyn_smem_bytes + 7) / 8 + 2;
+    const unsigned group = concurrent ? grid : 1;
+    for (unsigned b0 = 0; b0 < grid; b0 += group) {
+        // LDS is NOT zero on a GPU: poison it so that reads of never-written LDS surface here
+        std::vector<double> smem_store(smem_doubles * group, std::nan(""));
+        std::vector<BlockState> bss(group);
+        std::vector<std::thread> th;
+        for (unsigned g = 0; g < group; g++) {
+            BlockState &bs = bss[g];
+            bs.dyn_smem = reinterpret_cast<unsigned char *>(smem_store.data() + smem_doubles * g);
+            bs.live = (int)nw;
+            for (unsigned w = 0; w < nw; w++) {
+                WaveState *ws = new WaveState;
+                ws->nlanes = (int)std::min(64u, block - w * 64);
+                for (int k = 0; k < ws->nlanes; k++) ws->lane[k].tid = w * 64 + k;
+                ws->body = &fn;
+                std::memset(ws->slot, 0, sizeof(ws->slot));
+                bs.waves.push_back(ws);
+            }
         }
-        if (nw == 1) {
-            run_wave(&bs, bs.waves[0], block, b, grid);
+        if (group == 1 && nw == 1) {
+            run_wave(&bss[0], bss[0].waves[0], block, b0, grid);
         } else {
-            std::vector<std::thread> th;
-            th.reserve(nw);
-            for (unsigned w = 0; w < nw; w++) th.emplace_back([&, w, b]() { run_wave(&bs, bs.waves[w], block, b, grid); });
+            th.reserve((size_t)group * nw);
+            for (unsigned g = 0; g < group; g++)
+                for (unsigned w = 0; w < nw; w++) th.emplace_back([&, g, w]() { run_wave(&bss[g], bss[g].waves[w], block, b0 + g, grid); });
             for (auto &x : th) x.join();
         }
-        for (auto *ws : bs.waves) delete ws;
+        for (auto &bs : bss)
+            for (auto *ws : bs.waves) delete ws;
     }
 }
 }  // namespace emu

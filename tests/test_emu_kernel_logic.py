@@ -465,6 +465,18 @@ def test_instance_resident_team_kernel(emu):
     _run(emu, 200, 40, 6, [100.0, 95.0], O.DIV, 8, small=4)          # discrete dividends: the jump inside the time loop (4 nodes per lane)
     _run(emu, 300, 20, 12, [100.0], O.DIV, 8, small=4, put=True)     # ... 8 nodes per lane, put data (ex-dividend spot <= 0 takes the s = 0 value)
     _run(emu, 512, 256, 1, [100.0], O.EU, 8, small=4)                # the benchmarked shape: 257 rows, 8 chunks, 9 column tiles
+    # Teams of SEVERAL blocks (round 4: the emulator can run all blocks of a grid at once): formation counters, the team barrier
+    # with its arrival counter, rows and column tiles split over the blocks, the rows other blocks wrote read back through
+    # global memory.  2, 4 and 32 blocks per team (the last one the product's geometry: 256 wavefronts for 257 rows).
+    for nb, cases in ((2, [(300, 40, 2, [100.0, 93.0], O.EU, {}), (200, 100, 3, [100.0], O.DIV, dict(r_f=0.01))]),
+                      (4, [(512, 70, 2, [100.0, 96.0, 104.0], O.EU, dict(r_f=0.01)), (260, 130, 6, [100.0], O.DIV, dict(put=True))]),
+                      (32, [(512, 256, 2, [100.0], O.EU, {})])):
+        emu.emu_set_tuning(b"team_blocks", nb)
+        try:
+            for m1, m2, N, ks, var, kw in cases:
+                _run(emu, m1, m2, N, ks, var, 8, small=4, **kw)
+        finally:
+            emu.emu_set_tuning(b"reset", 0)
 
 
 def test_sequential_passes_for_shapes_beyond_the_streaming_kernels(emu):
