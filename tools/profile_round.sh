@@ -29,6 +29,8 @@ bash tools/profile_c5_pmc.sh all $TAG
 python3 tools/colpass_ab.py > profiles/${TAG}_colpass_ab.txt 2> $RAW/colpass_ab.err
 python3 tools/stream_sweep.py > profiles/${TAG}_stream_sweep.txt 2> $RAW/stream_sweep.err
 python3 tools/seq_bench.py > profiles/${TAG}_seq_bench.txt 2> $RAW/seq_bench.err
+# Craig-Sneyd on the strips / on the shared ring against Douglas (512x256 x256, 700x300 x128, 1024x512 x64, 256x128 x512)
+(python3 tools/cs_bench.py 256 100; python3 tools/cs_bench.py 128 100 700 300; python3 tools/cs_bench.py 64 60 1024 512; python3 tools/cs_bench.py 512 100 256 128) 2> $RAW/cs_bench.err | grep -v amdgpu.ids > profiles/${TAG}_cs_bench.txt
 # the literal config 2 (ONE 512x256x1000 instance) and small batches: instance-resident launch against the streaming path
 python3 tools/team_ab.py 1 2 4 8 > profiles/${TAG}_team_ab.txt 2> $RAW/team_ab.err
 mkdir -p gpurun_out/profiles_out && cp profiles/${TAG}_* profiles/pmc_traffic.json gpurun_out/profiles_out/
