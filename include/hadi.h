@@ -202,12 +202,15 @@ int hadi_get_timing(const hadi_ctx *ctx, hadi_timing *out);
  *                 tile prefetched into LDS by LDS-DMA -- instead of hadi_pass_b1; "tile_interleave" 0 (default) / 1: the blocks of
  *                 an instance walk their column tiles interleaved.  Both measured within +-2 % (profiles/r04_colpass_ab.txt);
  *                 same bits as the default path
+ *   "cs_strips"   1 (default) / 0: the predictor / corrector row passes of a Craig-Sneyd sweep on the barrier-free strips wherever
+ *                 the plan picks strips (0: on the shared ring, the path of rounds 2 - 3; same fields to round-off)
  *   "graph_max_melems" hipGraph replay of the time loop for batches of up to this many Mi state elements (default 8; larger
  *                 batches are not launch-bound: measured equal)
  *   "device_vgrid" v-grids of compute_base_prices / compute_jacobian rebuilt per instance on the device (default 1;
  *                 0 = built once on the host with glibc sinh/asinh and broadcast -- bit-identical to the reference's
  *                 host-side Grid, needs one shared V_0)
- *   "team_launch" instance-resident execution of batches of up to 8 large European instances (128 < m1 <= 512, m2 <= 263):
+ *   "team_launch" instance-resident execution of batches of up to 8 large European instances, with or without discrete dividends
+ *                 (128 < m1 <= 512, m2 <= 263):
  *                 the whole time loop in ONE launch, every instance kept in the L2 of one XCD by a team of 32 blocks
  *                 (hadi_team_kernel): -1 automatic (default), 0 never, 1 whenever the shape allows it.  If the team
  *                 protocol fails (it is bounded everywhere) the batch is solved again on the two-launches-per-step path
