@@ -415,7 +415,7 @@ struct PassEnv {
     int nstep;
     bool american, amp, xstep, f32;  // amp: P representation; xstep: this step runs on the explicit (U, lambda_bar) pair
     int col_prefetch;
-    bool cs_strips;                  // Craig-Sneyd row passes on strips where the plan chose strips (tuning key "cs_strips", default on)
+    int cs_strips;                   // Craig-Sneyd row passes on strips where the plan chose strips (tuning key "cs_strips", default on)
 };
 // Row pass of one time step.  mode: 0 Douglas, 1 / 2 Craig-Sneyd predictor / corrector.
 void launch_row_pass(const PassEnv &e, const HadiSweepArgs &ar, int mode) {
@@ -477,7 +477,7 @@ void launch_row_pass(const PassEnv &e, const HadiSweepArgs &ar, int mode) {
         }
         return;
     }
-    if (pl.use_strip && mode != 0 && !pl.use_pairs && e.cs_strips) {  // Craig-Sneyd predictor / corrector on strips (European, fp64)
+    if (pl.use_strip && mode != 0 && !pl.use_pairs && (e.cs_strips == 1 || e.cs_strips == 1 + mode)) {  // (2 / 3: diagnostics -- only the predictor / only the corrector on strips)  // Craig-Sneyd predictor / corrector on strips (European, fp64)
         const dim3 g(pl.grid_as), b(64 * HADI_STRIP_WAVES(L.B));
         if (L.G == 2) {
             if (mode == 1) hipLaunchKernelGGL((hadi_pass_a_strip<8, 0, double, 2, 1>), g, b, pl.smem_as, q, ar, nstep);
@@ -805,7 +805,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
                     hipLaunchKernelGGL(hadi_narrow_kernel, dim3(grid1d(tot)), dim3(256), 0, q, L, Ub, reinterpret_cast<float *>(a.U), tot);
             }
             if (prof) HIP_TRY(c, hipEventRecord(c->kev[ev0 + 4 * (nstep - 1) + 0], q));
-            const PassEnv env{pl, L, nsb, q, nstep, american, amp, xstep, f32, c->col_prefetch, c->cs_strips != 0};
+            const PassEnv env{pl, L, nsb, q, nstep, american, amp, xstep, f32, c->col_prefetch, c->cs_strips};
             auto row_pass = [&](const HadiSweepArgs &ar, int mode) { launch_row_pass(env, ar, mode); };
             auto col_pass = [&](const HadiSweepArgs &ar) { launch_col_pass(env, ar); };
             if (d.debug == 2) {  // diagnostics: one column solve of the packed input (moved to Y), nothing else
@@ -1519,7 +1519,7 @@ int hadi_set_tuning(hadi_ctx *ctx, const char *key, int value) {
     else if (!std::strcmp(key, "small_pairs")) c->small_pairs = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "streams")) c->streams = value == 2 ? 2 : (value == 1 ? 1 : 0);
     else if (!std::strcmp(key, "col_prefetch")) c->col_prefetch = value ? 1 : 0;
-    else if (!std::strcmp(key, "cs_strips")) c->cs_strips = value ? 1 : 0;
+    else if (!std::strcmp(key, "cs_strips")) c->cs_strips = (value >= 0 && value <= 3) ? value : 1;
     else if (!std::strcmp(key, "graph_max_melems")) c->graph_max_melems = value > 0 ? value : 0;
     else if (!std::strcmp(key, "tile_interleave")) c->tile_il = value ? 1 : 0;
     else if (!std::strcmp(key, "strip")) c->tune.strip = value < 0 ? -1 : (value ? 1 : 0);

@@ -58,55 +58,32 @@ HADI_DEV HADI_FORCEINLINE int hadi_flag_load(int *f) {
 #endif
 }
 
-// Craig-Sneyd corrector on strips: the R1 and C2 rows of a step are REGISTER loads, and they must not be the compiler's.
-// hipcc retires a load with `s_waitcnt vmcnt(k)`, k = the younger vector-memory operations IT knows of; the LDS-DMA
-// prefetch is inline asm, so its k would be too small by the DMA pieces in flight and every such wait would drain the
-// prefetch.  These loads are inline asm as well (the compiler sees values that are "ready" at once) and are retired by
-// the kernel's own counted wait before hadi_asm_block_take() hands the registers over -- the same bookkeeping as for the
-// ring rows: vector-memory operations of a wavefront retire in issue order.
-template <int B>
-struct HadiAsmBlock {
-#if defined(HADI_EMU)
-    double v[B], c0;
-#else
-    hadi_u32x4 q[B / 2];
-    hadi_u32x2 c0;
-#endif
-};
-// issues B / 2 + 1 vector loads: this lane's block of the row (hadi_get_block's pairs) and the row's i = 0 value
-template <int B, int G>
-HADI_DEV HADI_FORCEINLINE int hadi_asm_block_issue(const double *row, int half, int lane, HadiAsmBlock<B> &r) {
-#if defined(HADI_EMU)
-    hadi_get_block<B, G>(row, half, lane, r.v);
-    r.c0 = row[64 * B * G];
-#else
-#pragma unroll
-    for (int q = 0; q < B / 2; q++)
-        asm volatile("global_load_dwordx4 %0, %1, off" HADI_CS_POLICY : "=&v"(r.q[q]) : "v"(row + q * 128 * G + 128 * half + 2 * lane) : "memory");
-    asm volatile("global_load_dwordx2 %0, %1, off" HADI_CS_POLICY : "=&v"(r.c0) : "v"(row + 64 * B * G) : "memory");
-#endif
-    return B / 2 + 1;
-}
-#define HADI_ASM_BLOCK_LOADS(B) ((B) / 2 + 1)
-// call only behind the counted wait that retired the loads
-template <int B>
-HADI_DEV HADI_FORCEINLINE void hadi_asm_block_take(HadiAsmBlock<B> &r, double (&u)[B], double &c0) {
-#if defined(HADI_EMU)
-    for (int k = 0; k < B; k++) u[k] = r.v[k];
-    c0 = r.c0;
-#else
-#pragma unroll
-    for (int q = 0; q < B / 2; q++) {
-        asm volatile("" : "+v"(r.q[q]));  // (orders the reads below behind the wait, an asm volatile as well)
-        u[2 * q] = __hiloint2double((int)r.q[q].y, (int)r.q[q].x);
-        u[2 * q + 1] = __hiloint2double((int)r.q[q].w, (int)r.q[q].z);
-    }
-    asm volatile("" : "+v"(r.c0));
-    c0 = __hiloint2double((int)r.c0.y, (int)r.c0.x);
-#endif
-}
+// Craig-Sneyd corrector on strips: the R1 and C2 rows of a step are REGISTER loads -- ordinary loads of the compiler, on
+// purpose.  hipcc retires them with `s_waitcnt vmcnt(k)`, k = the younger vector-memory operations IT knows of (the row stores
+// of the step in between); the LDS-DMA prefetch is inline asm and not among them, so that wait also retires the DMA batch
+// issued between the loads and the stores: the corrector runs with ONE row of DMA prefetch in flight behind the landed ones
+// where the Douglas strips have two.  The first version of round 4 issued these loads from inline asm and retired them by the
+// kernel's own counted wait to keep that second row in flight -- and was wrong: registers with a load in flight are values the
+// compiler believes ready, and it moved copies of them (the operand set-up of the very asm that was to consume them) ABOVE
+// the wait.  Small tests passed (the data had landed by then); 256 instances of 512x256 gave garbage against the build whose
+// waits drain everything (tests/test_gpu_parity.py::test_craig_sneyd_on_strips_under_load_equals_full_drains, added first,
+// failing).  In-flight registers cannot be handed to a compiler that may copy them.
 template <int B>
 struct HadiCsRow { double r1[B], c2[B], r1c0, c2c0; };  // MODE 2: R1 and C2 of the step's row (block and i = 0 column)
+// the row's loads (non-temporal: hadi_get_block_nt); returns the number of vector-memory instructions (2 (B / 2 + 1))
+template <int B, int G>
+HADI_DEV HADI_FORCEINLINE int hadi_cs_row_load(const double *r1row, const double *c2row, int half, int lane, HadiCsRow<B> &o) {
+    hadi_get_block_nt<B, G>(r1row, half, lane, o.r1);
+    hadi_get_block_nt<B, G>(c2row, half, lane, o.c2);
+#if defined(HADI_EMU)
+    o.r1c0 = r1row[64 * B * G];
+    o.c2c0 = c2row[64 * B * G];
+#else
+    o.r1c0 = __builtin_nontemporal_load(r1row + 64 * B * G);
+    o.c2c0 = __builtin_nontemporal_load(c2row + 64 * B * G);
+#endif
+    return 2 * (B / 2 + 1);
+}
 
 // MODE 0: Douglas step.  MODE 1 / 2: predictor / corrector of Craig-Sneyd exactly as in hadi_row_step (solver.hpp:781-907):
 // MODE 1 is a Douglas row step that also stores R1 = Y1rhs - dt/2 A0U and C2; MODE 2 takes its rows from Y2, forms
@@ -521,9 +498,8 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
 // wait -- no wavefront ever reads ring data its partner fetched, except the one boundary node, see below).  LDS:
 // [4 pairs][NS slots][rowp] + 4 coefficient arrays of 1024 + the pairs' exchange buffers; with an fp64 state only NS = 3
 // slots fit the 160 KB (rows j+1, j+2 landed, j+3 in flight), with an fp32 state 4 as above.
-// MODE 1 / 2: predictor / corrector row pass of a Craig-Sneyd step (European, fp64 state).  The corrector's R1 and C2 rows
-// are register loads retired by this kernel's own counted waits (HadiAsmBlock): the row of step t + 1 is requested at the top
-// of step t, BEFORE that step's DMA, so that retiring it at the top of step t + 1 leaves the DMA batches of step t in flight.
+// MODE 1 / 2: predictor / corrector row pass of a Craig-Sneyd step (European, fp64 state).  The corrector's R1 and C2 rows are
+// ordinary register loads (hadi_cs_row_load): the row of step t + 1 is requested at the top of step t and used a step later.
 template <int B, int AMER, class T = double, int G = 1, int MODE = 0>
 #ifndef HADI_STRIP_OCC_B4
 #define HADI_STRIP_OCC_B4 2
@@ -637,11 +613,10 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
                 if (k + 2 < q) aft[k] += zq;
         }
     }
-    HadiAsmBlock<B> nr1, nc2;  // MODE 2: R1 / C2 of the NEXT step's row, in flight (the first row's: retired by the prologue's full wait)
+    HadiCsRow<B> cs_next;  // MODE 2: R1 / C2 of the NEXT step's row (requested a step ahead)
     if constexpr (MODE == 2) {
         const size_t ro = (size_t)(has_strip ? js : 0) * rowp;
-        hadi_asm_block_issue<B, G>(c.R1i + ro, half, lane, nr1);
-        hadi_asm_block_issue<B, G>(c.C2i + ro, half, lane, nc2);
+        hadi_cs_row_load<B, G>(c.R1i + ro, c.C2i + ro, half, lane, cs_next);
     }
     // rows behind by 2, behind by 1 (carried in the state's own type: with an fp32 state they are exact floats and cost
     // half the registers), current row (double: used throughout the step)
@@ -771,7 +746,6 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     c.stamp_acc_ = stamp_store_;
 #endif
     HADI_STAMP_DECL(c.stamp_acc_)
-    int regs_after = 0;  // MODE 2: vector-memory operations issued behind the register loads of the coming step's R1 / C2 rows
     for (int t = 0; t < cnt; t++) {
         const int j = js + dir * t;
         HADI_STAMPC(30);  // carry + loop
@@ -782,19 +756,20 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
         hadi_sload_issue(a.rowc + ((size_t)inst * nrows + j) * HADI_RC + HADI_SRC0, srow);  // flies during the DMA wait
         HadiCsRow<B> csrow;
         if constexpr (MODE == 2) {
-            // this step's R1 / C2 rows have landed once at most the operations issued behind them are in flight -- the DMA and
-            // the row stores of the step before; then the next row's are requested, ahead of this step's DMA
-            hadi_wait_vmcnt(regs_after);
-            hadi_asm_block_take<B>(nr1, csrow.r1, csrow.r1c0);
-            hadi_asm_block_take<B>(nc2, csrow.c2, csrow.c2c0);
+            csrow = cs_next;  // (the compiler's own wait for the loads of a step ago sits in front of their first use)
             int nl = 0;
+#if !defined(HADI_EMU)
+            asm volatile("" ::: "memory");  // the next row's loads stay HERE: behind the stores of the step before, ahead of this step's DMA
+#endif
             if (t + 1 < cnt) {
                 const size_t ro = (size_t)(j + dir) * rowp;
-                nl = hadi_asm_block_issue<B, G>(c.R1i + ro, half, lane, nr1) + hadi_asm_block_issue<B, G>(c.C2i + ro, half, lane, nc2);
+                nl = hadi_cs_row_load<B, G>(c.R1i + ro, c.C2i + ro, half, lane, cs_next);
             }
+#if !defined(HADI_EMU)
+            asm volatile("" ::: "memory");
+#endif
 #pragma unroll
-            for (int k = 0; k < NA; k++) aft[k] += nl;
-            regs_after = 0;
+            for (int k = 0; k < NA; k++) aft[k] += nl;  // (they come behind every DMA batch in flight)
         }
         hadi_wave_rendezvous();
         // the row D ahead goes to the slot of row j (of row j - 1 when one slot is kept behind): that row is in registers,
@@ -802,7 +777,6 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
         // wait below, so that the prefetch does not queue behind it.
         int z = 0;
         if (t + D <= cnt + 1) z = fetch(j + D * dir);
-        regs_after += z;
         hadi_wait_vmcnt(aft[0] + z);  // the row two ahead has landed (the row one ahead landed a step earlier)
         HADI_STAMPC(24);  // wait for the DMA
 #pragma unroll
@@ -872,7 +846,6 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
         constexpr int NST = (MODE == 1 ? 3 : 1) * hadi_put_block_stores<B, T>();
 #pragma unroll
         for (int k = 0; k < NA; k++) aft[k] += NST;
-        regs_after += NST;
         double enew = 0.0;
         if constexpr (G > 1) {
             // The partner's boundary node of the row TWO ahead, from the partner's half of the ring slot.  Safe here and only

@@ -185,7 +185,7 @@ def test_craig_sneyd_predictor_corrector(emu):
 
 def test_craig_sneyd_on_barrier_free_strips(emu):
     """Round 4: predictor (MODE 1: the Douglas strip step that also stores R1 and C2) and corrector (MODE 2: rows of Y2
-    through the ring, the R1 / C2 rows of each step as register loads retired by the kernel's own counted waits) on
+    through the ring, the R1 / C2 rows of each step as register loads requested a step ahead) on
     hadi_pass_a_strip at 2, 4 and 8 nodes per lane and on paired strips (m1 > 512); strips with and without a partner,
     descending and ascending, the b2 row, r_f != 0 (b1 along the anti-diagonal), several instances.  The emulator checks
     arithmetic and indexing; the waits are what libhadi_strict.so checks on hardware."""

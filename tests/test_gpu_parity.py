@@ -698,7 +698,7 @@ def test_craig_sneyd_on_strips_vs_oracle_ring_and_full_drains(solver, strict_sol
     """Round 4: predictor and corrector row passes of a Craig-Sneyd step on the barrier-free strips (2, 4, 8 nodes per lane,
     paired strips above 512 s-intervals).  Full field against the oracle; against the shared-ring kernels (tuning key
     `cs_strips` = 0: the path of rounds 2 - 3) to round-off; and bit for bit against libhadi_strict.so, whose waits drain
-    everything -- the corrector retires the register loads of its R1 / C2 rows by hand-counted waits."""
+    everything."""
     strikes = Cm.strikes_for(n)
     grids, U0 = _batch(m1, m2, strikes)
     args = (m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids)
@@ -725,6 +725,27 @@ def test_craig_sneyd_on_strips_vs_oracle_ring_and_full_drains(solver, strict_sol
     finally:
         strict_solver.set_tuning("strip", -1)
     assert np.array_equal(U, Us)
+
+
+def test_craig_sneyd_on_strips_under_load_equals_full_drains(solver, strict_solver):
+    """Counted waits are a statement about ISSUE ORDER; whether a wrong one shows depends on how late the memory system answers.
+    A batch that fills the chip (256 instances of 512x256: the plan picks the strips by itself) over 60 time steps -- 120
+    predictor and 120 corrector launches with every CU streaming -- must equal the build whose waits drain everything, bit for
+    bit, on every instance.  (This test was written before the first strip corrector was trusted, and failed: that version
+    loaded its R1 / C2 rows from inline asm and the compiler moved copies of the in-flight registers above the wait -- every
+    small test passed.  DESIGN.md section 4.2.)"""
+    m1, m2, N, n = 512, 256, 60, 256
+    strikes = Cm.strikes_for(n)
+    grids, U0 = _batch(m1, m2, strikes)
+    args = (m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids)
+    U, Us = U0.copy(), U0.copy()
+    solver.CS_scheme(*args, U)
+    d = solver.describe_last_sweep()
+    assert "hadi_pass_a_strip<8,EU,double,1,CS>" in d, d
+    strict_solver.CS_scheme(*args, Us)
+    assert strict_solver.describe_last_sweep() == d
+    assert np.array_equal(U, Us)
+    assert np.isfinite(U).all() and np.abs(U).max() < 1e4
 
 
 def test_strips_chosen_by_themselves_at_two_nodes_per_lane(solver):
