@@ -727,6 +727,51 @@ def test_craig_sneyd_on_strips_vs_oracle_ring_and_full_drains(solver, strict_sol
     assert np.array_equal(U, Us)
 
 
+LOAD_CASES = [  # (m1, m2, N, n, variant, tuning, fp32, kernel expected in the description)
+    (512, 256, 20, 256, H.EU, {}, False, "hadi_pass_a_strip<8,EU>"),                    # config 2 as benchmarked
+    (512, 256, 12, 256, H.AM, {}, False, "hadi_pass_a_strip<8,AM-P>"),                  # P representation on strips
+    (512, 256, 12, 256, H.AM, {"american_p": 0}, False, "hadi_pass_a_strip<8,AM>"),     # explicit (U, lambda_bar) pair
+    (512, 256, 12, 160, H.EU, {}, False, "two streams"),                               # two half-batches side by side
+    (512, 256, 12, 48, H.EU, {"strip": 0}, False, "hadi_pass_a<8,1"),                   # shared ring
+    (256, 128, 25, 512, H.AM_DIV, {}, False, "hadi_pass_a_pairs<AM-P>"),                # config 3 as benchmarked
+    (256, 128, 12, 300, H.EU, {"strip": 1, "pair_strips": 0}, False, "hadi_pass_a_strip<4,EU>"),
+    (128, 64, 12, 1100, H.EU, {}, False, "hadi_pass_a_strip<2,EU>"),
+    (1024, 512, 8, 64, H.EU, {}, False, "hadi_pass_a_strip<8,EU,double,2>"),            # config 5, fp64 state
+    (1024, 512, 8, 64, H.EU, {}, True, "hadi_pass_a_strip<8,EU,float,2>"),              # config 5, fp32 state
+    (1024, 512, 6, 64, H.AM, {}, False, "hadi_pass_a_strip<8,AM-P,double,2>"),
+]
+
+
+@pytest.mark.parametrize("m1,m2,N,n,variant,tuning,fp32,kernel", LOAD_CASES)
+def test_counted_waits_under_load_equal_full_drains(solver, strict_solver, m1, m2, N, n, variant, tuning, fp32, kernel):
+    """test_counted_vmcnt_waits_equal_full_drains (below) compares the two builds on two or three instances -- where every
+    load has landed long before it is waited for.  The defect of round 4's first strip corrector only showed with every CU
+    streaming; so the same comparison at the benchmarked batch geometries: every row-pass family with counted waits, bit for
+    bit against the build that drains everything."""
+    strikes = Cm.strikes_for(n)
+    grids, U0 = _batch(m1, m2, strikes)
+    res = []
+    reset = {"strip": -1, "american_p": 1, "pair_strips": -1}
+    for sv in (solver, strict_solver):
+        for k, v in tuning.items():
+            sv.set_tuning(k, v)
+        try:
+            U, lam = U0.copy(), np.zeros_like(U0)
+            american = variant in (H.AM, H.AM_DIV)
+            sv.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.01, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U,
+                               variant=variant, U_0=U0, lambda_bar=lam if american else None,
+                               dividends=H.Dividends(*Cm.DIVS) if variant in (H.DIV, H.AM_DIV) else None,
+                               state_precision=H.STATE_FP32 if fp32 else H.STATE_FP64)
+        finally:
+            for k in tuning:
+                sv.set_tuning(k, reset[k])
+        res.append((U, lam, sv.describe_last_sweep()))
+    assert kernel in res[0][2], res[0][2]
+    assert res[0][2] == res[1][2]
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert np.isfinite(res[0][0]).all()
+
+
 def test_craig_sneyd_on_strips_under_load_equals_full_drains(solver, strict_solver):
     """Counted waits are a statement about ISSUE ORDER; whether a wrong one shows depends on how late the memory system answers.
     A batch that fills the chip (256 instances of 512x256: the plan picks the strips by itself) over 60 time steps -- 120
