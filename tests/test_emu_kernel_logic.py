@@ -514,7 +514,20 @@ def test_pair_strips_two_strips_per_wavefront(emu):
 def _random_case(rng):
     """One random problem for the emulator sweep below: shape class, variant, scheme and the kernel-selection overrides the
     library's own tuning keys offer (the generator of tools/fuzz_parity.py is frozen; this one is the emulator's own)."""
-    cls = rng.choice(["one", "two", "four", "eight", "wide", "seq_row", "seq_col", "tall"])
+    cls = rng.choice(["one", "two", "four", "eight", "wide", "seq_row", "seq_col", "tall", "lds", "team"])
+    if cls == "lds":   # LDS-resident kernels: 4 or 8 wavefronts per instance, one wavefront per instance (pair of instances)
+        variant = rng.choice([O.EU, O.AM, O.DIV, O.AM_DIV])
+        small = rng.choice([1, 2]) if variant in (O.AM, O.AM_DIV) else rng.choice([1, 2, 3, 5])
+        n = rng.choice([1, 2, 3])
+        return dict(m1=rng.randint(8, 128), m2=rng.randint(4, 31), N=rng.randint(1, 3) if variant in (O.EU, O.AM) else rng.randint(4, 7),
+                    strikes=[rng.uniform(85, 115) for _ in range(n)], variant=variant, scheme=0, put=rng.random() < 0.3,
+                    r_f=rng.choice([0.0, 0.01, 0.03]), target_waves=8, tuning={}, small=small)
+    if cls == "team":  # instance-resident launch: teams of 1, 2 or 4 blocks (all blocks of the grid at once)
+        variant = rng.choice([O.EU, O.DIV])
+        n = rng.choice([1, 2, 3])
+        return dict(m1=rng.randint(129, 512), m2=rng.choice([rng.randint(8, 60), rng.randint(61, 263)]), N=rng.randint(1, 3) if variant == O.EU else rng.randint(4, 7),
+                    strikes=[rng.uniform(85, 115) for _ in range(n)], variant=variant, scheme=0, put=rng.random() < 0.3,
+                    r_f=rng.choice([0.0, 0.01, 0.03]), target_waves=8, tuning={"team_blocks": rng.choice([1, 2, 4])}, small=4)
     m1 = {"one": rng.randint(8, 64), "two": rng.randint(65, 128), "four": rng.randint(129, 256), "eight": rng.randint(257, 512),
           "wide": rng.randint(513, 1024), "seq_row": rng.randint(1025, 1100), "seq_col": rng.randint(20, 200),
           "tall": rng.randint(20, 140)}[cls]
@@ -537,14 +550,14 @@ def _random_case(rng):
     n = rng.choice([1, 1, 2, 3])
     N = rng.randint(1, 3) if variant in (O.EU, O.AM) else rng.randint(4, 7)   # (the dividends land on steps 2 .. 6)
     return dict(m1=m1, m2=m2, N=N, strikes=[rng.uniform(85, 115) for _ in range(n)], variant=variant, scheme=scheme, put=put,
-                r_f=rng.choice([0.0, 0.01, 0.03]), target_waves=rng.choice([1, 8]), tuning=tuning)
+                r_f=rng.choice([0.0, 0.01, 0.03]), target_waves=rng.choice([1, 8]), tuning=tuning, small=0)
 
 
 @pytest.mark.parametrize("seed", range(8))
 def test_random_shapes_and_kernel_choices_vs_oracle(emu, seed):
     """Since the emulator runs a wavefront's lanes as fibers (round 4) a sweep costs tenths of a second: 8 x 30 random problems
     -- every shape class (1 .. 8 nodes per lane, two wavefronts per row, the sequential passes beyond 1024 / 527 intervals,
-    9 .. 16 column chunks), the four variants, Craig-Sneyd, the fp32 state, the P representation, put data, forced strips /
+    9 .. 16 column chunks, the LDS-resident kernels, the instance-resident launch with teams of 1 / 2 / 4 blocks), the four variants, Craig-Sneyd, the fp32 state, the P representation, put data, forced strips /
     pair strips / several blocks per instance / column-pass alternatives -- each against the oracle's full field."""
     import random
     rng = random.Random(1000 + seed)
@@ -562,7 +575,7 @@ def test_random_shapes_and_kernel_choices_vs_oracle(emu, seed):
             assert emu.emu_set_tuning(key.encode(), val) == 0
         try:
             _run(emu, c["m1"], c["m2"], c["N"], c["strikes"], c["variant"], c["target_waves"], r_f=c["r_f"], scheme=c["scheme"], put=c["put"],
-                 tol=1e-10)  # (the bound of the GPU parity tests)
+                 small=c["small"], tol=1e-10)  # (the bound of the GPU parity tests)
         except AssertionError as e:
             raise AssertionError("seed %d case %d: %r" % (seed, k, c)) from e
         finally:
