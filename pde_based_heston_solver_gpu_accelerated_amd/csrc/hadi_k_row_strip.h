@@ -911,6 +911,25 @@ HADI_DEV HADI_FORCEINLINE void hadi_pair_get(const double *p, int ch1, double (&
     const double2 c = *reinterpret_cast<const double2 *>(p + ch1), d = *reinterpret_cast<const double2 *>(p + ch1 + 2);
     u[0] = a.x; u[1] = a.y; u[4] = b.x; u[5] = b.y; u[2] = c.x; u[3] = c.y; u[6] = d.x; u[7] = d.y;
 }
+// The same from LDS, where the two 16-byte pieces of a chunk are SWAPPED for the lanes 8 .. 15 of every 16 (round 4).  A lane's
+// chunk is 32 bytes, so 16 lanes reading "the first 16 bytes of my chunk" touch every other 16-byte bank group of two 256-byte
+// bank rows: a 2-way conflict on every ds_read_b128 of this kernel (SQ_LDS_BANK_CONFLICT 5.0 M cycles per dispatch on config
+// 3, as many as the reads themselves).  With the pieces of the upper eight lanes swapped in the LDS image, "first piece" reads
+// hit the even groups in lanes 0 .. 7 and the odd groups in lanes 8 .. 15 -- all 16 distinct.  The image is swizzled where it
+// is WRITTEN (the LDS-DMA's lane -> LDS position is fixed, its source address is not; the coefficient / payoff copies permute
+// their index); the readers use two per-lane offsets instead of one offset and a constant.  offA / offB: where this lane's
+// first / second piece sits (hadi_pair_offs).
+HADI_DEV HADI_FORCEINLINE int hadi_pair_swz(int e) { return e ^ (((e >> 5) & 1) << 1); }  // position of element e (doubles) in a swizzled image
+HADI_DEV HADI_FORCEINLINE void hadi_pair_offs(int h, int chunk, int &offA, int &offB) {
+    const int s2 = (h & 8) ? 2 : 0;
+    offA = chunk + s2;
+    offB = chunk + 2 - s2;
+}
+HADI_DEV HADI_FORCEINLINE void hadi_pair_get_lds(const double *base, int offA, int offB, int ch1, double (&u)[8]) {
+    const double2 a = *reinterpret_cast<const double2 *>(base + offA), b = *reinterpret_cast<const double2 *>(base + offB);
+    const double2 c = *reinterpret_cast<const double2 *>(base + offA + ch1), d = *reinterpret_cast<const double2 *>(base + offB + ch1);
+    u[0] = a.x; u[1] = a.y; u[4] = b.x; u[5] = b.y; u[2] = c.x; u[3] = c.y; u[6] = d.x; u[7] = d.y;
+}
 HADI_DEV HADI_FORCEINLINE void hadi_pair_put(double *p, const double (&u)[8]) {  // global row: the chunks are 128 doubles apart
     double2 a, b, c, d;
     a.x = u[0]; a.y = u[1]; b.x = u[4]; b.y = u[5]; c.x = u[2]; c.y = u[3]; d.x = u[6]; d.y = u[7];
@@ -921,18 +940,20 @@ HADI_DEV HADI_FORCEINLINE void hadi_pair_put(double *p, const double (&u)[8]) { 
 HADI_DEV HADI_FORCEINLINE void hadi_pair_fetch(const double *__restrict__ grow, double *slot, int lane) {
     const int H = lane >> 5, h = lane & 31;
 #if defined(HADI_EMU)
+    const int hs = h ^ (h >= 16 ? 1 : 0);  // (the piece this lane fetches: hadi_pair_get_lds)
     for (int pc = 0; pc < 4; pc++)
-        for (int e = 0; e < 2; e++) slot[pc * 128 + H * 64 + 2 * h + e] = grow[64 * pc + 2 * h + e];
+        for (int e = 0; e < 2; e++) slot[pc * 128 + H * 64 + 2 * h + e] = grow[64 * pc + 2 * hs + e];
     if (h < 8)
         for (int e = 0; e < 2; e++) slot[512 + 16 * H + 2 * h + e] = grow[256 + 2 * h + e];
 #else
-    const double *gsrc = grow + 2 * h;
+    const double *gsrc = grow + 2 * h;                        // (the tails: not swizzled)
+    const double *gswz = grow + 2 * (h ^ (h >= 16 ? 1 : 0));  // the piece this lane fetches: hadi_pair_get_lds
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)slot);
 #pragma unroll
     for (int pc = 0; pc < 4; pc++) {
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" HADI_DMA_POLICY "\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(gsrc + 64 * pc), "s"(lds0 + 1024u * pc) : "memory");
+                     : "=&s"(keep) : "v"(gswz + 64 * pc), "s"(lds0 + 1024u * pc) : "memory");
     }
     // the 128-byte tails (slot 256 = i = 0 and the pads): half A to bytes 4096.., half B right behind it (the hardware adds
     // 16 x lane to M0: 512 for lane 32, hence the base 4096 + 128 - 512)
@@ -957,8 +978,9 @@ template <int AMER, bool LAST>
 HADI_DEV HADI_FORCEINLINE void hadi_pair_step(const HadiStripCtxT<double> &c, int h, bool act, bool is_last, const double (&rv)[HADI_RCL],
                                               const double (&um2)[8], const double (&um1)[8], const double (&u0)[8],
                                               const double (&up1)[8], const double (&up2)[8], double c0m2, double c0m1, double c00,
-                                              double c0p1, double c0p2, double lamc0_in, const double *raw_chunk,
-                                              const double *next_chunk, double (&u_next)[8], double *yrow, const double *lrow) {
+                                              double c0p1, double c0p2, double lamc0_in, const double *raw_slot,
+                                              const double *next_slot, int offA, int offB, double (&u_next)[8], double *yrow,
+                                              const double *lrow) {
     constexpr int B = 8, NB = 7, c0slot = 256;
     const int lane = c.lane;
     const bool first = (h == 0);
@@ -1009,7 +1031,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_pair_step(const HadiStripCtxT<double> &c, in
     if constexpr (AMER == 1) hadi_pair_get(lrow + 4 * h, 128, lam);
     if constexpr (AMER == 2) {
         double praw[B];
-        hadi_pair_get(raw_chunk, 256, praw);  // the raw P of row j, still intact in its ring slot
+        hadi_pair_get_lds(raw_slot, offA, offB, 256, praw);  // the raw P of row j, still intact in its ring slot
 #pragma unroll
         for (int r = 0; r < B; r++) {
             lam[r] = (u0[r] - praw[r]) * c.inv_dt;  // exactly max(0, (U_0 - P) / dt): U = max(P, U_0)
@@ -1026,14 +1048,17 @@ HADI_DEV HADI_FORCEINLINE void hadi_pair_step(const HadiStripCtxT<double> &c, in
     double Bm[B], Bp[B], Dm[B], Dp[B];
     double ys[B], ps[B], gs[B], iu[B], cp[B];
     double il_last = 0.0, im_last = 1.0, d_last = 0.0;
+    int cA, cB;
+    hadi_pair_offs(h, 4 * h, cA, cB);
 #pragma unroll
     for (int r = 0; r < B; r++) {
         if ((r & 3) == 0 || (r & 3) == 2) {
 #if !defined(HADI_EMU)
             asm volatile("" ::: "memory");
 #endif
-            // nodes {0,1,4,5} sit in the lane's first chunk, {2,3,6,7} in the second (128 doubles on)
-            const int co = 4 * h + ((r & 2) ? 128 : 0) + ((r & 4) ? 2 : 0);
+            // nodes {0,1,4,5} sit in the lane's first chunk, {2,3,6,7} in the second (128 doubles on); the coefficient arrays
+            // are swizzled images too (hadi_pair_get_lds)
+            const int co = ((r & 4) ? cB : cA) + ((r & 2) ? 128 : 0);
             const double2 t0 = *reinterpret_cast<const double2 *>(c.coef + 0 * 256 + co);
             const double2 t1 = *reinterpret_cast<const double2 *>(c.coef + 1 * 256 + co);
             const double2 t2 = *reinterpret_cast<const double2 *>(c.coef + 2 * 256 + co);
@@ -1127,7 +1152,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_pair_step(const HadiStripCtxT<double> &c, in
         }
     }
     hadi_set_prio(0);
-    hadi_pair_get(next_chunk, 256, u_next);  // the row ahead again from its ring slot (flies during the stores)
+    hadi_pair_get_lds(next_slot, offA, offB, 256, u_next);  // the row ahead again from its ring slot (flies during the stores)
     const double X = rf, XL = hadi_lane_prev(X);  // (lane 32: lane 31's X, times ps = 0)
     double yo[B];
 #pragma unroll
@@ -1200,6 +1225,9 @@ __global__ void __launch_bounds__(64 * HADI_PAIR_WAVES, 2) hadi_pass_a_pairs(Had
     auto grow = [&](int jj) { return Ub + (size_t)(jj < 0 ? 0 : (jj >= nrows ? nrows - 1 : jj)) * ROWP; };
     auto slot = [&](int q) { return ring + (size_t)(((q % NS) + NS) % NS) * HADI_PAIR_SLOT; };  // q = step index of the row (any sign)
     const int chunk_off = (h >> 4) * 128 + H * 64 + (h & 15) * 4;  // this lane's first chunk inside a slot (doubles)
+    int offA, offB, payA, payB;                                    // ... and where its two pieces sit in the swizzled images
+    hadi_pair_offs(h, chunk_off, offA, offB);
+    hadi_pair_offs(h, 4 * h, payA, payB);
     const int c0_off = 512 + 16 * H;
     const double *__restrict__ rtab = a.rowc + (size_t)inst * nrows * HADI_RC + HADI_SRC0;
     auto clampj = [&](int jj) { return jj < 0 ? 0 : (jj >= nrows ? nrows - 1 : jj); };
@@ -1257,12 +1285,12 @@ __global__ void __launch_bounds__(64 * HADI_PAIR_WAVES, 2) hadi_pass_a_pairs(Had
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int e = threadIdx.x + q * 64 * NWV;
-            coef[e] = (e < 2 * 256) ? mq * sc_tmp[q] : sc_tmp[q];
+            coef[hadi_pair_swz(e)] = (e < 2 * 256) ? mq * sc_tmp[q] : sc_tmp[q];
         }
     }
     if constexpr (AMER == 2) {
         const double *__restrict__ pg = a.U0 + (size_t)inst * a.L.inst_stride;
-        for (int e = threadIdx.x; e < ROWP; e += 64 * NWV) payl[e] = pg[e];
+        for (int e = threadIdx.x; e < ROWP; e += 64 * NWV) payl[e < 256 ? hadi_pair_swz(e) : e] = pg[e];
     }
     __syncthreads();
     if (cntA == 0) return;
@@ -1272,17 +1300,17 @@ __global__ void __launch_bounds__(64 * HADI_PAIR_WAVES, 2) hadi_pass_a_pairs(Had
         // consumed loads that were issued behind them (the wait is spelled out all the same).
         hadi_wait_vmcnt(0);
         hadi_wave_rendezvous();
-        const int other_off = chunk_off ^ 64;  // (the half index is bit 6 of the offset)
-        hadi_pair_get(slot(0) + chunk_off, 256, u0);
-        hadi_pair_get(slot(0) + other_off, 256, um1);
-        hadi_pair_get(slot(1) + other_off, 256, um2);
+        // (the other half's chunk: the half index is bit 6 of the offsets)
+        hadi_pair_get_lds(slot(0), offA, offB, 256, u0);
+        hadi_pair_get_lds(slot(0), offA ^ 64, offB ^ 64, 256, um1);
+        hadi_pair_get_lds(slot(1), offA ^ 64, offB ^ 64, 256, um2);
 #if !defined(HADI_EMU)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // retired before the loop's first fetch reuses slot 0
 #endif
     }
     if constexpr (AMER == 2) {  // U = max(P, U_0) on the rows behind
         double pay[8];
-        hadi_pair_get(payl + 4 * h, 128, pay);
+        hadi_pair_get_lds(payl, payA, payB, 128, pay);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             um2[r] = fmax(um2[r], pay[r]);
@@ -1313,8 +1341,8 @@ __global__ void __launch_bounds__(64 * HADI_PAIR_WAVES, 2) hadi_pass_a_pairs(Had
         if (NA > 0) aft[NA - 1] = 0;
         hadi_wave_rendezvous();
         double up1[8], up2[8];
-        hadi_pair_get(slot(t + 1) + chunk_off, 256, up1);
-        hadi_pair_get(slot(t + 2) + chunk_off, 256, up2);
+        hadi_pair_get_lds(slot(t + 1), offA, offB, 256, up1);
+        hadi_pair_get_lds(slot(t + 2), offA, offB, 256, up2);
         const double c0p2r = slot(t + 2)[c0_off];
         const double c0m2r = hist[(t + 2) & 3], c0m1r = hist[(t + 3) & 3], c00r = hist[t & 3], c0p1r = hist[(t + 1) & 3];
         double rvs[HADI_RCL];
@@ -1344,7 +1372,7 @@ __global__ void __launch_bounds__(64 * HADI_PAIR_WAVES, 2) hadi_pass_a_pairs(Had
         double e0m2 = c0m2r, e0m1 = c0m1r, e00 = c00r, e0p1 = c0p1r, e0p2 = c0p2r, lamc0 = 0.0;
         if constexpr (AMER == 2) {
             double pay[8];
-            hadi_pair_get(payl + 4 * h, 128, pay);
+            hadi_pair_get_lds(payl, payA, payB, 128, pay);
             const double pay_c0 = payl[c0slot];
 #pragma unroll
             for (int r = 0; r < 8; r++) {
@@ -1366,7 +1394,7 @@ __global__ void __launch_bounds__(64 * HADI_PAIR_WAVES, 2) hadi_pass_a_pairs(Had
         // A: 244 live registers in A against 146 in B, 44 - 60 of them spilled into the row loop, 2.4x slower than the kernel
         // it was to replace (tools/experiments/README.md).
         hadi_pair_step<AMER, true>(c, h, act, is_last, rvs, um2, um1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, lamc0,
-                                   slot(t) + chunk_off, slot(t + 1) + chunk_off, un, yrow, lrow);
+                                   slot(t), slot(t + 1), offA, offB, un, yrow, lrow);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             um2[r] = um1[r];
