@@ -512,7 +512,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_row_step(const HadiRowCtxT<T> &c, bool activ
         if constexpr (G > 1) {
             const double A = c.xch[8 * c.wrow + 0], Bc = c.xch[8 * c.wrow + 1];
             const double Cc = c.xch[8 * c.wrow + 2], Dd = c.xch[8 * c.wrow + 3];
-            const double xhi = (A - Bc * Cc) / (1.0 - Bc * Dd);  // last node of the low half
+            const double xhi = (A - Bc * Cc) * hadi_rcp(1.0 - Bc * Dd);  // last node of the low half (reciprocal + Newton step as in the line solves: the IEEE division sequence is 12 dependent instructions on the pair's critical path)
             const double tlo = Cc - Dd * xhi;                    // first node of the high half
             X = Ysol - (first_half ? tlo : xhi) * Ssol;
             XL = hadi_lane_prev(X);

@@ -454,7 +454,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
         }
         if (guard >= polls && lane == 0) hadi_report(c.err, HADI_DEVERR_RENDEZVOUS);
         const double A = xb[0], Bc = xb[1], Cc = xb[2], Dd = xb[3];
-        const double xhi = (A - Bc * Cc) / (1.0 - Bc * Dd);  // last node of the low half
+        const double xhi = (A - Bc * Cc) * hadi_rcp(1.0 - Bc * Dd);  // last node of the low half (reciprocal + Newton step as in the line solves: the IEEE division sequence is 12 dependent instructions on the pair's critical path)
         const double tlo = Cc - Dd * xhi;                    // first node of the high half
         X = rf - (first_half ? tlo : xhi) * rs;
         XL = hadi_lane_prev(X);
