@@ -36,6 +36,7 @@ struct Ctx {
     // grow-only device buffers
     DevBuf U, Y, LAM, U0, UT;
     DevBuf V, R1, C2;                 // Craig-Sneyd: predictor result and carry-over arrays
+    DevBuf rs_tab;                    // paired strips: the pairs' coupling column behind the cyclic reduction, per (instance, v-row, half, lane)
     DevBuf Uf, Yf;                    // fp32-state sweep: the two state arrays as float
     DevBuf scoef, b2row, rowc, a2i, pb, rinv, rwork, ipar, par8;
     DevBuf g_s, g_v, g_ds, g_dv;      // grids owned by the library (staged / broadcast)
@@ -636,6 +637,8 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     if (f32 && ((rc = ensure(c, c->Uf, st / 2)) || (rc = ensure(c, c->Yf, st / 2)))) return rc;
     if (cs && ((rc = ensure(c, c->V, st)) || (rc = ensure(c, c->R1, st)) || (rc = ensure(c, c->C2, st)))) return rc;
     if (pl.row_seq && (rc = ensure(c, c->R1, st))) return rc;  // (hadi_pass_a_seq parks the Thomas multipliers there)
+    const bool pair_tab = L.G == 2 && !cs && !pl.row_seq;  // paired strips (Douglas steps) take the pairs' coupling column from a table built once per solve
+    if (pair_tab && (rc = ensure(c, c->rs_tab, (size_t)d.n * L.nrows * 128 * 8))) return rc;
     const size_t n = d.n;
     if ((rc = ensure(c, c->scoef, pl.n_scoef * n * 8))) return rc;
     if ((rc = ensure(c, c->b2row, pl.n_b2row * n * 8))) return rc;
@@ -733,6 +736,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
     a.err = c->err_dev; a.debug = c->debug_fault;
     a.R1 = (cs || pl.row_seq) ? ptr<double>(c->R1) : nullptr;
     a.C2 = cs ? ptr<double>(c->C2) : nullptr;
+    a.rs_tab = pair_tab ? ptr<double>(c->rs_tab) : nullptr;
     // Craig-Sneyd: the predictor's column pass writes V (= Y2), the corrector's row pass reads V
     HadiSweepArgs av = a;
     if (cs) av.U = ptr<double>(c->V);
@@ -764,6 +768,7 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         if (x.pay_mis) x.pay_mis += o;
         if (x.R1) x.R1 += so;
         if (x.C2) x.C2 += so;
+        if (x.rs_tab) x.rs_tab += (size_t)o * L.nrows * 128;
         x.scoef += (size_t)o * pl.n_scoef; x.b2row += (size_t)o * pl.n_b2row; x.rowc += (size_t)o * pl.n_rowc;
         x.pb += (size_t)o * pl.n_pb; x.rinv += (size_t)o * pl.n_rinv; x.ipar += o;
         return x;
@@ -787,6 +792,13 @@ int run_sweep(Ctx *c, const SweepDesc &d, HadiPlan &pl) {
         double *const Ub = ptr<double>(c->U) + so, *const LAMb = american ? ptr<double>(c->LAM) + so : nullptr;
         double *const U0b = american ? ptr<double>(c->U0) + so : nullptr, *const UTb = dividend ? ptr<double>(c->UT) + so : nullptr;
         const int ev0 = 4 * sb * d.Nmax;  // profiling events of this sub-batch
+        if (pair_tab && pl.use_strip) {  // paired strips: the pairs' coupling column, once per solve (hadi_strip_step, RSTAB)
+            HadiSweepArgs at = a;
+            at.U = Ub;  // (any packed fp64 array: the table depends on the matrix only)
+            // (its own LDS size: the fp64 ring of 4 pairs x 3 slots, whatever the state precision of the sweep -- hadi_plan.h)
+            const size_t sm = (size_t)4 * HADI_STRIP_NS(8, 2, 8) * L.rowp * sizeof(double) + ((size_t)4 * 64 * 8 * 2 + (size_t)4 * 16) * sizeof(double);
+            hipLaunchKernelGGL((hadi_pass_a_strip<8, 0, double, 2, 3>), dim3(pl.grid_as), dim3(512), sm, q, at, 1);
+        }
         for (int nstep = n_first; nstep <= n_last; nstep++) {
             // P representation: the first step (the caller's initial U need not dominate the payoff) and dividend steps
             // (the jump acts on U alone) run on the explicit (U, lambda_bar) pair, converted on the way in and out

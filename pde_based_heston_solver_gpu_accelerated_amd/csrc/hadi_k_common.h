@@ -8,6 +8,7 @@ struct HadiSweepArgs {
     double *Y;         // A2 right-hand side between the passes
     double *LAM;       // lambda_bar (American) or nullptr
     double *R1, *C2;   // Craig-Sneyd only: predictor quantities reused by the corrector (see hadi_row_step)
+    double *rs_tab;    // paired strips only: [inst][v-row][half][lane] -- the cyclic-reduction image of the pair's coupling column (hadi_strip_step, RSTAB)
     const double *U0;  // payoff (American) or nullptr
     const int *pay_mis;  // American: per instance, != 0 if the payoff differs between v-rows (0 = it depends on s only)
     // tables

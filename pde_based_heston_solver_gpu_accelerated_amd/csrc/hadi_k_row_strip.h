@@ -68,6 +68,13 @@ HADI_DEV HADI_FORCEINLINE int hadi_flag_load(int *f) {
 // the wait.  Small tests passed (the data had landed by then); 256 instances of 512x256 gave garbage against the build whose
 // waits drain everything (tests/test_gpu_parity.py::test_craig_sneyd_on_strips_under_load_equals_full_drains, added first,
 // failing).  In-flight registers cannot be handed to a compiler that may copy them.
+HADI_DEV HADI_FORCEINLINE double hadi_nt_load(const double *p) {
+#if defined(HADI_EMU)
+    return *p;
+#else
+    return __builtin_nontemporal_load(p);
+#endif
+}
 template <int B>
 struct HadiCsRow { double r1[B], c2[B], r1c0, c2c0; };  // MODE 2: R1 and C2 of the step's row (block and i = 0 column)
 // the row's loads (non-temporal: hadi_get_block_nt); returns the number of vector-memory instructions (2 (B / 2 + 1))
@@ -96,7 +103,13 @@ HADI_DEV HADI_FORCEINLINE int hadi_cs_row_load(const double *r1row, const double
 // the values, on the rows behind / at / ahead of j, of the one node next to this half that belongs to the partner; the
 // tridiagonal system is split at the boundary exactly as in hadi_row_step (second right-hand side through the cyclic
 // reduction, 2x2 system exchanged through LDS), with a rendezvous of the two wavefronts only.
-template <int B, int AMER, bool LAST, class T = double, int G = 1, int CREG = 0, int MODE = 0>
+// RSTAB (paired strips, round 4): the second right-hand side of a pair's half-row system -- its coupling column, carried through
+// the six levels of the cyclic reduction next to the real right-hand side -- depends on the MATRIX only: on the instance, the
+// v-row and the half, not on the time step.  It is computed once per solve (MODE 3: this step with nothing but that column;
+// the result, one double per lane, goes to rs_tab) and every later step takes it from there (rs_in, loaded by the caller a
+// step ahead): 18 cross-lane fetches and ~25 operations per row and wavefront less in the reduction (the 1024x512 row pass
+// -6 % with the updates compiled out; profiles/r04_pair_spike_ab.txt).
+template <int B, int AMER, bool LAST, class T = double, int G = 1, int CREG = 0, int MODE = 0, bool RSTAB = false>
 HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j, const double (&rt)[HADI_RCL],
                                                const double (&um2)[B], const double (&um1)[B], const double (&u0)[B],
                                                const double (&up1)[B], const double (&up2)[B], double c0m2, double c0m1,
@@ -104,9 +117,11 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
                                                double lamc0_in, const T *next_row, double (&u_next)[B],
                                                double eb = 0.0, double e0 = 0.0, double ea = 0.0, const T *raw_row = nullptr,
                                                const double *pay_row = nullptr, const double *cf = nullptr,
-                                               const HadiCsRow<B> *cs = nullptr) {
+                                               const HadiCsRow<B> *cs = nullptr, double rs_in = 0.0, double *rs_out = nullptr) {
     static_assert(G == 1 || (G == 2 && (AMER == 0 || sizeof(T) == 8)), "paired strips: American sweeps with the fp64 state only");
     static_assert(MODE == 0 || (AMER == 0 && sizeof(T) == 8), "Craig-Sneyd: European sweeps, fp64 state");
+    static_assert(MODE != 3 || (G == 2 && !RSTAB), "MODE 3 builds the coupling-column table of the paired strips");
+    static_assert(!RSTAB || G == 2, "the coupling column exists on paired strips only");
     const int lane = c.lane, rowp = c.rowp;
     const int half = (G > 1) ? c.half : 0;
     // P representation: where the raw P of row j comes from -- its ring slot again (8 nodes per lane, one wavefront per row:
@@ -374,6 +389,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
         if constexpr (G > 1) {
             if (edge_hi) { rs = iu[B - 1]; rcc = 0.0; }  // couples to t = first node of the partner's half
             if (edge_lo) { rs = ra; ra = 0.0; }          // couples to the last node of the partner's half
+            // (RSTAB: rs is dead from here to the end of the reduction -- the stored image replaces it there)
         }
     }
     HADI_STAMPC(27);  // backward Thomas + reduced row
@@ -401,7 +417,7 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
             const double bn = fma(-rcc, aR, fma(-ra, cL, 1.0));
             const double rn = hadi_rcp(bn);
             rf = fma(-rcc, fR, fma(-ra, fL, rf)) * rn;
-            if constexpr (G > 1) {  // the second right-hand side (coupling to the partner's boundary node)
+            if constexpr (G > 1 && !RSTAB) {  // the second right-hand side (coupling to the partner's boundary node)
                 const double sL = (s == 1) ? hadi_lane_prev(rs) : hadi_lane_get(rs, up_lane);
                 const double sR = (s == 1) ? hadi_lane_next(rs) : (s == 32) ? sL : hadi_lane_get(rs, dn_lane);
                 rs = fma(-rcc, sR, fma(-ra, sL, rs)) * rn;
@@ -416,6 +432,13 @@ HADI_DEV HADI_FORCEINLINE void hadi_strip_step(const HadiStripCtxT<T> &c, int j,
     }
     HADI_STAMPC(28);  // PCR
     hadi_set_prio(0);
+    if constexpr (MODE == 3) {  // the table entry of this (row, half, lane); no exchange, no result
+        *rs_out = rs;
+#pragma unroll
+        for (int r = 0; r < B; r++) u_next[r] = 0.0;
+        return;
+    }
+    if constexpr (RSTAB) rs = rs_in;
     // the next row (this step's "row ahead") again from its ring slot, intact until the next step: issued here so that the
     // read flies during the final combination and the stores instead of being waited for at the end of the step
     hadi_get_block<B, G, T>(next_row, half, lane, u_next);
@@ -510,6 +533,16 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
     static_assert(sizeof(T) == 8 || AMER == 0, "the fp32-state sweep is European only");
     static_assert(G == 1 || (G == 2 && B == 8), "paired strips: 8 nodes per lane");
     static_assert(MODE == 0 || (AMER == 0 && sizeof(T) == 8), "Craig-Sneyd: European sweeps, fp64 state");
+    static_assert(MODE != 3 || G == 2, "MODE 3: the coupling-column table of the paired strips");
+    // paired strips: the pair's coupling column from the table MODE 3 built at the start of the solve (hadi_strip_step, RSTAB)
+#ifndef HADI_PAIR_RSTAB
+#define HADI_PAIR_RSTAB 1
+#endif
+    // (not the P representation: that kernel sits at 256 VGPRs, and the two registers the table entry keeps across the step
+    // sent six others to scratch -- a scratch reload inside the row loop drains the DMA prefetch)
+    // ... and not the explicit (U, lambda_bar) pair either: measured 3 % SLOWER there (its lambda_bar rows are register loads of the
+    // compiler already; one more shifts its waits) -- European sweeps, both state precisions (profiles/r04_pair_spike_ab.txt)
+    constexpr bool RSTAB = (G == 2 && MODE == 0 && AMER == 0 && HADI_PAIR_RSTAB);
     HADI_DYN_SMEM(double, smem);
     constexpr int NS = HADI_STRIP_NS(B, G, (int)sizeof(T)), NWV = HADI_STRIP_WAVES(B), NPAIR = NWV / G, c0slot = 64 * B * G;
     // American P representation at 8 nodes per lane: one slot stays BEHIND the prefetch -- row j itself, whose raw P the step
@@ -613,6 +646,9 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
                 if (k + 2 < q) aft[k] += zq;
         }
     }
+    double rs_next = 0.0;  // RSTAB: the table entry of the NEXT step's row (an ordinary load, requested a step ahead: hadi_cs_row_load)
+    const double *rs_lane = (RSTAB || MODE == 3) ? a.rs_tab + ((size_t)inst * nrows * 2 + half) * 64 + lane : nullptr;  // + 128 j
+    if constexpr (RSTAB) rs_next = hadi_nt_load(rs_lane + (size_t)(has_strip ? js : 0) * 128);
     HadiCsRow<B> cs_next;  // MODE 2: R1 / C2 of the NEXT step's row (requested a step ahead)
     if constexpr (MODE == 2) {
         const size_t ro = (size_t)(has_strip ? js : 0) * rowp;
@@ -754,6 +790,23 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
         // the prologue -- keeps 24 scalar registers live across the loop edge; at 106 SGPRs the compiler parks them in VGPR
         // lanes (two variants even spill to scratch): row pass +1.2 % at 33-row strips, +3 % at 9 rows, +6.5 % on paired strips)
         hadi_sload_issue(a.rowc + ((size_t)inst * nrows + j) * HADI_RC + HADI_SRC0, srow);  // flies during the DMA wait
+        double rs_cur = 0.0;
+        if constexpr (RSTAB) {
+            rs_cur = rs_next;  // (the compiler's wait for the load of a step ago sits here, in front of this step's loads and DMA)
+            int nl = 0;
+#if !defined(HADI_EMU)
+            asm volatile("" : "+v"(rs_cur) :: "memory");
+#endif
+            if (t + 1 < cnt) {
+                rs_next = hadi_nt_load(rs_lane + (size_t)(j + dir) * 128);  // (non-temporal: 33 MB of table per step must not displace Y from the memory-side cache -- the column pass ran 4 % slower with default-policy loads here)
+                nl = 1;
+            }
+#if !defined(HADI_EMU)
+            asm volatile("" ::: "memory");
+#endif
+#pragma unroll
+            for (int k = 0; k < NA; k++) aft[k] += nl;
+        }
         HadiCsRow<B> csrow;
         if constexpr (MODE == 2) {
             csrow = cs_next;  // (the compiler's own wait for the loads of a step ago sits in front of their first use)
@@ -840,10 +893,12 @@ __global__ void __launch_bounds__(64 * HADI_STRIP_WAVES(B), (B >= 8 ? 2 : B == 4
                 xb_ = fmax(xb_, pay_e); x0_ = fmax(x0_, pay_e); xa_ = fmax(xa_, pay_e);
             }
         }
-        if (MODE != 2 && j == nrows - 1) hadi_strip_step<B, AMER, (MODE != 2), T, G, CREG, MODE>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_, slot(j), payl, cf, &csrow);
-        else hadi_strip_step<B, AMER, false, T, G, CREG, MODE>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_, slot(j), payl, cf, &csrow);
-        // the row's vector stores (the i = 0 stores are not counted: lower bound); the predictor stores R1 and C2 as well
-        constexpr int NST = (MODE == 1 ? 3 : 1) * hadi_put_block_stores<B, T>();
+        double *rs_out = (MODE == 3) ? const_cast<double *>(rs_lane) + (size_t)j * 128 : nullptr;
+        if (MODE < 2 && j == nrows - 1) hadi_strip_step<B, AMER, (MODE < 2), T, G, CREG, MODE, RSTAB>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_, slot(j), payl, cf, &csrow, rs_cur, rs_out);
+        else hadi_strip_step<B, AMER, false, T, G, CREG, MODE, RSTAB>(c, j, rt, dm2, dm1, u0, up1, up2, e0m2, e0m1, e00, e0p1, e0p2, praw, lamc0, slot(j + dir), un, xb_, x0_, xa_, slot(j), payl, cf, &csrow, rs_cur, rs_out);
+        // the row's vector stores (the i = 0 stores are not counted: lower bound); the predictor stores R1 and C2 as well; the
+        // table build (MODE 3) stores one double per lane (counted as nothing: lower bound)
+        constexpr int NST = (MODE == 3 ? 0 : MODE == 1 ? 3 : 1) * hadi_put_block_stores<B, T>();
 #pragma unroll
         for (int k = 0; k < NA; k++) aft[k] += NST;
         double enew = 0.0;

@@ -273,6 +273,9 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
     if (american) emu::launch(8, 64, [&]() { hadi_payoff_shape_kernel(L, n_inst, dU0.data(), pay_mis.data()); });
     std::vector<double> dW(pl.row_seq ? st : 0);
     a.R1 = cs ? dR1.data() : pl.row_seq ? dW.data() : nullptr; a.C2 = cs ? dC2.data() : nullptr;
+    const bool pair_tab = pl.L.G == 2 && !cs && !pl.row_seq && pl.use_strip;  // as hadi_api.hip: the pairs' coupling column, built once
+    std::vector<double> dRS(pair_tab ? (size_t)n_inst * pl.L.nrows * 128 : 0, std::nan(""));
+    a.rs_tab = pair_tab ? dRS.data() : nullptr;
     HadiSweepArgs av = a;
     if (cs) av.U = dV.data();
 
@@ -327,6 +330,9 @@ extern "C" int emu_solve(int n_inst, int m1, int m2, int N, double dt, double th
         if (american && lam_out) emu::launch(8, 64, [&]() { hadi_unpack_kernel(L, n_inst, dLAM.data(), lam_out); });
         return 0;
     }
+    if (pair_tab)  // (before any sweep of the streaming path, as hadi_api.hip does at the start of a sub-batch's time loop)
+        emu::launch(pl.grid_as, 512, [&]() { hadi_pass_a_strip<8, 0, double, 2, 3>(a, 1); },
+                    (size_t)4 * HADI_STRIP_NS(8, 2, 8) * pl.L.rowp * sizeof(double) + ((size_t)4 * 64 * 8 * 2 + (size_t)4 * 16) * sizeof(double));
     if (f32) {  // round the packed state to float, sweep on float arrays, widen again
         std::vector<float> fU(st), fY(st, 0.0f);
         emu::launch(8, 64, [&]() { hadi_narrow_kernel(L, dU.data(), fU.data(), st); });

@@ -42,7 +42,7 @@ def test_python_mirrors_match_the_source():
     k = "".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)) if f.startswith("hadi_k"))
     c = open(os.path.join(csrc, "hadi_core.h")).read()
     assert "return B == 1 ? 1 : (sizeof(T) == 4 && B >= 4) ? B / 4 : B / 2;" in k
-    assert "constexpr int NST = (MODE == 1 ? 3 : 1) * hadi_put_block_stores<B, T>();" in k      # strips (Craig-Sneyd predictor: + R1, C2)
+    assert "constexpr int NST = (MODE == 3 ? 0 : MODE == 1 ? 3 : 1) * hadi_put_block_stores<B, T>();" in k      # strips (Craig-Sneyd predictor: + R1, C2; table build: none counted)
     assert "for (int k = 0; k < NA; k++) aft[k] += NST;" in k
     assert "for (int k = 0; k < PD; k++) ya[k] += hadi_put_block_stores<B, T>();" in k       # shared ring
     assert "#define HADI_ROW_PAD(B, ES) ((B) < 4 ? 8 : ((ES) == 4 ? 32 : 16))" in c
@@ -75,7 +75,8 @@ def test_strip_kernels_issue_at_least_the_stores_and_exactly_the_dma_pieces_the_
         assert n_dma == sites * pieces, (name, n_dma)
         # hadi_strip_step is instantiated twice (last v-row or not): each copy stores the row block once; the Craig-Sneyd
         # predictor (mode 1) stores R1 and C2 as well, the corrector (mode 2) has one copy of the step
-        assert n_st >= (6 if mode == 1 else 1 if mode == 2 else 2) * STORES(B, es), (name, n_st)
+        # (mode 3 -- the table of the pairs' coupling column -- stores one double per lane and nothing the waits count)
+        assert n_st >= (6 if mode == 1 else 1 if mode == 2 else 0 if mode == 3 else 2) * STORES(B, es), (name, n_st)
         if mode == 2:
             # the corrector's R1 / C2 rows: ordinary register loads of the compiler, B / 2 per row and array at two sites
             # (prologue, loop) -- the counted waits of the DMA ring add them as a lower bound -- plus the prologue's three
@@ -150,26 +151,74 @@ def test_row_table_entries_in_flight_are_not_touched_before_their_wait(kernels):
     FLIGHT -- values the compiler believes ready.  If it ever copied or parked them there (live-range splitting, SGPR pressure:
     v_writelane spills), the copy would be stale; that is exactly what happened to the VECTOR registers of round 4's first
     Craig-Sneyd corrector.  So: in every kernel, no instruction between one of our load triples and the
-    first lgkmcnt(0) wait behind it IN THE TEXT (any such wait retires them; the code in between has forward branches only -- the
-    vmcnt switch, the conditional fetch -- so the text order covers every path) may name a register of the three octets."""
+    first lgkmcnt(0) wait behind it (any such wait retires them) may name a register of the three octets -- on EVERY path: the
+    code in between branches (the vmcnt switch, the conditional fetch, the back edge of a rotated loop), so the test walks the
+    control flow from the triple."""
     seen = 0
     for name, body in kernels["__all__"].items():
         lines = [l.split(";")[0].strip() for l in body.split("\n")]
-        lines = [l for l in lines if l and not l.endswith(":") and not l.startswith(".")]
-        i = 0
-        while i + 2 < len(lines):
+        lines = [l for l in lines if l and (l.endswith(":") or not l.startswith("."))]
+        label = {l[:-1]: k for k, l in enumerate(lines) if l.endswith(":")}
+        for i in range(len(lines) - 2):
             trip = lines[i:i + 3]
-            if all(t.startswith("s_load_dwordx8") for t in trip) and [t.rsplit(",", 1)[1].strip() for t in trip] == ["0x0", "0x20", "0x40"]:
-                dst = set()
-                for t in trip:
-                    dst |= _sregs(t.split(",")[0])
-                assert len(dst) == 24, (name, trip)
-                k = i + 3
-                while k < len(lines) and not re.search(r"s_waitcnt\b.*lgkmcnt\(0\)", lines[k]):
-                    assert not (_sregs(lines[k]) & dst), (name, lines[k], sorted(dst))
+            if not (all(t.startswith("s_load_dwordx8") for t in trip) and [t.rsplit(",", 1)[1].strip() for t in trip] == ["0x0", "0x20", "0x40"]):
+                continue
+            dst = set()
+            for t in trip:
+                dst |= _sregs(t.split(",")[0])
+            assert len(dst) == 24, (name, trip)
+            # every path from behind the triple to the first lgkmcnt(0) wait (forward branches, and the back edge of a rotated loop)
+            todo, visited = [i + 3], set()
+            while todo:
+                k = todo.pop()
+                while k not in visited:
+                    visited.add(k)
+                    assert k < len(lines), name
+                    ln = lines[k]
+                    if re.search(r"s_waitcnt\b.*lgkmcnt\(0\)", ln):
+                        break
+                    assert not ln.startswith("s_endpgm"), (name, "a path leaves the kernel with the loads in flight")
+                    if not ln.endswith(":"):
+                        assert not (_sregs(ln) & dst), (name, ln, sorted(dst))
+                    m = re.match(r"s_(c?branch)\w*\s+(\S+)", ln)
+                    if m:
+                        todo.append(label[m.group(2)])
+                        if m.group(1) == "branch":
+                            break
                     k += 1
-                assert k < len(lines), name
-                seen += 1
-                i = k
-            i += 1
-    assert seen >= 25   # (strip kernels, pair strips with two entries per step, the instance-resident launch)
+            seen += 1
+    assert seen >= 25
+
+
+def test_pair_strip_kernels_issue_the_dma_pieces_and_stores_the_waits_count(kernels):
+    """hadi_pass_a_pairs: HADI_PAIR_DMA = 6 LDS-DMA instructions per fetch (four 1 KiB pieces of both rows + the two 128-byte
+    tails), five fetch sites (the first row and the rows 1 .. 3 ahead in the prologue, one in the loop; the P representation
+    keeps the first row's slot and has the rows 1 .. 2 ahead: four), HADI_PAIR_STORES = 4 counted row stores per step (one
+    copy of the step)."""
+    csrc = os.path.join(ROOT, "pde_based_heston_solver_gpu_accelerated_amd", "csrc")
+    k = "".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)) if f.startswith("hadi_k"))
+    assert "#define HADI_PAIR_DMA 6" in k and "#define HADI_PAIR_STORES 4" in k
+    seen = 0
+    for name, body in kernels.items():
+        if not name.startswith("hadi_pass_a_pairs<"):
+            continue
+        n_dma = len(re.findall(r"\bglobal_load_lds_dwordx4\b", body))
+        n_st = len(re.findall(r"\bglobal_store_dwordx4\b", body))
+        assert n_dma == (4 if _args(name)[0] == "2" else 5) * 6, (name, n_dma)
+        assert n_st >= 4, (name, n_st)
+        seen += 1
+    assert seen == 3
+
+
+def test_no_row_kernel_with_counted_waits_touches_scratch(kernels):
+    """The counted `s_waitcnt vmcnt(n)` of the strip and pair-strip kernels know the LDS-DMA pieces and the result stores of a
+    row step and nothing else: a register spilled into scratch is reloaded by a vector-memory operation inside the row loop
+    that the count does not include -- the wait would pass with a DMA piece still in flight (and, at best, the reload drains
+    the prefetch).  No such kernel may have a scratch segment or a spilled VGPR (compiler metadata, tools/kernel_regs.py)."""
+    seen = 0
+    for name, vgpr, sgpr, spills, scratch, lds in kernels["__rows__"]:
+        if "hadi_pass_a_strip<" in name or "hadi_pass_a_pairs<" in name:
+            assert spills == 0 and scratch == 0, (name, vgpr, spills, scratch)
+            assert vgpr <= 256
+            seen += 1
+    assert seen >= 17
