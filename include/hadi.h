@@ -197,7 +197,9 @@ int hadi_get_timing(const hadi_ctx *ctx, hadi_timing *out);
  *                 fill whole rounds (64, 128, 256, 512 instances): the automatic choice cuts the batch (or the remainder
  *                 behind its full rounds of one instance per CU) in two exactly when the plan's row pass leaves 4 % or more
  *                 of its CU-rounds idle (hadi_plan_row_idle) -- a function of the grid shape and the batch size alone.
- *                 With 2 the sub-batches of a large batch alternate between the streams; DESIGN.md section 7
+ *                 With 2 the sub-batches of a large batch alternate between the streams -- and so they do in the automatic mode
+ *                 when a batch is several sub-batches of strip launches (measured never slower, +3 .. +6 % with a remainder behind
+ *                 one full round); DESIGN.md sections 4.2, 7
  *   "col_prefetch" 0 (default) / 1: European sweeps of 9 .. 16 chunks (264 <= m2 <= 527) on hadi_pass_b2 -- part of the next column
  *                 tile prefetched into LDS by LDS-DMA -- instead of hadi_pass_b1; "tile_interleave" 0 (default) / 1: the blocks of
  *                 an instance walk their column tiles interleaved.  Both measured within +-2 % (profiles/r04_colpass_ab.txt);

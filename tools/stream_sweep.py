@@ -23,6 +23,9 @@ if not quick:
     CASES += [("g200", 200, 100, 200, n, "EU") for n in (200, 700)]
     CASES += [("c5", 1024, 512, 100, n, "EU") for n in (16, 32, 48, 64, 96, 128)]
     CASES += [("am512", 512, 256, 200, n, "AM") for n in (96, 160, 192, 256)]
+if "big" in sys.argv[1:]:   # batches of several sub-batches (whole rounds of one instance per CU plus a remainder)
+    CASES = [("c2", 512, 256, 100, n, "EU") for n in (320, 384, 448, 512, 600, 640, 768, 1024)] + \
+            [("am512", 512, 256, 100, n, "AM") for n in (320, 384, 512, 640)] + [("c5", 1024, 512, 40, n, "EU") for n in (320, 384)]
 if ring:
     CASES = [("c2", 512, 256, 200, n, "EU") for n in (16, 24, 32, 48, 96)] + [("c3", 256, 128, 200, n, "AM_DIV") for n in (128, 300, 384)] + \
             [("g256", 256, 128, 200, n, "EU") for n in (100, 200, 300)] + [("g200", 200, 100, 200, n, "EU") for n in (200, 400, 700)] + \
