@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""GPU campaign with the EMULATOR's random generator (tests/test_emu_kernel_logic.py::_random_case): shapes of every class, the
+four variants, Craig-Sneyd, fp32 state, P representation / explicit pair, put data, and the kernel-selection keys the library
+offers (strip, pair_strips, strip_blocks, cs_strips, col_prefetch, tile_interleave) -- through the C ABI on the GPU, full field
+(and lambda_bar) against the oracle.  tools/fuzz_parity.py is the frozen campaign; this one adds the keys and Craig-Sneyd.
+    python tools/gpu_sweep.py [first_seed] [seeds] [instances]     (30 cases per seed)"""
+import os, sys, random
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import pde_based_heston_solver_gpu_accelerated_amd as H
+from oracle import oracle as O
+import common as Cm
+import test_emu_kernel_logic as T
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 700
+seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+n_over = int(sys.argv[3]) if len(sys.argv) > 3 else 0     # > 0: that many instances per case instead of the generator's 1 .. 3
+s = H.HestonADI(0)
+RESET = {"strip": -1, "pair_strips": -1, "strip_blocks": 0, "cs_strips": 1, "col_prefetch": 0, "tile_interleave": 0, "american_p": 1}
+VAR = {O.EU: H.EU, O.AM: H.AM, O.DIV: H.DIV, O.AM_DIV: H.AM_DIV}
+bad = total = 0
+worst = 0.0
+for seed in range(first, first + seeds):
+    rng = random.Random(9000 + seed)
+    for k in range(30):
+        c = T._random_case(rng)
+        if c["small"] == 4:
+            c["tuning"] = {}                      # (team_blocks is an emulator key; the library forms its teams itself)
+        if n_over:
+            c["strikes"] = [rng.uniform(85, 115) for _ in range(n_over)]
+        # well-conditioned s-grids only (the frozen rule of tools/fuzz_parity.py sends the others to the binary128 adjudicator): every
+        # strike whose grid has neighbouring intervals more than 30x apart is drawn again, one by one
+        for _ in range(200):
+            d = np.diff(Cm.oracle_grids(c["m1"], 8, c["strikes"])[0], axis=1)
+            ratio = np.maximum(d[:, 1:] / d[:, :-1], d[:, :-1] / d[:, 1:]).max(axis=1)
+            if ratio.max() <= 30.0: break
+            c["strikes"] = [k if r <= 30.0 else rng.uniform(85, 115) for k, r in zip(c["strikes"], ratio)]
+        else:
+            raise SystemExit("could not draw well-conditioned strikes")
+        m1, m2, N, ks, var, scheme, put = c["m1"], c["m2"], c["N"], c["strikes"], c["variant"], c["scheme"], c["put"]
+        if scheme == 3 and rng.random() < 0.0: pass
+        tun = dict(c["tuning"])
+        if var in (O.AM, O.AM_DIV) and scheme != 3: tun["american_p"] = 0      # (scheme 3 = P representation, otherwise the explicit pair)
+        grids = H.GridViewsBatch.for_strikes(m1, m2, Cm.S_0, Cm.V_0, ks)
+        U0 = grids.put_payoff(ks) if put else grids.call_payoff(ks)
+        p = Cm.oracle_params(m1, m2, N, var, r_f=c["r_f"], option_type=O.PUT if put else O.CALL, strikes=np.array(ks) if put else None)
+        p.scheme = 1 if scheme == 1 else 0
+        p.state_fp32 = 1 if scheme == 2 else 0
+        Uo, lamo, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0, want_lambda=True)
+        for key, val in tun.items(): s.set_tuning(key, val)
+        try:
+            U, lam = U0.copy(), np.zeros_like(U0)
+            american = var in (O.AM, O.AM_DIV)
+            args = (m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, c["r_f"], Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids)
+            if scheme == 1:
+                s.CS_scheme(*args, U)
+            else:
+                kw = dict(variant=VAR[var], U_0=U0, lambda_bar=lam if american else None,
+                          dividends=H.Dividends(*Cm.DIVS) if var in (O.DIV, O.AM_DIV) else None,
+                          state_precision=H.STATE_FP32 if scheme == 2 else H.STATE_FP64)
+                if put: kw.update(option_type=H.PUT, strikes=ks)
+                s.DO_timestepping(*args, U, **kw)
+            path = s.describe_last_sweep()
+        finally:
+            for key in tun: s.set_tuning(key, RESET[key])
+        scale = np.abs(Uo).max()
+        err = np.abs(U - Uo).max() / scale
+        tol = 2e-7 * N if scheme == 2 else 1e-10
+        lerr = (np.abs(lam - lamo).max() / max(1.0, np.abs(lamo).max())) if (american and lamo is not None) else 0.0
+        ok = err <= tol and lerr <= 1e-8
+        if scheme != 2: worst = max(worst, err)
+        total += 1
+        verdict = ""
+        if not ok and scheme != 2:
+            # the binary128 adjudicator on the worst instance (tools/fuzz_parity.py): how far libhadi and the fp64 oracle each are
+            # from the scheme's exact result
+            per = np.abs(U - Uo).max(axis=1) / scale
+            if american and lamo is not None:
+                per = per + np.abs(lam - lamo).max(axis=1) / max(1.0, np.abs(lamo).max())
+            kk = int(per.argmax())
+            Ux, lx = O.solve_xp(p, grids.Vec_s[kk], grids.Vec_v[kk], grids.Delta_s[kk], grids.Delta_v[kk], U0[kk], U0[kk], strike=ks[kk] if put else None)
+            sc = np.abs(Ux).max()
+            verdict = " | exact (instance %d): hadi %.2e oracle %.2e" % (kk, np.abs(U[kk] - Ux).max() / sc, np.abs(Uo[kk] - Ux).max() / sc)
+            if lx is not None:
+                sl = max(1.0, np.abs(lx).max())
+                verdict += ", lambda_bar hadi %.2e oracle %.2e (max |lambda_bar| %.3g)" % (np.abs(lam[kk] - lx).max() / sl, np.abs(lamo[kk] - lx).max() / sl, np.abs(lx).max())
+        if not ok:
+            bad += 1
+        print("%s %d/%d m1=%d m2=%d N=%d n=%d var=%d scheme=%d put=%d r_f=%.2f %s err=%.2e lam=%.2e | %s" % (
+            "ok " if ok else "BAD", seed, k, m1, m2, N, len(ks), var, scheme, put, c["r_f"], tun, err, lerr, path[:110]) + verdict, flush=True)
+print("%d bad of %d, worst fp64 field error %.2e" % (bad, total, worst))
