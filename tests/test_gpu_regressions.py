@@ -124,6 +124,36 @@ def test_fuzz_seed331_case358_fp32_state_on_an_ill_conditioned_wide_grid(solver)
     assert ok, j
 
 
+def test_gpu_sweep_seed1052_case1_tall_grid_american_lambda_bar(solver):
+    """Outside the bounds in round 4's second campaign (tools/gpu_sweep.py 1052 1, case 1): one American call on a 102 x 432 grid
+    -- taller than anything the frozen generator of tools/fuzz_parity.py draws: 14 column chunks -- P representation on forced
+    strips, 3 steps.  lambda_bar 1.4e-8 against the oracle (bound 1e-8), field 5.3e-11.  Adjudicated (binary128): libhadi 3.9e-10
+    from the exact field where the oracle is 3.9e-10, lambda_bar 2.8e-8 where the oracle is 3.3e-8 -- the tall grid's own
+    round-off, in both solvers alike.  Pinned as that relation: libhadi within 3x of the oracle's own distance from exact."""
+    from oracle import oracle as O
+    m1, m2, N, ks = 102, 432, 3, [86.33639475947474]
+    grids = H.GridViewsBatch.for_strikes(m1, m2, Cm.S_0, Cm.V_0, ks)
+    U0 = grids.call_payoff(ks)
+    p = Cm.oracle_params(m1, m2, N, O.AM, r_f=0.0)
+    Uo, lo, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0, want_lambda=True)
+    U, lam = U0.copy(), np.zeros_like(U0)
+    solver.set_tuning("strip", 1)
+    try:
+        solver.DO_timestepping(m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, 0.0, Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids, U,
+                               variant=H.AM, U_0=U0, lambda_bar=lam)
+        path = solver.describe_last_sweep()
+    finally:
+        solver.set_tuning("strip", -1)
+    assert "hadi_pass_a_strip<2,AM-P>" in path and "hadi_pass_b1<16,AM-P>" in path, path
+    Ux, lx = O.solve_xp(p, grids.Vec_s[0], grids.Vec_v[0], grids.Delta_s[0], grids.Delta_v[0], U0[0], U0[0])
+    sc, sl = np.abs(Ux).max(), max(1.0, np.abs(lx).max())
+    hadi_U, oracle_U = np.abs(U[0] - Ux).max() / sc, np.abs(Uo[0] - Ux).max() / sc
+    hadi_l, oracle_l = np.abs(lam[0] - lx).max() / sl, np.abs(lo[0] - lx).max() / sl
+    assert hadi_U < max(3 * oracle_U, 1e-11), (hadi_U, oracle_U)
+    assert hadi_l < max(3 * oracle_l, 1e-9), (hadi_l, oracle_l)
+    assert np.abs(U - Uo).max() <= 1e-10 * np.abs(Uo).max()
+
+
 @pytest.mark.parametrize("strip", [1, 0])
 def test_rendezvous_timeout_fails_the_call(solver, strip):
     """The pair rendezvous of the two-wavefront rows (paired strips / shared ring, m1 > 512) polls a bounded number of

@@ -39,7 +39,7 @@ for seed in range(first, first + seeds):
         else:
             raise SystemExit("could not draw well-conditioned strikes")
         m1, m2, N, ks, var, scheme, put = c["m1"], c["m2"], c["N"], c["strikes"], c["variant"], c["scheme"], c["put"]
-        if scheme == 3 and rng.random() < 0.0: pass
+        if scheme == 3: rng.random()   # (a draw the first campaign consumed here: kept so that its recorded (seed, case) pairs stay the same problems)
         tun = dict(c["tuning"])
         if var in (O.AM, O.AM_DIV) and scheme != 3: tun["american_p"] = 0      # (scheme 3 = P representation, otherwise the explicit pair)
         grids = H.GridViewsBatch.for_strikes(m1, m2, Cm.S_0, Cm.V_0, ks)
