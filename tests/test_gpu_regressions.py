@@ -128,8 +128,11 @@ def test_gpu_sweep_seed1052_case1_tall_grid_american_lambda_bar(solver):
     """Outside the bounds in round 4's second campaign (tools/gpu_sweep.py 1052 1, case 1): one American call on a 102 x 432 grid
     -- taller than anything the frozen generator of tools/fuzz_parity.py draws: 14 column chunks -- P representation on forced
     strips, 3 steps.  lambda_bar 1.4e-8 against the oracle (bound 1e-8), field 5.3e-11.  Adjudicated (binary128): libhadi 3.9e-10
-    from the exact field where the oracle is 3.9e-10, lambda_bar 2.8e-8 where the oracle is 3.3e-8 -- the tall grid's own
-    round-off, in both solvers alike.  Pinned as that relation: libhadi within 3x of the oracle's own distance from exact."""
+    from the exact field where the oracle is 3.9e-10, lambda_bar 2.8e-8 where the oracle is 3.3e-8 -- round-off in both solvers
+    alike, and the larger campaign (11 400 cases) said whose: ALL its outliers sit on m2 = 432, the one v-grid size whose V_0 =
+    0.04 is inserted 2.4e-8 beside a node (v-intervals 2.8e4 x apart; 2.5 .. 3.8 x at every other size tried): the column
+    operator's twin of the ill-conditioned s-grids of DESIGN.md section 2.  Pinned as the adjudicated relation: libhadi within 3x
+    of the oracle's own distance from exact."""
     from oracle import oracle as O
     m1, m2, N, ks = 102, 432, 3, [86.33639475947474]
     grids = H.GridViewsBatch.for_strikes(m1, m2, Cm.S_0, Cm.V_0, ks)
