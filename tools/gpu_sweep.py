@@ -3,7 +3,7 @@
 four variants, Craig-Sneyd, fp32 state, P representation / explicit pair, put data, and the kernel-selection keys the library
 offers (strip, pair_strips, strip_blocks, cs_strips, col_prefetch, tile_interleave) -- through the C ABI on the GPU, full field
 (and lambda_bar) against the oracle.  tools/fuzz_parity.py is the frozen campaign; this one adds the keys and Craig-Sneyd.
-    python tools/gpu_sweep.py [first_seed] [seeds] [instances]     (30 cases per seed)"""
+    python tools/gpu_sweep.py [first_seed] [seeds] [instances] [wide]     (30 cases per seed; wide: also theta, r_f = r_d, model parameters)"""
 import os, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -13,9 +13,12 @@ from oracle import oracle as O
 import common as Cm
 import test_emu_kernel_logic as T
 
-first = int(sys.argv[1]) if len(sys.argv) > 1 else 700
-seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-n_over = int(sys.argv[3]) if len(sys.argv) > 3 else 0     # > 0: that many instances per case instead of the generator's 1 .. 3
+wide = "wide" in sys.argv[1:]   # also theta in {0.5, 0.8, 1}, r_f = r_d now and then, random model parameters (drawn from a second
+                                 # stream: the (seed, case) pairs of the recorded campaigns stay the same shapes)
+pos = [a for a in sys.argv[1:] if a != "wide"]
+first = int(pos[0]) if len(pos) > 0 else 700
+seeds = int(pos[1]) if len(pos) > 1 else 10
+n_over = int(pos[2]) if len(pos) > 2 else 0     # > 0: that many instances per case instead of the generator's 1 .. 3
 s = H.HestonADI(0)
 RESET = {"strip": -1, "pair_strips": -1, "strip_blocks": 0, "cs_strips": 1, "col_prefetch": 0, "tile_interleave": 0, "american_p": 1}
 VAR = {O.EU: H.EU, O.AM: H.AM, O.DIV: H.DIV, O.AM_DIV: H.AM_DIV}
@@ -23,6 +26,7 @@ bad = total = 0
 worst = 0.0
 for seed in range(first, first + seeds):
     rng = random.Random(9000 + seed)
+    rng2 = random.Random(77000 + seed)
     for k in range(30):
         c = T._random_case(rng)
         if c["small"] == 4:
@@ -44,7 +48,14 @@ for seed in range(first, first + seeds):
         if var in (O.AM, O.AM_DIV) and scheme != 3: tun["american_p"] = 0      # (scheme 3 = P representation, otherwise the explicit pair)
         grids = H.GridViewsBatch.for_strikes(m1, m2, Cm.S_0, Cm.V_0, ks)
         U0 = grids.put_payoff(ks) if put else grids.call_payoff(ks)
-        p = Cm.oracle_params(m1, m2, N, var, r_f=c["r_f"], option_type=O.PUT if put else O.CALL, strikes=np.array(ks) if put else None)
+        theta, r_f, model = Cm.THETA, c["r_f"], (Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA)
+        if wide:
+            theta = rng2.choice([0.5, 0.8, 0.8, 1.0])
+            if rng2.random() < 0.12: r_f = Cm.R_D      # (r_d = r_f: the strips' scaled convection weights do not exist -- shared ring)
+            model = (rng2.uniform(-0.95, 0.5), rng2.uniform(0.1, 0.8), rng2.uniform(0.3, 4.0), rng2.uniform(0.01, 0.2))
+        c["r_f"] = r_f
+        p = O.make_params(m1, m2, N, Cm.T / N, theta, Cm.R_D, r_f, *model, var, Cm.DIVS if var in (O.DIV, O.AM_DIV) else None,
+                          option_type=O.PUT if put else O.CALL, strikes=np.array(ks) if put else None)
         p.scheme = 1 if scheme == 1 else 0
         p.state_fp32 = 1 if scheme == 2 else 0
         Uo, lamo, _ = O.solve_batch(p, grids.Vec_s, grids.Vec_v, grids.Delta_s, grids.Delta_v, U0, U0, want_lambda=True)
@@ -52,7 +63,7 @@ for seed in range(first, first + seeds):
         try:
             U, lam = U0.copy(), np.zeros_like(U0)
             american = var in (O.AM, O.AM_DIV)
-            args = (m1, m2, N, Cm.T / N, Cm.THETA, Cm.R_D, c["r_f"], Cm.RHO, Cm.SIGMA, Cm.KAPPA, Cm.ETA, grids)
+            args = (m1, m2, N, Cm.T / N, theta, Cm.R_D, r_f, *model, grids)
             if scheme == 1:
                 s.CS_scheme(*args, U)
             else:
